@@ -1,0 +1,177 @@
+/*
+ * shark_hip.h -- C ABI of libsharkhip: the MI355X (gfx950) implementation of
+ * shark's k-mer classification hot path.
+ *
+ * shark (AlgoLab/shark) has no plugin/FFI interface; the seam this library
+ * replaces is the group of functor calls inside the two worker loops of
+ * main.cpp plus the BF methods they use.  Each entry point below cites the
+ * reference interface it stands in for (file:line relative to the reference
+ * tree).  Plain pointers and sizes only; no C++/torch types; every function
+ * returns 0 (SHK_OK) or a negative error code and never throws.
+ *
+ * Mode machine (bloomfilter.h:104-110): shk_ref_add* -> shk_ref_finalize ->
+ * shk_classify*; going backwards returns SHK_ERR_STATE.
+ *
+ * There is NO CPU fallback: without a HIP device every call that computes
+ * fails with SHK_ERR_HIP / SHK_ERR_NO_DEVICE.
+ */
+#ifndef SHARK_HIP_H
+#define SHARK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHK_OK                    0
+#define SHK_ERR_ARG              -1  /* bad argument (k outside [1,31], c outside [0,1], NULL, ...) */
+#define SHK_ERR_STATE            -2  /* call not allowed in the current mode */
+#define SHK_ERR_HIP              -3  /* HIP runtime error; text via shk_last_error */
+#define SHK_ERR_NOMEM            -4
+#define SHK_ERR_TOO_MANY_GENES   -5  /* > 65536 FASTA records: gene ids are uint16_t (small_vector.hpp:46) */
+#define SHK_ERR_INDEX_TOO_LARGE  -6  /* >= 2^31 set bits or list entries (int in bloomfilter.h:70,:130) */
+#define SHK_ERR_NO_DEVICE        -7
+
+#define SHK_INLINE_IDS 4             /* gene ids stored inline per read in the device result */
+
+typedef struct shk_ctx shk_ctx;
+
+/* argument_parser.hpp:49-63 (namespace opt) */
+typedef struct shk_params {
+  uint32_t k;            /* -k, default 17, range [1,31]      (:56, :112-121) */
+  double   c;            /* -c, default 0.6, range [0,1]      (:57, :122-129) */
+  uint64_t bf_bits;      /* filter size in BITS; -b N => N<<33 (:58, :130-134) */
+  int32_t  min_quality;  /* -q, 0 = no masking, max 94        (:59, :135-145) */
+  int32_t  single;       /* -s                                 (:60, :146-148) */
+  int32_t  device;       /* HIP device ordinal */
+} shk_params;
+
+/* BF::BF(size) bloomfilter.h:48-53 + ReadAnalyzer ctor ReadAnalyzer.hpp:36-37 */
+int  shk_create(const shk_params *params, shk_ctx **out);
+void shk_destroy(shk_ctx *ctx);
+const char *shk_strerror(int code);
+const char *shk_last_error(const shk_ctx *ctx);
+
+/* ---- index build -------------------------------------------------------- */
+/* One FASTA record, in FILE ORDER, including records shorter than k and
+ * records without any valid k-mer (the library reproduces main.cpp:162-186's
+ * gene numbering, quirk included).  Stands in for
+ *   FastaSplitter::operator()   FastaSplitter.hpp:42-54  (record order = legend order)
+ *   KmerBuilder::operator()     KmerBuilder.hpp:40-72
+ *   BloomfilterFiller::operator() BloomfilterFiller.hpp:38-46 / BF::add_at bloomfilter.h:57-59
+ *   pass 2 + BF::add_to_kmer    main.cpp:154-189, bloomfilter.h:61-75
+ * The sequence bytes are only buffered here; all k-mer work happens on the
+ * device in shk_ref_finalize. */
+int shk_ref_add(shk_ctx *ctx, const char *seq, uint64_t len);
+
+/* BF::switch_mode(1) + switch_mode(2)  bloomfilter.h:111-188, main.cpp:148,:193.
+ * Runs on the device: canonical k-mers -> XXH64 -> bit set; rank directory;
+ * (set bit -> ascending unique gene id list) CSR. */
+int shk_ref_finalize(shk_ctx *ctx);
+
+typedef struct shk_index_info {
+  uint64_t n_records;    /* FASTA records added (= legend_ID.size(), FastaSplitter.hpp:48) */
+  uint64_t nidx;         /* final gene counter (main.cpp:191) */
+  uint64_t bf_bits;
+  uint64_t n_set_bits;   /* num_kmer, bloomfilter.h:122 */
+  uint64_t tot_idx;      /* _index_kmer.size(), bloomfilter.h:130-133 */
+  uint64_t n_ref_kmers;  /* valid reference k-mer occurrences hashed */
+} shk_index_info;
+int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
+
+/* Parity introspection: copy the device-resident index to host buffers.
+ * words: (bf_bits+63)/64 uint64_t in sdsl::bit_vector layout, bit i =
+ * (words[i>>6] >> (i&63)) & 1 (bloomfilter.h:51,:58,:89).
+ * offsets[n_set_bits+1] / ids[tot_idx]: list r (the r-th set bit, r = rank)
+ * is ids[offsets[r]..offsets[r+1]) -- the explicit form of _bv/_select_bv/
+ * _index_kmer (bloomfilter.h:142-167). */
+int shk_index_copy_bf(const shk_ctx *ctx, uint64_t *words, uint64_t n_words);
+int shk_index_copy_lists(const shk_ctx *ctx, uint32_t *offsets, uint16_t *ids);
+
+/* ---- classification ------------------------------------------------------ */
+/* A batch of reads as structure-of-arrays.  Mate 1 of read i is
+ * seq1[off1[i] .. off1[i+1]); seq2/off2 NULL => single-end.  qual1/qual2 use
+ * the same offsets and may be NULL when min_quality == 0.  The mate join
+ * ("N", FastqSplitter.hpp:63) and the quality mask (FastqSplitter.hpp:70,
+ * :104-109) are applied ON THE DEVICE; the caller passes raw FASTQ fields. */
+typedef struct shk_batch {
+  uint64_t        n;
+  const char     *seq1;
+  const uint64_t *off1;   /* n+1 */
+  const char     *seq2;
+  const uint64_t *off2;   /* n+1 */
+  const char     *qual1;
+  const char     *qual2;
+} shk_batch;
+
+/* Associations per read: read i belongs to genes
+ * gene_ids[gene_off[i] .. gene_off[i+1]) (ascending), the indices the
+ * reference passes to legend_ID[] at ReadAnalyzer.hpp:106.  Buffers are owned
+ * by the context and stay valid until the next shk_classify* call on it. */
+typedef struct shk_result {
+  uint64_t        n;
+  const uint32_t *gene_off;  /* n+1 */
+  const uint16_t *gene_ids;  /* gene_off[n] */
+  uint64_t        n_assoc;
+} shk_result;
+
+/* ReadAnalyzer::operator()(const vector<elem_t>&, vector<assoc_t>&) const
+ * ReadAnalyzer.hpp:39-110 over host buffers (H2D, kernels, D2H). */
+int shk_classify(shk_ctx *ctx, const shk_batch *batch, shk_result *result);
+
+/* Same, for inputs ALREADY RESIDENT IN HBM: every pointer in `batch` is a
+ * device pointer; the result pointers returned in `result` are DEVICE
+ * pointers owned by the context.  max_read_len is an upper bound on the
+ * longest mate (0 = unknown); it only selects the kernel specialisation --
+ * reads that do not fit are routed to the general kernel, never dropped.
+ * Work is enqueued on the context's stream and the call returns after the
+ * stream has drained. */
+int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_len, shk_result *result);
+
+/* Per-gene number of assigned reads accumulated over all classify calls since
+ * the last reset (counts[g] for g in [0, 65536)); the quantity all-reduced
+ * across GPUs.  n must be <= 65536. */
+int shk_gene_counts(shk_ctx *ctx, uint64_t *counts, uint32_t n);
+int shk_gene_counts_reset(shk_ctx *ctx);
+
+/* ---- measurement --------------------------------------------------------- */
+/* HIP-event timing of the dominant kernel (classify) on the context's own
+ * stream.  enable=1 starts recording one event pair per launch. */
+int shk_timing_enable(shk_ctx *ctx, int enable);
+/* n_launches classify-kernel launches since enable, their summed duration,
+ * and the algorithmic work counters of the LAST classify call. */
+typedef struct shk_timing {
+  uint64_t n_launches;
+  double   total_ms;
+  uint64_t last_n_reads;     /* pairs (or single reads) in the last call */
+  uint64_t last_n_long;      /* reads routed to the general kernel */
+  uint64_t last_n_tie;       /* reads with more than SHK_INLINE_IDS genes */
+  uint64_t last_n_assoc;
+} shk_timing;
+int shk_timing_get(shk_ctx *ctx, shk_timing *t);
+
+/* Exact per-call work counters for the roofline's algorithmic-byte formula
+ * (SURVEY.md 8d): counts k-mers probed, probes that hit, and gene-list
+ * entries read during the NEXT classify call when enabled (a separate,
+ * slower kernel build is used; never enabled in timed runs). */
+typedef struct shk_work_counters {
+  uint64_t n_kmers;      /* valid k-mers probed */
+  uint64_t n_hits;       /* probes whose bit was set */
+  uint64_t n_list_ids;   /* sum of list lengths over hits */
+  uint64_t n_bases;      /* input base bytes consumed */
+} shk_work_counters;
+int shk_count_work(shk_ctx *ctx, const shk_batch *dev_batch, shk_work_counters *out);
+
+/* pinned host memory helpers for callers that stream batches */
+void *shk_alloc_pinned(size_t bytes);
+void  shk_free_pinned(void *p);
+
+/* library / build identification */
+const char *shk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,212 @@
+"""ctypes binding of libsharkhip.so (include/shark_hip.h).
+
+Plumbing for tests and bench.py; the product is the C ABI itself.  There is no
+fallback of any kind: if the HIP library is missing this module raises, and if
+no GPU is present every computing call returns an error that is raised here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsharkhip.so")
+
+SHK_INLINE_IDS = 4
+
+
+class ShkParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("c", C.c_double), ("bf_bits", C.c_uint64),
+                ("min_quality", C.c_int32), ("single", C.c_int32), ("device", C.c_int32)]
+
+
+class ShkIndexInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("nidx", C.c_uint64), ("bf_bits", C.c_uint64),
+                ("n_set_bits", C.c_uint64), ("tot_idx", C.c_uint64), ("n_ref_kmers", C.c_uint64)]
+
+
+class ShkBatch(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("seq1", C.c_void_p), ("off1", C.c_void_p), ("seq2", C.c_void_p),
+                ("off2", C.c_void_p), ("qual1", C.c_void_p), ("qual2", C.c_void_p)]
+
+
+class ShkResult(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("gene_off", C.c_void_p), ("gene_ids", C.c_void_p), ("n_assoc", C.c_uint64)]
+
+
+class ShkTiming(C.Structure):
+    _fields_ = [("n_launches", C.c_uint64), ("total_ms", C.c_double), ("last_n_reads", C.c_uint64),
+                ("last_n_long", C.c_uint64), ("last_n_tie", C.c_uint64), ("last_n_assoc", C.c_uint64)]
+
+
+class ShkWorkCounters(C.Structure):
+    _fields_ = [("n_kmers", C.c_uint64), ("n_hits", C.c_uint64), ("n_list_ids", C.c_uint64), ("n_bases", C.c_uint64)]
+
+
+# every symbol include/shark_hip.h declares
+EXPORTS = [
+    "shk_create", "shk_destroy", "shk_strerror", "shk_last_error", "shk_ref_add", "shk_ref_finalize",
+    "shk_index_info_get", "shk_index_copy_bf", "shk_index_copy_lists", "shk_classify", "shk_classify_device",
+    "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
+    "shk_alloc_pinned", "shk_free_pinned", "shk_version",
+]
+
+_lib = None
+
+
+class SharkHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsharkhip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SharkHipError("libsharkhip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C shark_amd/csrc`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    L.shk_create.restype = C.c_int; L.shk_create.argtypes = [C.POINTER(ShkParams), C.POINTER(p)]
+    L.shk_destroy.restype = None; L.shk_destroy.argtypes = [p]
+    L.shk_strerror.restype = C.c_char_p; L.shk_strerror.argtypes = [C.c_int]
+    L.shk_last_error.restype = C.c_char_p; L.shk_last_error.argtypes = [p]
+    L.shk_ref_add.restype = C.c_int; L.shk_ref_add.argtypes = [p, C.c_char_p, C.c_uint64]
+    L.shk_ref_finalize.restype = C.c_int; L.shk_ref_finalize.argtypes = [p]
+    L.shk_index_info_get.restype = C.c_int; L.shk_index_info_get.argtypes = [p, C.POINTER(ShkIndexInfo)]
+    L.shk_index_copy_bf.restype = C.c_int; L.shk_index_copy_bf.argtypes = [p, p, C.c_uint64]
+    L.shk_index_copy_lists.restype = C.c_int; L.shk_index_copy_lists.argtypes = [p, p, p]
+    L.shk_classify.restype = C.c_int; L.shk_classify.argtypes = [p, C.POINTER(ShkBatch), C.POINTER(ShkResult)]
+    L.shk_classify_device.restype = C.c_int
+    L.shk_classify_device.argtypes = [p, C.POINTER(ShkBatch), C.c_uint32, C.POINTER(ShkResult)]
+    L.shk_gene_counts.restype = C.c_int; L.shk_gene_counts.argtypes = [p, p, C.c_uint32]
+    L.shk_gene_counts_reset.restype = C.c_int; L.shk_gene_counts_reset.argtypes = [p]
+    L.shk_timing_enable.restype = C.c_int; L.shk_timing_enable.argtypes = [p, C.c_int]
+    L.shk_timing_get.restype = C.c_int; L.shk_timing_get.argtypes = [p, C.POINTER(ShkTiming)]
+    L.shk_count_work.restype = C.c_int; L.shk_count_work.argtypes = [p, C.POINTER(ShkBatch), C.POINTER(ShkWorkCounters)]
+    L.shk_alloc_pinned.restype = p; L.shk_alloc_pinned.argtypes = [C.c_size_t]
+    L.shk_free_pinned.restype = None; L.shk_free_pinned.argtypes = [p]
+    L.shk_version.restype = C.c_char_p; L.shk_version.argtypes = []
+    _lib = L
+    return L
+
+
+def _u8(a):
+    if a is None:
+        return None
+    if isinstance(a, (bytes, bytearray)):
+        return np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class SharkHip:
+    """One classification context on one GPU (shk_ctx)."""
+
+    def __init__(self, k=17, c=0.6, bf_bits=1 << 33, min_quality=0, single=False, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        prm = ShkParams(k, c, bf_bits, min_quality, int(bool(single)), device)
+        rc = self.L.shk_create(C.byref(prm), C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise SharkHipError("shk_create: %s" % self.L.shk_strerror(rc).decode())
+        self.k, self.c, self.bf_bits = k, c, bf_bits
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SharkHipError("%s: %s (%s)" % (what, self.L.shk_strerror(rc).decode(),
+                                                 self.L.shk_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.L.shk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- index -----------------------------------------------------------------
+    def ref_add(self, seq):
+        return self.L.shk_ref_add(self.h, bytes(seq), len(seq))
+
+    def ref_finalize(self):
+        return self.L.shk_ref_finalize(self.h)
+
+    def build(self, seqs):
+        for s in seqs:
+            self._check(self.ref_add(s), "shk_ref_add")
+        self._check(self.ref_finalize(), "shk_ref_finalize")
+        return self.index_info()
+
+    def index_info(self):
+        info = ShkIndexInfo()
+        self._check(self.L.shk_index_info_get(self.h, C.byref(info)), "shk_index_info_get")
+        return {f: getattr(info, f) for f, _ in ShkIndexInfo._fields_}
+
+    def copy_bf(self):
+        nw = (self.bf_bits + 63) // 64
+        w = np.zeros(nw, dtype=np.uint64)
+        self._check(self.L.shk_index_copy_bf(self.h, _ptr(w), nw), "shk_index_copy_bf")
+        return w
+
+    def copy_lists(self):
+        info = self.index_info()
+        off = np.zeros(info["n_set_bits"] + 1, dtype=np.uint32)
+        ids = np.zeros(max(info["tot_idx"], 1), dtype=np.uint16)
+        self._check(self.L.shk_index_copy_lists(self.h, _ptr(off), _ptr(ids)), "shk_index_copy_lists")
+        return off, ids[:info["tot_idx"]]
+
+    # ---- classification --------------------------------------------------------
+    def classify(self, seq1, off1, seq2=None, off2=None, qual1=None, qual2=None):
+        """host SoA batch -> (gene_off[n+1] u32, gene_ids u16)"""
+        seq1, seq2, qual1, qual2 = _u8(seq1), _u8(seq2), _u8(qual1), _u8(qual2)
+        off1 = np.ascontiguousarray(off1, dtype=np.uint64)
+        off2 = np.ascontiguousarray(off2, dtype=np.uint64) if off2 is not None else None
+        n = len(off1) - 1
+        b = ShkBatch(n, _ptr(seq1), _ptr(off1), _ptr(seq2), _ptr(off2), _ptr(qual1), _ptr(qual2))
+        r = ShkResult()
+        self._check(self.L.shk_classify(self.h, C.byref(b), C.byref(r)), "shk_classify")
+        gene_off = np.ctypeslib.as_array(C.cast(r.gene_off, C.POINTER(C.c_uint32)), shape=(n + 1,)).copy()
+        tot = int(r.n_assoc)
+        if tot:
+            ids = np.ctypeslib.as_array(C.cast(r.gene_ids, C.POINTER(C.c_uint16)), shape=(tot,)).copy()
+        else:
+            ids = np.zeros(0, np.uint16)
+        return gene_off, ids
+
+    def classify_device(self, n, seq1, off1, seq2=0, off2=0, qual1=0, qual2=0, max_read_len=0):
+        """device pointers (ints) -> ShkResult with DEVICE pointers"""
+        b = ShkBatch(n, seq1 or None, off1 or None, seq2 or None, off2 or None, qual1 or None, qual2 or None)
+        r = ShkResult()
+        self._check(self.L.shk_classify_device(self.h, C.byref(b), max_read_len, C.byref(r)), "shk_classify_device")
+        return r
+
+    def count_work(self, n, seq1, off1, seq2=0, off2=0, qual1=0, qual2=0):
+        b = ShkBatch(n, seq1 or None, off1 or None, seq2 or None, off2 or None, qual1 or None, qual2 or None)
+        w = ShkWorkCounters()
+        self._check(self.L.shk_count_work(self.h, C.byref(b), C.byref(w)), "shk_count_work")
+        return {f: getattr(w, f) for f, _ in ShkWorkCounters._fields_}
+
+    def gene_counts(self, n=65536):
+        a = np.zeros(n, dtype=np.uint64)
+        self._check(self.L.shk_gene_counts(self.h, _ptr(a), n), "shk_gene_counts")
+        return a
+
+    def gene_counts_reset(self):
+        self._check(self.L.shk_gene_counts_reset(self.h), "shk_gene_counts_reset")
+
+    def timing_enable(self, on=True):
+        self._check(self.L.shk_timing_enable(self.h, int(on)), "shk_timing_enable")
+
+    def timing(self):
+        t = ShkTiming()
+        self._check(self.L.shk_timing_get(self.h, C.byref(t)), "shk_timing_get")
+        return {f: getattr(t, f) for f, _ in ShkTiming._fields_}

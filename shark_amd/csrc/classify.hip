@@ -1,0 +1,445 @@
+// classify.hip -- per-read k-mer classification on gfx950 (wave64).
+//
+// One WAVEFRONT per read (pair).  Replaces, with bit-identical results,
+//   FastqSplitter.hpp:63,:83,:104-109   mate join + quality mask (semantics)
+//   ReadAnalyzer::operator()            ReadAnalyzer.hpp:39-110
+//   BF::get_index                       bloomfilter.h:78-102
+//
+// How the reference's serial loop is re-expressed:
+//  * k-mer slots.  The rolling walk with restart-on-invalid (ReadAnalyzer.hpp
+//    :51-77, kmer_utils.hpp:57-71) visits exactly the k-mers whose k
+//    characters are all valid.  Slot t < nk1 is the k-mer starting at base t of
+//    mate 1, slot t >= nk1 the one starting at base t-nk1 of mate 2 (nk_m =
+//    max(0, L_m-k+1)).  The joiner 'N' (FastqSplitter.hpp:63) is invalid, so no
+//    k-mer spans the mates and the two mates are just two slot ranges.
+//  * per-gene coverage.  For a gene g with hit end positions p0<p1<..., the
+//    reference accumulates cov = k + sum min(k, p_j - p_{j-1}), nk = #hits
+//    (ReadAnalyzer.hpp:56-62,:79-86; a fresh map entry is ((0,0),0) and its
+//    first increment is min(k, pos-0) = k).  Hits in different mates are more
+//    than k apart in joined coordinates, so the min clamps to k there.
+//  * gene order.  Every set bit's list is ascending and duplicate free
+//    (bloomfilter.h:68-74), so a k-way merge over the lists of all hit slots
+//    visits genes in ascending id order -- the std::map iteration order used by
+//    the arg-max with ties (ReadAnalyzer.hpp:90-102).
+//  * threshold.  `max >= c*len` is evaluated in double exactly as written
+//    (ReadAnalyzer.hpp:104); gfx950 has IEEE fp64 multiply/compare.
+//
+// Data path per read: 8 bases per lane are loaded with one (unaligned) 8-byte
+// global load, classified with SWAR, and written to LDS as a 2-bit packed
+// big-endian code stream plus a 1-bit validity stream.  Every lane then cuts
+// its k-mers out of LDS with two 64-bit reads and a funnel shift, hashes them
+// (XXH64, 5 64-bit multiplies) and issues all its filter probes before the
+// first wait.  `__ballot` of the hit flags ends the read immediately when no
+// probe hit -- the common case for off-target reads.
+#include <hip/hip_runtime.h>
+
+#include "kmer_device.hpp"
+#include "shark_internal.hpp"
+
+namespace shk {
+
+constexpr int CF_WAVES = 4;              // wavefronts per workgroup
+constexpr int CF_THREADS = CF_WAVES * 64;
+constexpr uint32_t GENE_INF = 0xFFFFFFFFu;
+
+// per-wave storage sizes (in 64-bit words) for a slot capacity S
+__host__ __device__ constexpr uint32_t code_words_for(uint32_t S) { return (S + 91 + 31) / 32 + 1; }
+__host__ __device__ constexpr uint32_t vbit_words_for(uint32_t S) { return (S + 91 + 63) / 64 + 2; }
+
+struct WaveStore {
+  uint64_t *codes;      // 2-bit codes, 32 bases per word, first base in bits 63:62
+  uint64_t *vbits;      // validity, 64 bases per word, LSB first
+  uint32_t *rec_start;  // per slot: cursor into csr_ids
+  uint32_t *rec_end;    // per slot: end of its list
+  uint32_t *cur;        // per slot: gene at the cursor, GENE_INF when exhausted / no hit
+};
+
+// 8 bytes starting at p, of which only `rem` (>= 1) belong to the read.  The
+// full-width load is used only when all 8 bytes are inside the read, so no
+// byte outside the caller's buffers is ever touched.
+__device__ __forceinline__ uint64_t load8(const uint8_t *p, uint32_t rem)
+{
+  if (rem >= 8) {
+    uint64_t w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+  }
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < rem; ++i) w |= (uint64_t)p[i] << (8 * i);
+  return w;
+}
+
+template <int U, bool POW2, bool HASQ, bool FAST, bool EMIT>
+__device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
+                                             const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk)
+{
+  const uint32_t k = P.k;
+  const uint64_t o1 = P.off1[read];
+  const uint32_t L1 = (uint32_t)(P.off1[read + 1] - o1);
+  uint64_t o2 = 0;
+  uint32_t L2 = 0;
+  if (P.seq2) {
+    o2 = P.off2[read];
+    L2 = (uint32_t)(P.off2[read + 1] - o2);
+  }
+  const uint32_t nk1 = L1 >= k ? L1 - k + 1 : 0;
+  const uint32_t nk2 = L2 >= k ? L2 - k + 1 : 0;
+  const uint32_t ns = nk1 + nk2;
+  const uint32_t P2 = ((L1 + 31) >> 5) << 5;  // packed position of mate 2's first base
+
+  if (FAST) {
+    if (ns > slot_cap) {  // does not fit the LDS specialisation: general kernel
+      if (lane == 0) {
+        const uint32_t q = atomicAdd(&P.counters[CTR_LONG], 1u);
+        P.long_queue[q] = (uint32_t)read;
+        atomicMax(&P.counters[CTR_MAX_SLOTS], ns);
+        atomicMax(&P.counters[CTR_MAX_BASES], P2 + L2);
+        P.count[read] = 0;
+      }
+      return;
+    }
+  }
+
+  // ---- stage the read: 8 bases per lane -> packed codes + validity in LDS ----
+  const uint32_t g2 = P2 >> 3;
+  const uint32_t n_groups = g2 + ((L2 + 7) >> 3);
+  uint32_t my_valid = 0;
+  for (uint32_t gi = lane; gi < n_groups; gi += 64) {
+    const bool m2 = gi >= g2;
+    const uint32_t b = (m2 ? gi - g2 : gi) << 3;
+    const uint32_t L = m2 ? L2 : L1;
+    uint32_t code16 = 0, valid8 = 0;
+    if (b < L) {
+      const uint32_t rem = L - b;
+      const uint64_t w = load8((m2 ? P.seq2 + o2 : P.seq1 + o1) + b, rem);
+      uint32_t c_lo, c_hi, i_lo, i_hi;
+      classify4((uint32_t)w, c_lo, i_lo);
+      classify4((uint32_t)(w >> 32), c_hi, i_hi);
+      code16 = (pack4(c_lo) << 8) | pack4(c_hi);
+      uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4);
+      if (HASQ) {
+        const uint64_t q = load8((m2 ? P.qual2 + o2 : P.qual1 + o1) + b, rem);
+        inv8 |= gather4(qmask4((uint32_t)q, P.mq)) | (gather4(qmask4((uint32_t)(q >> 32), P.mq)) << 4);
+      }
+      if (rem < 8) inv8 |= 0xFFu << rem;
+      valid8 = ~inv8 & 0xFFu;
+    }
+    // 16-bit chunk q4 of word W, chunk 0 most significant (little-endian LDS)
+    reinterpret_cast<uint16_t *>(st.codes)[((gi >> 2) << 2) + (3u - (gi & 3u))] = (uint16_t)code16;
+    reinterpret_cast<uint8_t *>(st.vbits)[gi] = (uint8_t)valid8;
+    my_valid += __builtin_popcount(valid8);
+  }
+  // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49)
+  const uint32_t len = wave_sum_u32(my_valid);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- probe every k-mer slot ----------------------------------------------
+  const uint64_t kmask = (1ull << k) - 1ull;
+  bool any_hit = false;
+  unsigned long long wk_kmers = 0, wk_hits = 0, wk_ids = 0;
+  for (uint32_t base = 0; base < ns; base += 64 * U) {
+    uint64_t pos[U];
+    uint32_t word[U];
+    bool ok[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t t = base + lane + 64 * j;
+      const bool act = t < ns;
+      const bool m2 = t >= nk1;
+      const uint32_t pp = act ? (m2 ? t - nk1 + P2 : t) : 0u;
+      const uint32_t W = pp >> 5, sh = (pp & 31u) << 1;
+      const uint64_t w0 = st.codes[W], w1 = st.codes[W + 1];
+      const uint64_t top = (w0 << sh) | ((w1 >> 1) >> (63u - sh));
+      const uint32_t V = pp >> 6, vs = pp & 63u;
+      const uint64_t v0 = st.vbits[V], v1 = st.vbits[V + 1];
+      const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+      ok[j] = act && ((win & kmask) == kmask);
+      const uint64_t canon = canonical_from_top(top, k);
+      pos[j] = bf_pos<POW2>(xxh64_u64(canon), P.bf_bits, P.bf_mask);
+    }
+    // all probes of this lane are issued before the first use (bloomfilter.h:87-89)
+#pragma unroll
+    for (int j = 0; j < U; ++j) word[j] = ok[j] ? __builtin_nontemporal_load(P.bf32 + (pos[j] >> 5)) : 0u;
+    bool hit[U];
+    bool lane_any = false;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      hit[j] = (word[j] >> (pos[j] & 31u)) & 1u;
+      lane_any |= hit[j];
+    }
+    const bool round_any = __ballot(lane_any) != 0ull;
+    if (P.work_counters) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) { wk_kmers += ok[j]; wk_hits += hit[j]; }
+    }
+    if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
+    any_hit |= round_any;
+    // ---- hits: rank -> list range (bloomfilter.h:90-94) ----------------------
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t t = base + lane + 64 * j;
+      if (t < ns) {
+        uint32_t s = 0, e = 0, g = GENE_INF;
+        if (hit[j]) {
+          const uint32_t r = bf_rank(P.bf32, P.rank_blk, pos[j]);
+          s = P.csr_off[r];
+          e = P.csr_off[r + 1];
+          g = P.csr_ids[s];
+          if (P.work_counters) wk_ids += e - s;
+        }
+        st.rec_start[t] = s;
+        st.rec_end[t] = e;
+        st.cur[t] = g;
+      }
+    }
+  }
+  if (P.work_counters) {
+    const uint32_t a = wave_sum_u32((uint32_t)wk_kmers), b = wave_sum_u32((uint32_t)wk_hits), c = wave_sum_u32((uint32_t)wk_ids);
+    if (lane == 0) {
+      atomicAdd(&P.work_counters[0], (unsigned long long)a);
+      atomicAdd(&P.work_counters[1], (unsigned long long)b);
+      atomicAdd(&P.work_counters[2], (unsigned long long)c);
+      atomicAdd(&P.work_counters[3], (unsigned long long)(L1 + L2) * (HASQ ? 2ull : 1ull));
+    }
+  }
+
+  uint32_t best_cov = 0, best_nk = 0, n_best = 0;
+  uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
+  uint32_t n_emit = 0;
+  if (any_hit) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t out_base = EMIT ? P.gene_off[read] : 0u;
+    // ---- k-way merge over the hit lists, ascending gene id -------------------
+    for (;;) {
+      uint32_t mymin = GENE_INF;
+      for (uint32_t t = lane; t < ns; t += 64) {
+        const uint32_t g = st.cur[t];
+        mymin = g < mymin ? g : mymin;
+      }
+      const uint32_t g = wave_min_u32(mymin);
+      if (g == GENE_INF) break;
+      uint32_t contrib = 0, nk = 0;
+      uint64_t hprev = 0;
+      for (uint32_t tb = 0; tb < ns; tb += 64) {
+        const uint32_t t = tb + lane;
+        const bool h = t < ns && st.cur[t] == g;
+        const uint64_t H = __ballot(h);
+        nk += (uint32_t)__builtin_popcountll(H);
+        if (h) {
+          // distance (in slots = bases) to the previous k-mer of this gene
+          const uint64_t below = H & ((1ull << lane) - 1ull);
+          uint32_t d = k;
+          if (below) d = lane - (63u - (uint32_t)__builtin_clzll(below));
+          else if (hprev) d = lane + 1u + (uint32_t)__builtin_clzll(hprev);
+          if (t >= nk1 && t - d < nk1) d = k;  // previous hit is in the other mate
+          contrib += d < k ? d : k;            // min(k, pos - last)  ReadAnalyzer.hpp:81
+          // advance this slot's cursor past g
+          const uint32_t s = st.rec_start[t] + 1u;
+          st.rec_start[t] = s;
+          st.cur[t] = s < st.rec_end[t] ? (uint32_t)P.csr_ids[s] : GENE_INF;
+        }
+        hprev = H;
+      }
+      const uint32_t cov = wave_sum_u32(contrib);
+      if (EMIT) {
+        if (cov == tie_cov && nk == tie_nk) {
+          if (lane == 0) {
+            P.gene_ids[out_base + n_emit] = (uint16_t)g;
+            atomicAdd(&P.gene_counts[g & 0xFFFFu], 1ull);
+          }
+          ++n_emit;
+        }
+      } else {
+        // arg-max with ties in ascending gene order (ReadAnalyzer.hpp:90-102)
+        if (cov > best_cov || (cov == best_cov && nk > best_nk)) {
+          best_cov = cov;
+          best_nk = nk;
+          n_best = 1;
+          best_id[0] = g;
+        } else if (cov == best_cov && nk == best_nk) {
+          if (n_best < SHK_INLINE_IDS) {
+#pragma unroll
+            for (int i = 1; i < SHK_INLINE_IDS; ++i)
+              if ((int)n_best == i) best_id[i] = g;
+          }
+          ++n_best;
+        }
+      }
+    }
+  }
+  if (EMIT) return;
+
+  // ---- threshold + --single (ReadAnalyzer.hpp:104) ---------------------------
+  uint32_t n_out = 0;
+  if (n_best > 0 && (double)best_cov >= P.c * (double)len && (!P.single || n_best == 1)) n_out = n_best;
+  if (lane == 0) {
+    P.count[read] = n_out;
+    if (n_out > 0) {
+      if (!P.work_counters) {
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&P.counters[CTR_ASSOC_LO]), (unsigned long long)n_out);
+        (void)old;
+      }
+      uint16_t *o = P.inl + read * SHK_INLINE_IDS;
+#pragma unroll
+      for (int i = 0; i < SHK_INLINE_IDS; ++i)
+        if ((uint32_t)i < n_out) o[i] = (uint16_t)best_id[i];
+      if (n_out > SHK_INLINE_IDS) {
+        const uint32_t q = atomicAdd(&P.counters[CTR_TIE], 1u);
+        P.tie_queue[3 * q + 0] = (uint32_t)read;
+        P.tie_queue[3 * q + 1] = best_cov;
+        P.tie_queue[3 * q + 2] = best_nk;
+      } else if (!P.work_counters) {
+#pragma unroll
+        for (int i = 0; i < SHK_INLINE_IDS; ++i)
+          if ((uint32_t)i < n_out) atomicAdd(&P.gene_counts[best_id[i] & 0xFFFFu], 1ull);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fast kernel: everything per wave lives in LDS; slot capacity 64*U
+// ---------------------------------------------------------------------------
+template <int U, bool POW2, bool HASQ>
+__global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const ClassifyParams P)
+{
+  constexpr uint32_t S = 64 * U;
+  constexpr uint32_t CW = code_words_for(S), VW = vbit_words_for(S);
+  constexpr uint32_t WORDS = CW + VW + (3 * S) / 2;
+  __shared__ uint64_t lds[CF_WAVES * WORDS];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint64_t *base = lds + wave * WORDS;
+  WaveStore st;
+  st.codes = base;
+  st.vbits = base + CW;
+  st.rec_start = reinterpret_cast<uint32_t *>(base + CW + VW);
+  st.rec_end = st.rec_start + S;
+  st.cur = st.rec_end + S;
+  const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
+  for (uint64_t read = (uint64_t)blockIdx.x * CF_WAVES + wave; read < P.n; read += stride)
+    process_read<U, POW2, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);
+}
+
+// ---------------------------------------------------------------------------
+// general kernel: same algorithm, per-wave storage in a global scratch slice,
+// k-mer slots processed in rounds of 64*U; used for reads that exceed the
+// fast kernel's capacity (MAIN) and to write out tie lists longer than
+// SHK_INLINE_IDS (EMIT).  Work items come from a queue.
+// ---------------------------------------------------------------------------
+template <bool POW2, bool HASQ, bool EMIT>
+__global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const ClassifyParams P)
+{
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t gw = (uint64_t)blockIdx.x * CF_WAVES + wave;
+  uint64_t *base = P.scratch + gw * P.scratch_stride_words;
+  const uint32_t S = P.scratch_slots;
+  const uint32_t CW = P.scratch_code_words, VW = P.scratch_code_words / 2 + 2;
+  WaveStore st;
+  st.codes = base;
+  st.vbits = base + CW;
+  st.rec_start = reinterpret_cast<uint32_t *>(base + CW + VW);
+  st.rec_end = st.rec_start + S;
+  st.cur = st.rec_end + S;
+  const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
+  for (uint64_t w = gw; w < P.n_work; w += stride) {
+    uint64_t read = w;
+    uint32_t tc = 0, tn = 0;
+    if (EMIT) {
+      read = P.work[3 * w];
+      tc = P.work[3 * w + 1];
+      tn = P.work[3 * w + 2];
+    } else if (P.work) {
+      read = P.work[w];
+    }
+    process_read<U, POW2, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn);
+  }
+}
+
+// copy the inline ids of reads with 1..SHK_INLINE_IDS genes into the CSR result
+__global__ __launch_bounds__(256) void gather_inline_kernel(const uint32_t *__restrict__ count, const uint16_t *__restrict__ inl,
+                                                            const uint32_t *__restrict__ gene_off, uint16_t *__restrict__ gene_ids, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = count[i];
+  if (c == 0 || c > SHK_INLINE_IDS) return;
+  const uint32_t o = gene_off[i];
+  for (uint32_t j = 0; j < c; ++j) gene_ids[o + j] = inl[i * SHK_INLINE_IDS + j];
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+uint32_t fast_kernel_max_slots() { return 64 * 8; }
+
+uint32_t fast_kernel_unroll(uint32_t max_slots)
+{
+  const uint32_t u = max_slots == 0 ? 5 : (max_slots + 63) / 64;
+  if (u <= 2) return 2;
+  if (u <= 6) return u;
+  return 8;
+}
+
+template <int U>
+static void launch_fast_u(const ClassifyParams &p, bool pow2, bool hasq, unsigned grid, hipStream_t s)
+{
+  if (pow2) {
+    if (hasq) hipLaunchKernelGGL((classify_fast_kernel<U, true, true>), dim3(grid), dim3(CF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((classify_fast_kernel<U, true, false>), dim3(grid), dim3(CF_THREADS), 0, s, p);
+  } else {
+    if (hasq) hipLaunchKernelGGL((classify_fast_kernel<U, false, true>), dim3(grid), dim3(CF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((classify_fast_kernel<U, false, false>), dim3(grid), dim3(CF_THREADS), 0, s, p);
+  }
+}
+
+int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
+{
+  if (p.n == 0) return SHK_OK;
+  const bool pow2 = ctx->idx.pow2, hasq = p.mq != 0;
+  // persistent grid: enough workgroups to fill 256 CUs several times over
+  const uint64_t want = (p.n + CF_WAVES - 1) / CF_WAVES;
+  const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+  const uint32_t u = fast_kernel_unroll(max_slots);
+  if (u == 2) launch_fast_u<2>(p, pow2, hasq, grid, stream);
+  else if (u == 3) launch_fast_u<3>(p, pow2, hasq, grid, stream);
+  else if (u == 4) launch_fast_u<4>(p, pow2, hasq, grid, stream);
+  else if (u == 5) launch_fast_u<5>(p, pow2, hasq, grid, stream);
+  else if (u == 6) launch_fast_u<6>(p, pow2, hasq, grid, stream);
+  else launch_fast_u<8>(p, pow2, hasq, grid, stream);
+  SHK_HIP(ctx, hipGetLastError());
+  return SHK_OK;
+}
+
+int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream)
+{
+  if (p.n_work == 0) return SHK_OK;
+  const bool pow2 = ctx->idx.pow2, hasq = p.mq != 0;
+  const unsigned grid = (n_waves + CF_WAVES - 1) / CF_WAVES;
+#define LG(P2_, HQ_, EM_) hipLaunchKernelGGL((classify_general_kernel<P2_, HQ_, EM_>), dim3(grid), dim3(CF_THREADS), 0, stream, p)
+  if (emit) {
+    if (pow2) { if (hasq) LG(true, true, true); else LG(true, false, true); }
+    else { if (hasq) LG(false, true, true); else LG(false, false, true); }
+  } else {
+    if (pow2) { if (hasq) LG(true, true, false); else LG(true, false, false); }
+    else { if (hasq) LG(false, true, false); else LG(false, false, false); }
+  }
+#undef LG
+  SHK_HIP(ctx, hipGetLastError());
+  return SHK_OK;
+}
+
+int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n, hipStream_t stream)
+{
+  if (n == 0) return SHK_OK;
+  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, inl, gene_off, gene_ids, n);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
+}  // namespace shk

@@ -1,0 +1,269 @@
+// index_build.hip -- on-device construction of shark's k-mer index (gfx950).
+//
+// Replaces, with identical resulting content,
+//   pass 1   KmerBuilder.hpp:40-72 + BloomfilterFiller.hpp:38-46 + BF::add_at
+//            bloomfilter.h:57-59                    -> ref_kmer_kernel<MODE_SET>
+//   switch_mode(1)  bloomfilter.h:112-125 (rank)    -> bf_block_popcount + scan
+//   pass 2   main.cpp:154-189 + BF::add_to_kmer bloomfilter.h:61-75
+//                                                   -> ref_kmer_kernel<MODE_KEYS> + radix sort
+//   switch_mode(2)  bloomfilter.h:126-184           -> unique + CSR kernels
+//
+// The reference rolls k-mers serially and restarts after an invalid
+// character; here every base position is an independent thread: the k-mer
+// STARTING at position s of a record exists iff s + k <= len and characters
+// s..s+k-1 are all valid, which is the same set (kmer_utils.hpp:57-71).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "device_scan.hpp"
+#include "kmer_device.hpp"
+#include "shark_internal.hpp"
+
+namespace shk {
+
+enum { MODE_SET = 0, MODE_KEYS = 1 };
+constexpr int RK_THREADS = 256;
+
+// to_int (kmer_utils.hpp:29-41) for one byte: 0..3, or 4 = invalid
+__device__ __forceinline__ uint32_t base_code(uint32_t c)
+{
+  const uint32_t t = c & 0xDFu;
+  const uint32_t code = ((t >> 1) ^ (t >> 2)) & 3u;
+  const uint32_t expect = (0x54474341u >> (8 * code)) & 0xFFu;
+  return expect == t ? code : 4u;
+}
+
+// one thread per base position of the concatenated reference records
+template <int MODE>
+__global__ __launch_bounds__(RK_THREADS) void ref_kmer_kernel(const uint8_t *__restrict__ bytes, uint64_t total,
+                                                              const uint64_t *__restrict__ rec_off, uint32_t n_rec, uint32_t k,
+                                                              uint32_t *__restrict__ bf32, uint64_t bf_bits, uint64_t bf_mask, int pow2,
+                                                              uint8_t *__restrict__ rec_has, unsigned long long *__restrict__ n_valid,
+                                                              const uint32_t *__restrict__ rank_blk, const uint32_t *__restrict__ rec_nidx,
+                                                              uint64_t *__restrict__ keys, uint64_t sentinel)
+{
+  __shared__ uint8_t codes[RK_THREADS + 32];
+  const uint64_t b0 = (uint64_t)blockIdx.x * RK_THREADS;
+  const uint64_t i = b0 + threadIdx.x;
+  if (i < total) codes[threadIdx.x] = (uint8_t)base_code(bytes[i]);
+  if (threadIdx.x < k - 1) {
+    const uint64_t j = b0 + RK_THREADS + threadIdx.x;
+    codes[RK_THREADS + threadIdx.x] = j < total ? (uint8_t)base_code(bytes[j]) : (uint8_t)4;
+  }
+  __syncthreads();
+  if (i >= total) return;
+
+  // record containing position i: last r with rec_off[r] <= i
+  uint32_t lo = 0, hi = n_rec;  // invariant: rec_off[lo] <= i < rec_off[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (rec_off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const uint32_t r = lo;
+  const uint64_t s = i - rec_off[r];
+  const uint64_t len = rec_off[r + 1] - rec_off[r];
+  bool valid = s + k <= len;
+  uint64_t fw = 0;
+  if (valid) {
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+      const uint32_t c = codes[threadIdx.x + j];
+      bad |= c >> 2;
+      fw = (fw << 2) | (c & 3u);
+    }
+    valid = bad == 0;
+  }
+  if (!valid) {
+    if (MODE == MODE_KEYS) keys[i] = sentinel;
+    return;
+  }
+  const uint64_t canon = canonical_from_top(fw << (64 - 2 * k), k);
+  const uint64_t h = xxh64_u64(canon);
+  const uint64_t pos = pow2 ? (h & bf_mask) : (h % bf_bits);
+  if (MODE == MODE_SET) {
+    atomicOr(&bf32[pos >> 5], 1u << (pos & 31));   // BF::add_at, bloomfilter.h:57-59 (idempotent)
+    rec_has[r] = 1;                                 // record owns >= 1 valid k-mer (main.cpp:165)
+    atomicAdd(n_valid, 1ull);
+  } else {
+    // bloomfilter.h:70: kmer_rank = _brank(bf_idx); the list entry is (rank, gene)
+    const uint32_t rk = bf_rank(bf32, rank_blk, pos);
+    keys[i] = ((uint64_t)rk << 16) | (uint64_t)rec_nidx[r];
+  }
+}
+
+// popcount of each 512-bit block: 4 lanes x 16 bytes per block, coalesced
+__global__ __launch_bounds__(256) void bf_block_popcount_kernel(const uint4 *__restrict__ bf, uint64_t n_vec, uint32_t *__restrict__ counts)
+{
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;
+  if (g < n_vec) {
+    const uint4 v = bf[g];
+    c = __builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w);
+  }
+  c += __shfl_xor(c, 1, 64);
+  c += __shfl_xor(c, 2, 64);
+  if ((threadIdx.x & 3) == 0 && g < n_vec) counts[g >> 2] = c;
+}
+
+// sorted keys -> head flags (first occurrence of each distinct (rank, gene))
+__global__ __launch_bounds__(256) void unique_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t sentinel, uint32_t *__restrict__ flags)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  flags[i] = (key < sentinel && (i == 0 || keys[i - 1] != key)) ? 1u : 0u;
+}
+
+// write the CSR: ids[o] for every distinct key, offsets[r] at the first key of rank r
+__global__ __launch_bounds__(256) void csr_write_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx, uint64_t n, uint64_t sentinel,
+                                                        uint32_t *__restrict__ csr_off, uint16_t *__restrict__ csr_ids)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key >= sentinel) return;
+  const bool head = i == 0 || keys[i - 1] != key;
+  if (!head) return;
+  const uint32_t o = idx[i];
+  csr_ids[o] = (uint16_t)(key & 0xFFFFu);
+  const uint64_t r = key >> 16;
+  if (i == 0 || (keys[i - 1] >> 16) != r) csr_off[r] = o;
+}
+
+static unsigned grid_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+int build_index(Ctx *ctx)
+{
+  DeviceIndex &ix = ctx->idx;
+  hipStream_t st = ctx->stream;
+  const uint32_t k = ctx->prm.k;
+  const uint64_t total = ctx->ref_bytes.size();
+  const uint32_t n_rec = (uint32_t)ctx->n_records;
+
+  // ---- rank directory needs to exist even for an empty reference ----------
+  uint8_t *d_bytes = nullptr;
+  uint64_t *d_rec_off = nullptr;
+  uint8_t *d_rec_has = nullptr;
+  unsigned long long *d_n_valid = nullptr;
+  uint32_t *d_rec_nidx = nullptr;
+  uint64_t *d_keys = nullptr, *d_keys_alt = nullptr;
+  uint32_t *d_flags = nullptr;
+  void *d_sort_tmp = nullptr;
+  uint64_t *d_scan_tmp = nullptr;
+  int rc = SHK_OK;
+
+  auto cleanup = [&]() {
+    (void)hipFree(d_bytes); (void)hipFree(d_rec_off); (void)hipFree(d_rec_has); (void)hipFree(d_n_valid); (void)hipFree(d_rec_nidx);
+    (void)hipFree(d_keys); (void)hipFree(d_keys_alt); (void)hipFree(d_flags); (void)hipFree(d_sort_tmp); (void)hipFree(d_scan_tmp);
+  };
+#define BI_HIP(call)                                                   \
+  do {                                                                 \
+    hipError_t e__ = (call);                                           \
+    if (e__ != hipSuccess) { rc = set_hip_error(ctx, e__, #call); cleanup(); return rc; } \
+  } while (0)
+
+  BI_HIP(hipMalloc((void **)&d_n_valid, sizeof(unsigned long long)));
+  BI_HIP(hipMemsetAsync(d_n_valid, 0, sizeof(unsigned long long), st));
+  std::vector<uint8_t> h_has(n_rec ? n_rec : 1, 0);
+
+  if (total > 0) {
+    BI_HIP(hipMalloc((void **)&d_bytes, total));
+    BI_HIP(hipMemcpyAsync(d_bytes, ctx->ref_bytes.data(), total, hipMemcpyHostToDevice, st));
+    BI_HIP(hipMalloc((void **)&d_rec_off, (n_rec + 1) * sizeof(uint64_t)));
+    BI_HIP(hipMemcpyAsync(d_rec_off, ctx->ref_off.data(), (n_rec + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    BI_HIP(hipMalloc((void **)&d_rec_has, n_rec));
+    BI_HIP(hipMemsetAsync(d_rec_has, 0, n_rec, st));
+
+    // ---- pass 1: set bits ---------------------------------------------------
+    hipLaunchKernelGGL(ref_kmer_kernel<MODE_SET>, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st,
+                       d_bytes, total, d_rec_off, n_rec, k, ix.bf32, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
+                       d_rec_has, d_n_valid, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0ull);
+    BI_HIP(hipGetLastError());
+    BI_HIP(hipMemcpyAsync(h_has.data(), d_rec_has, n_rec, hipMemcpyDeviceToHost, st));
+  }
+
+  // ---- switch_mode(1): rank directory -------------------------------------
+  const uint64_t n_blocks = ix.n_blocks;
+  BI_HIP(hipMalloc((void **)&ix.rank_blk, (n_blocks + 1) * sizeof(uint32_t)));
+  BI_HIP(hipMalloc((void **)&d_scan_tmp, scan_temp_words(std::max<uint64_t>(std::max<uint64_t>(n_blocks + 1, total), 1)) * sizeof(uint64_t)));
+  BI_HIP(hipMemsetAsync(ix.rank_blk + n_blocks, 0, sizeof(uint32_t), st));
+  hipLaunchKernelGGL(bf_block_popcount_kernel, dim3(grid_for(n_blocks * 4, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const uint4 *>(ix.bf32), n_blocks * 4, ix.rank_blk);
+  BI_HIP(hipGetLastError());
+  const uint64_t *d_total = exclusive_scan_u32(ix.rank_blk, ix.rank_blk, n_blocks + 1, d_scan_tmp, st);
+  uint64_t n_set = 0;
+  unsigned long long n_valid = 0;
+  BI_HIP(hipMemcpyAsync(&n_set, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  BI_HIP(hipMemcpyAsync(&n_valid, d_n_valid, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  BI_HIP(hipStreamSynchronize(st));
+  ix.n_set = n_set;
+  ctx->n_ref_kmers = n_valid;
+  if (n_set >= (1ull << 31)) { cleanup(); ctx->last_error = "index has >= 2^31 set bits (int kmer_rank, bloomfilter.h:70)"; return SHK_ERR_INDEX_TOO_LARGE; }
+
+  // ---- gene numbering: main.cpp:158-186 -------------------------------------
+  // nidx advances for every record EXCEPT one that is at least k long but has
+  // no valid k-mer (`continue` at :165 skips `++nidx` at :185).
+  std::vector<uint32_t> h_nidx(n_rec ? n_rec : 1, 0);
+  uint64_t nidx = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    h_nidx[r] = (uint32_t)nidx;
+    const uint64_t len = ctx->ref_off[r + 1] - ctx->ref_off[r];
+    if (len >= k && !h_has[r]) continue;
+    ++nidx;
+  }
+  ctx->nidx = nidx;
+  // gene ids are stored as uint16_t (small_vector.hpp:46); beyond 65536 the
+  // reference wraps and duplicates -- refused here instead of reproduced.
+  for (uint32_t r = 0; r < n_rec; ++r)
+    if (h_has[r] && h_nidx[r] > 0xFFFFu) { cleanup(); ctx->last_error = "more than 65536 genes"; return SHK_ERR_TOO_MANY_GENES; }
+
+  // ---- pass 2 + switch_mode(2): (rank, gene) keys -> sort -> unique -> CSR ----
+  BI_HIP(hipMalloc((void **)&ix.csr_off, (n_set + 2) * sizeof(uint32_t)));
+  uint64_t tot_idx = 0;
+  if (n_valid > 0) {
+    const uint64_t sentinel = n_set << 16;
+    BI_HIP(hipMalloc((void **)&d_rec_nidx, n_rec * sizeof(uint32_t)));
+    BI_HIP(hipMemcpyAsync(d_rec_nidx, h_nidx.data(), n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    BI_HIP(hipMalloc((void **)&d_keys, total * sizeof(uint64_t)));
+    BI_HIP(hipMalloc((void **)&d_keys_alt, total * sizeof(uint64_t)));
+    hipLaunchKernelGGL(ref_kmer_kernel<MODE_KEYS>, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st,
+                       d_bytes, total, d_rec_off, n_rec, k, ix.bf32, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
+                       (uint8_t *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)ix.rank_blk, (const uint32_t *)d_rec_nidx, d_keys, sentinel);
+    BI_HIP(hipGetLastError());
+
+    // bits needed to order keys up to and including the sentinel
+    unsigned end_bit = 17;
+    while (end_bit < 64 && (sentinel >> end_bit) != 0) ++end_bit;
+    size_t tmp_bytes = 0;
+    BI_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_keys_alt, (size_t)total, 0u, end_bit, st));
+    BI_HIP(hipMalloc(&d_sort_tmp, tmp_bytes ? tmp_bytes : 16));
+    BI_HIP(rocprim::radix_sort_keys(d_sort_tmp, tmp_bytes, d_keys, d_keys_alt, (size_t)total, 0u, end_bit, st));
+    const uint64_t *sorted = d_keys_alt;
+
+    BI_HIP(hipMalloc((void **)&d_flags, total * sizeof(uint32_t)));
+    hipLaunchKernelGGL(unique_flags_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, total, sentinel, d_flags);
+    BI_HIP(hipGetLastError());
+    const uint64_t *d_tot = exclusive_scan_u32(d_flags, d_flags, total, d_scan_tmp, st);
+    BI_HIP(hipMemcpyAsync(&tot_idx, d_tot, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    BI_HIP(hipStreamSynchronize(st));
+    if (tot_idx >= (1ull << 31)) { cleanup(); ctx->last_error = "index has >= 2^31 list entries (int tot_idx, bloomfilter.h:130)"; return SHK_ERR_INDEX_TOO_LARGE; }
+    BI_HIP(hipMalloc((void **)&ix.csr_ids, (tot_idx + 8) * sizeof(uint16_t)));
+    hipLaunchKernelGGL(csr_write_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, (const uint32_t *)d_flags, total, sentinel, ix.csr_off, ix.csr_ids);
+    BI_HIP(hipGetLastError());
+  } else {
+    BI_HIP(hipMalloc((void **)&ix.csr_ids, 8 * sizeof(uint16_t)));
+  }
+  const uint32_t tot32 = (uint32_t)tot_idx;
+  BI_HIP(hipMemcpyAsync(ix.csr_off + n_set, &tot32, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  BI_HIP(hipStreamSynchronize(st));
+  ix.tot_idx = tot_idx;
+  cleanup();
+#undef BI_HIP
+  return SHK_OK;
+}
+
+}  // namespace shk

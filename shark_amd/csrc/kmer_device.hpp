@@ -1,0 +1,154 @@
+// kmer_device.hpp -- device-side k-mer arithmetic for gfx950 (wave64).
+//
+// Re-derivations of the reference's scalar helpers in a form that suits the
+// GPU: no rolling state, no tables in memory.  Each helper cites the reference
+// code whose RESULT it must reproduce bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace shk {
+
+// ---------------------------------------------------------------------------
+// XXH64 of the 8 little-endian bytes of a k-mer, seed 0.
+// Must equal _get_hash(kmer) (kmer_utils.hpp:81-83 -> xxhash.hpp:495-500; for
+// len == 8 only the short-input branch :487-489, one 8-byte lane :427-433 and
+// the avalanche :449-453 execute).  Primes: xxhash.hpp:349.
+// ---------------------------------------------------------------------------
+constexpr uint64_t XP1 = 0x9E3779B185EBCA87ull;
+constexpr uint64_t XP2 = 0xC2B2AE3D27D4EB4Full;
+constexpr uint64_t XP3 = 0x165667B19E3779F9ull;
+constexpr uint64_t XP4 = 0x85EBCA77C2B2AE63ull;
+constexpr uint64_t XP5 = 0x27D4EB2F165667C5ull;
+
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t v)
+{
+  uint64_t h = XP5 + 8ull;          // seed(0) + PRIME5 + len
+  uint64_t k1 = v * XP2;            // round(0, v)
+  k1 = rotl64(k1, 31);
+  k1 *= XP1;
+  h ^= k1;
+  h = rotl64(h, 27) * XP1 + XP4;
+  h ^= h >> 33;
+  h *= XP2;
+  h ^= h >> 29;
+  h *= XP3;
+  h ^= h >> 32;
+  return h;
+}
+
+// ---------------------------------------------------------------------------
+// Base classification, 4 ASCII bytes at a time (SWAR).
+// Result must agree with to_int (kmer_utils.hpp:29-41): A/a C/c G/g T/t are
+// valid with codes 0..3 (= to_int-1, kmer_utils.hpp:68), every other byte --
+// including bytes >= 128, which are undefined behaviour in the reference -- is
+// invalid.
+//   code4 : 2-bit code in the low bits of each byte
+//   inv4  : bit 0 of each byte set when that byte is NOT one of ACGTacgt
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void classify4(uint32_t w, uint32_t &code4, uint32_t &inv4)
+{
+  const uint32_t t = w & 0xDFDFDFDFu;                       // fold lower case onto upper case
+  code4 = ((t >> 1) ^ (t >> 2)) & 0x03030303u;              // A->0 C->1 G->2 T->3
+  const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, code4);
+  uint32_t x = expect ^ t;                                  // zero byte <=> valid base
+  x |= x >> 4;
+  x |= x >> 2;
+  x |= x >> 1;
+  inv4 = x & 0x01010101u;
+}
+
+// 4 x 2-bit codes (one per byte, first character in the LOW byte) -> 8 bits,
+// first character most significant (kmer_utils.hpp:67-69 packs MSB first).
+__device__ __forceinline__ uint32_t pack4(uint32_t code4) { return (code4 * 0x40100401u) >> 24; }
+
+// bit 0 of each byte -> 4 contiguous bits, byte 0 -> bit 0
+__device__ __forceinline__ uint32_t gather4(uint32_t flags4) { return ((flags4 * 0x00204081u) >> 21) & 0xFu; }
+
+// quality mask (FastqSplitter.hpp:70,:104-109): a base is masked when its
+// quality character, compared as a SIGNED char, is below mq = Q + 33.
+// Returns bit 0 of each byte set where masked.
+__device__ __forceinline__ uint32_t qmask4(uint32_t q4, int mq)
+{
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = (int)(int8_t)(q4 >> (8 * i));
+    m |= (q < mq ? 1u : 0u) << (8 * i);
+  }
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// Reverse complement of a k-mer held LEFT-ALIGNED in 64 bits (first base in
+// bits 63:62).  Returns it right-aligned in the low 2k bits; must equal
+// revcompl(kmer, k) (kmer_utils.hpp:47-55).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t revcomp_left_aligned(uint64_t top, uint32_t k)
+{
+  uint64_t x = ~top;
+  // reverse all 64 bits, then swap the two bits of every base back
+  uint32_t lo = __builtin_bitreverse32((uint32_t)(x >> 32));
+  uint32_t hi = __builtin_bitreverse32((uint32_t)x);
+  lo = ((lo >> 1) & 0x55555555u) | ((lo & 0x55555555u) << 1);
+  hi = ((hi >> 1) & 0x55555555u) | ((hi & 0x55555555u) << 1);
+  const uint64_t r = ((uint64_t)hi << 32) | lo;
+  return r & ((1ull << (2 * k)) - 1ull);
+}
+
+// canonical k-mer = min(kmer, revcompl) (KmerBuilder.hpp:49, ReadAnalyzer.hpp:55)
+__device__ __forceinline__ uint64_t canonical_from_top(uint64_t top, uint32_t k)
+{
+  const uint64_t fw = top >> (64 - 2 * k);
+  const uint64_t rc = revcomp_left_aligned(top, k);
+  return fw < rc ? fw : rc;
+}
+
+// position of a hash in the filter: hash % _size (bloomfilter.h:58,:66,:88)
+template <bool POW2>
+__device__ __forceinline__ uint64_t bf_pos(uint64_t h, uint64_t bits, uint64_t mask)
+{
+  if constexpr (POW2) return h & mask;
+  else return h % bits;
+}
+
+// rank of a set bit = number of ones in [0,pos) (bloomfilter.h:70 _brank(bf_idx);
+// :90 uses rank(pos+1) 1-based -- the same list).  512-bit blocks: one
+// directory word + the 64-byte line that holds the probed bit.
+__device__ __forceinline__ uint32_t bf_rank(const uint32_t *__restrict__ bf32, const uint32_t *__restrict__ rank_blk, uint64_t pos)
+{
+  const uint64_t blk = pos >> 9;
+  const uint4 *bp = reinterpret_cast<const uint4 *>(bf32 + (blk << 4));
+  const uint4 q0 = bp[0], q1 = bp[1], q2 = bp[2], q3 = bp[3];
+  const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+  const uint32_t wi = (uint32_t)(pos >> 5) & 15u;
+  const uint32_t bit = (uint32_t)pos & 31u;
+  uint32_t r = rank_blk[blk];
+#pragma unroll
+  for (uint32_t i = 0; i < 16; ++i) {
+    const uint32_t m = i < wi ? 0xFFFFFFFFu : (i == wi ? ((1u << bit) - 1u) : 0u);
+    r += __builtin_popcount(w[i] & m);
+  }
+  return r;
+}
+
+// wave64 reductions (all 64 lanes must participate)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace shk

@@ -1,0 +1,484 @@
+// shark_cli.cpp -- the `shark` command line on top of libsharkhip.
+//
+// Drop-in for the reference binary: identical flags, defaults and validation
+// (argument_parser.hpp:29-174), ssv on stdout (ReadOutput.hpp:43), surviving
+// reads as FASTQ in -o/-p (ReadOutput.hpp:44-47), `[shark/...] Time elapsed`
+// lines on stderr (main.cpp:47-54).  Output order is the reference's `-t 1`
+// order (input order, genes ascending).
+//
+// Host structure mirrors main.cpp's three functor stages per worker loop
+// (main.cpp:66-77): a splitter thread fills SoA batches (FastqSplitter role,
+// but WITHOUT joining or masking -- the device does that), one analyzer thread
+// per GPU calls shk_classify (ReadAnalyzer role), and the main thread writes
+// batches in input order (ReadOutput role).  Extra flags: --gpus N, --batch N.
+#include <getopt.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/shark_hip.h"
+#include "fastx_reader.hpp"
+
+namespace {
+
+// ---- argument_parser.hpp ---------------------------------------------------
+const char *USAGE_MESSAGE =
+    "Usage: shark -r <references> -1 <sample1> [OPTIONAL ARGUMENTS]\n"
+    "\n"
+    "Arguments:\n"
+    "      -r, --reference                   reference sequences in FASTA format (can be gzipped)\n"
+    "      -1, --sample1                     sample in FASTQ (can be gzipped)\n"
+    "\n"
+    "Optional arguments:\n"
+    "      -h, --help                        display this help and exit\n"
+    "      -2, --sample2                     second sample in FASTQ (optional, can be gzipped)\n"
+    "      -o, --out1                        first output sample in FASTQ (default: sharked_sample.1)\n"
+    "      -p, --out2                        second output sample in FASTQ (default: sharked_sample.2)\n"
+    "      -k, --kmer-size                   size of the kmers to index (default:17, max:31)\n"
+    "      -c, --confidence                  confidence for associating a read to a gene (default:0.6)\n"
+    "      -b, --bf-size                     bloom filter size in GB (default:1)\n"
+    "      -q, --min-base-quality            minimum base quality (assume FASTQ Illumina 1.8+ Phred scale, default:0, i.e., no filtering)\n"
+    "      -s, --single                      report an association only if a single gene is found\n"
+    "      -t, --threads                     number of threads (default:1)\n"
+    "      -v, --verbose                     verbose mode\n"
+    "\n"
+    "MI355X build only:\n"
+    "          --gpus N                      number of GPUs to shard the reads over (default:1)\n"
+    "          --batch N                     reads per device batch (default:1048576)\n";
+
+struct Options {
+  std::string fasta_path, sample1_path, sample2_path, out1_path, out2_path;
+  bool paired_flag = false;
+  unsigned k = 17;
+  double c = 0.6;
+  uint64_t bf_size = (uint64_t)1 << 33;
+  char min_quality = 0;
+  bool single = false, verbose = false;
+  int nThreads = 1;
+  int gpus = 1;
+  uint64_t batch = 1u << 20;
+};
+
+Options parse_arguments(int argc, char **argv)
+{
+  Options opt;
+  static const char *shortopts = "t:r:1:2:o:p:k:c:b:q:svh";
+  static const struct option longopts[] = {
+      {"reference", required_argument, NULL, 'r'}, {"threads", required_argument, NULL, 't'},
+      {"sample1", required_argument, NULL, '1'},   {"sample2", required_argument, NULL, '2'},
+      {"out1", required_argument, NULL, 'o'},      {"out2", required_argument, NULL, 'p'},
+      {"kmer-size", required_argument, NULL, 'k'}, {"confidence", required_argument, NULL, 'c'},
+      {"bf-size", required_argument, NULL, 'b'},   {"min-base-quality", required_argument, NULL, 'q'},
+      {"single", no_argument, NULL, 's'},          {"verbose", no_argument, NULL, 'v'},
+      {"help", no_argument, NULL, 'h'},            {"gpus", required_argument, NULL, 1000},
+      {"batch", required_argument, NULL, 1001},    {NULL, 0, NULL, 0}};
+  for (int ch; (ch = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
+    std::istringstream arg(optarg != NULL ? optarg : "");
+    switch (ch) {
+    case 'r': arg >> opt.fasta_path; break;
+    case 't':
+      arg >> opt.nThreads;
+      if (opt.nThreads <= 0) {  // argument_parser.hpp:93-98 (prints the literal text)
+        std::cerr << "USAGE_MESSAGE";
+        std::cerr << "shark: at least 1 thread is required." << std::endl << "aborting..." << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      break;
+    case '1': arg >> opt.sample1_path; break;
+    case '2': arg >> opt.sample2_path; opt.paired_flag = true; break;
+    case 'o': arg >> opt.out1_path; break;
+    case 'p': arg >> opt.out2_path; break;
+    case 'k':
+      arg >> opt.k;
+      if (opt.k == 0 || opt.k > 31) {
+        std::cerr << USAGE_MESSAGE;
+        std::cerr << "shark: k must be in the range [1, 31]." << std::endl << "aborting..." << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      break;
+    case 'c':
+      arg >> opt.c;
+      if (opt.c < 0 || opt.c > 1) {
+        std::cerr << "shark: c must be in the range [0, 1]." << std::endl << "aborting..." << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      break;
+    case 'b':
+      arg >> opt.bf_size;
+      opt.bf_size = opt.bf_size * ((uint64_t)1 << 33);  // GB -> bits
+      break;
+    case 'q': {
+      int mq = 0;
+      arg >> mq;
+      if (mq < 0) {
+        std::cerr << USAGE_MESSAGE;
+        std::cerr << "shark: q must be a positive value." << std::endl << "aborting..." << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      opt.min_quality = static_cast<char>(mq);
+      break;
+    }
+    case 's': opt.single = true; break;
+    case 'v': opt.verbose = true; break;
+    case 'h': std::cerr << USAGE_MESSAGE; exit(EXIT_SUCCESS);
+    case 1000: arg >> opt.gpus; if (opt.gpus < 1) opt.gpus = 1; break;
+    case 1001: arg >> opt.batch; if (opt.batch < 1) opt.batch = 1; break;
+    default:
+      std::cerr << "shark : unknown argument" << std::endl;
+      std::cerr << "\n" << USAGE_MESSAGE;
+      exit(EXIT_FAILURE);
+    }
+  }
+  if (opt.fasta_path == "" || opt.sample1_path == "") {
+    std::cerr << "shark : missing required files" << std::endl;
+    std::cerr << "\n" << USAGE_MESSAGE;
+    exit(EXIT_FAILURE);
+  }
+  if (opt.out1_path == "") opt.out1_path = "sharked_sample.1";
+  if (opt.out2_path == "" && opt.sample2_path != "") opt.out2_path = "sharked_sample.2";
+  return opt;
+}
+
+auto start_t = std::chrono::high_resolution_clock::now();
+void pelapsed(const std::string &s)  // main.cpp:47-54
+{
+  auto now_t = std::chrono::high_resolution_clock::now();
+  std::cerr << "[shark/" << s << "] Time elapsed "
+            << std::chrono::duration_cast<std::chrono::milliseconds>(now_t - start_t).count() / 1000 << std::endl;
+}
+
+// ---- one batch of reads, structure of arrays ---------------------------------
+struct Strings {
+  std::vector<char> bytes;
+  std::vector<uint64_t> off{0};
+  void push(const std::string &s) { bytes.insert(bytes.end(), s.begin(), s.end()); off.push_back(bytes.size()); }
+  void push(const char *p, size_t n) { bytes.insert(bytes.end(), p, p + n); off.push_back(bytes.size()); }
+  size_t size() const { return off.size() - 1; }
+  const char *at(size_t i) const { return bytes.data() + off[i]; }
+  size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
+};
+
+struct ReadBatch {
+  uint64_t index = 0;       // position in the input stream (ordering contract)
+  uint64_t first_read = 0;  // global index of its first read
+  Strings id1, seq1, qual1, id2, seq2, qual2;
+  // result
+  std::vector<uint32_t> gene_off;
+  std::vector<uint16_t> gene_ids;
+  int rc = 0;
+};
+
+// FastqSplitter role (FastqSplitter.hpp:47-93): batches of reads in input order
+class BatchSplitter {
+ public:
+  BatchSplitter(const Options &o) : r1_(o.sample1_path), paired_(o.paired_flag), maxnum_(o.batch)
+  {
+    if (paired_) r2_.reset(new shk::FastxReader(o.sample2_path));
+  }
+  bool ok() const { return r1_.ok() && (!paired_ || r2_->ok()); }
+  std::unique_ptr<ReadBatch> operator()()
+  {
+    std::unique_ptr<ReadBatch> b(new ReadBatch());
+    b->index = next_index_++;
+    b->first_read = n_reads_;
+    shk::FastxRecord a, c;
+    while (b->seq1.size() < maxnum_) {
+      if (r1_.read(a) < 0) break;
+      if (paired_ && r2_->read(c) < 0) break;
+      // the reference builds std::string from C strings (FastqSplitter.hpp:55,63): stop at NUL
+      const size_t l1 = strnlen(a.seq.data(), a.seq.size());
+      b->id1.push(a.name.c_str(), strlen(a.name.c_str()));
+      b->seq1.push(a.seq.data(), l1);
+      b->qual1.push(a.qual.data(), std::min(strnlen(a.qual.data(), a.qual.size()), a.qual.size()));
+      if (paired_) {
+        const size_t l2 = strnlen(c.seq.data(), c.seq.size());
+        b->id2.push(c.name.c_str(), strlen(c.name.c_str()));
+        b->seq2.push(c.seq.data(), l2);
+        b->qual2.push(c.qual.data(), std::min(strnlen(c.qual.data(), c.qual.size()), c.qual.size()));
+      }
+    }
+    n_reads_ += b->seq1.size();
+    if (b->seq1.size() == 0) return nullptr;
+    return b;
+  }
+
+ private:
+  shk::FastxReader r1_;
+  std::unique_ptr<shk::FastxReader> r2_;
+  bool paired_;
+  uint64_t maxnum_;
+  uint64_t next_index_ = 0, n_reads_ = 0;
+};
+
+// ReadAnalyzer role (ReadAnalyzer.hpp:39-110): reads -> associations, on one GPU
+class ReadAnalyzer {
+ public:
+  ReadAnalyzer(shk_ctx *ctx, bool need_qual) : ctx_(ctx), need_qual_(need_qual) {}
+  void operator()(ReadBatch &b) const
+  {
+    shk_batch in{};
+    in.n = b.seq1.size();
+    in.seq1 = b.seq1.bytes.data();
+    in.off1 = b.seq1.off.data();
+    if (b.seq2.size() == in.n && b.id2.size() == in.n && in.n) {
+      in.seq2 = b.seq2.bytes.data();
+      in.off2 = b.seq2.off.data();
+    }
+    if (need_qual_) {
+      // quality strings share the sequence offsets (kseq.h:216 guarantees equal lengths)
+      in.qual1 = b.qual1.bytes.data();
+      if (in.seq2) in.qual2 = b.qual2.bytes.data();
+    }
+    shk_result out{};
+    b.rc = shk_classify(ctx_, &in, &out);
+    if (b.rc != SHK_OK) return;
+    b.gene_off.assign(out.gene_off, out.gene_off + in.n + 1);
+    b.gene_ids.assign(out.gene_ids, out.gene_ids + out.n_assoc);
+  }
+
+ private:
+  shk_ctx *ctx_;
+  bool need_qual_;
+};
+
+// ReadOutput role (ReadOutput.hpp:37-50)
+class ReadOutput {
+ public:
+  ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend) : out1_(out1), out2_(out2), legend_(legend) {}
+  void operator()(const ReadBatch &b)
+  {
+    const size_t n = b.seq1.size();
+    for (size_t i = 0; i < n; ++i) {
+      // the reference starts a new output call -- and clears previd -- every
+      // 50 000 input reads (main.cpp:215, ReadOutput.hpp:39)
+      if ((b.first_read + i) % 50000 == 0) previd_.clear();
+      for (uint32_t j = b.gene_off[i]; j < b.gene_off[i + 1]; ++j) {
+        const std::string &gene = legend_[b.gene_ids[j]];
+        fwrite(b.id1.at(i), 1, b.id1.len(i), stdout);
+        fputc(' ', stdout);
+        fwrite(gene.data(), 1, gene.size(), stdout);
+        fputc('\n', stdout);
+        const bool same = previd_.size() == b.id1.len(i) && memcmp(previd_.data(), b.id1.at(i), previd_.size()) == 0;
+        if (!same) {
+          if (out1_) record(out1_, b.id1, b.seq1, b.qual1, i);
+          if (out2_) record(out2_, b.id2, b.seq2, b.qual2, i);
+        }
+        previd_.assign(b.id1.at(i), b.id1.len(i));
+      }
+    }
+  }
+
+ private:
+  static void record(FILE *f, const Strings &id, const Strings &seq, const Strings &qual, size_t i)
+  {
+    fputc('@', f);
+    if (i < id.size()) fwrite(id.at(i), 1, id.len(i), f);
+    fputc('\n', f);
+    if (i < seq.size()) fwrite(seq.at(i), 1, seq.len(i), f);
+    fputs("\n+\n", f);
+    if (i < qual.size()) fwrite(qual.at(i), 1, qual.len(i), f);
+    fputc('\n', f);
+  }
+  FILE *out1_, *out2_;
+  const std::vector<std::string> &legend_;
+  std::string previd_;
+};
+
+template <typename T>
+class BoundedQueue {
+ public:
+  explicit BoundedQueue(size_t cap) : cap_(cap) {}
+  void push(T v)
+  {
+    std::unique_lock<std::mutex> l(m_);
+    cv_space_.wait(l, [&] { return q_.size() < cap_; });
+    q_.push_back(std::move(v));
+    cv_item_.notify_one();
+  }
+  bool pop(T &v)
+  {
+    std::unique_lock<std::mutex> l(m_);
+    cv_item_.wait(l, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    v = std::move(q_.front());
+    q_.pop_front();
+    cv_space_.notify_one();
+    return true;
+  }
+  void close()
+  {
+    std::lock_guard<std::mutex> l(m_);
+    closed_ = true;
+    cv_item_.notify_all();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_item_, cv_space_;
+  std::deque<T> q_;
+  size_t cap_;
+  bool closed_ = false;
+};
+
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+  const Options opt = parse_arguments(argc, argv);
+
+  if (opt.verbose) {  // main.cpp:113-123
+    std::cerr << "Reference texts: " << opt.fasta_path << std::endl;
+    std::cerr << "Sample 1: " << opt.sample1_path << std::endl;
+    if (opt.paired_flag) std::cerr << "Sample 2: " << opt.sample2_path << std::endl;
+    std::cerr << "K-mer length: " << opt.k << std::endl;
+    std::cerr << "Threshold value: " << opt.c << std::endl;
+    std::cerr << "Only single associations: " << (opt.single ? "Yes" : "No") << std::endl;
+    std::cerr << "Minimum base quality: " << static_cast<int>(opt.min_quality) << std::endl;
+    std::cerr << std::endl;
+  }
+
+  // ---- contexts: one per GPU, index replicated by deterministic rebuild -------
+  const int n_gpus = opt.gpus;
+  std::vector<shk_ctx *> ctxs((size_t)n_gpus, nullptr);
+  for (int g = 0; g < n_gpus; ++g) {
+    shk_params p{};
+    p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single; p.device = g;
+    const int rc = shk_create(&p, &ctxs[(size_t)g]);
+    if (rc != SHK_OK) {
+      std::cerr << "shark: cannot create a context on GPU " << g << ": " << shk_strerror(rc) << std::endl;
+      return EXIT_FAILURE;
+    }
+  }
+
+  // ---- 1+2. reference: legend in file order (FastaSplitter.hpp:48) + index ----
+  std::vector<std::string> legend_ID;
+  {
+    shk::FastxReader fa(opt.fasta_path);
+    if (!fa.ok()) {
+      std::cerr << "shark: cannot open " << opt.fasta_path << std::endl;
+      return EXIT_FAILURE;
+    }
+    shk::FastxRecord rec;
+    while (fa.read(rec) >= 0) {
+      legend_ID.push_back(rec.name.c_str());
+      const size_t len = strnlen(rec.seq.data(), rec.seq.size());  // C-string semantics (main.cpp:164)
+      for (auto *ctx : ctxs) {
+        const int rc = shk_ref_add(ctx, rec.seq.data(), len);
+        if (rc != SHK_OK) {
+          std::cerr << "shark: " << shk_strerror(rc) << std::endl;
+          return EXIT_FAILURE;
+        }
+      }
+    }
+  }
+  pelapsed("Transcript file processed");
+  {
+    std::vector<std::thread> th;
+    std::vector<int> rcs((size_t)n_gpus, 0);
+    for (int g = 0; g < n_gpus; ++g) th.emplace_back([&, g] { rcs[(size_t)g] = shk_ref_finalize(ctxs[(size_t)g]); });
+    for (auto &t : th) t.join();
+    for (int g = 0; g < n_gpus; ++g)
+      if (rcs[(size_t)g] != SHK_OK) {
+        std::cerr << "shark: index build failed on GPU " << g << ": " << shk_strerror(rcs[(size_t)g]) << " " << shk_last_error(ctxs[(size_t)g]) << std::endl;
+        return EXIT_FAILURE;
+      }
+  }
+  pelapsed("First switch performed");
+  shk_index_info info{};
+  shk_index_info_get(ctxs[0], &info);
+  pelapsed("BF created from transcripts (" + std::to_string(info.nidx) + " genes)");
+  pelapsed("Second switch performed");
+
+  // ---- 3. sample ---------------------------------------------------------------
+  {
+    BatchSplitter fs(opt);
+    if (!fs.ok()) {
+      std::cerr << "shark: cannot open the sample" << std::endl;
+      return EXIT_FAILURE;
+    }
+    FILE *out1 = fopen(opt.out1_path.c_str(), "w");
+    FILE *out2 = (opt.paired_flag && opt.out2_path != "") ? fopen(opt.out2_path.c_str(), "w") : nullptr;
+    ReadOutput ro(out1, out2, legend_ID);
+
+    BoundedQueue<std::unique_ptr<ReadBatch>> todo((size_t)n_gpus * 2);
+    std::mutex done_m;
+    std::condition_variable done_cv;
+    std::map<uint64_t, std::unique_ptr<ReadBatch>> done;
+    uint64_t n_batches = 0;
+    bool split_finished = false;
+
+    std::thread splitter([&] {
+      for (;;) {
+        auto b = fs();
+        if (!b) break;
+        {
+          std::lock_guard<std::mutex> l(done_m);
+          n_batches = b->index + 1;
+        }
+        todo.push(std::move(b));
+      }
+      todo.close();
+      std::lock_guard<std::mutex> l(done_m);
+      split_finished = true;
+      done_cv.notify_all();
+    });
+    std::vector<std::thread> analyzers;
+    for (int g = 0; g < n_gpus; ++g) {
+      analyzers.emplace_back([&, g] {
+        ReadAnalyzer ra(ctxs[(size_t)g], opt.min_quality != 0);
+        std::unique_ptr<ReadBatch> b;
+        while (todo.pop(b)) {
+          ra(*b);
+          std::lock_guard<std::mutex> l(done_m);
+          done[b->index] = std::move(b);
+          done_cv.notify_all();
+        }
+      });
+    }
+    // ordered drain
+    uint64_t next = 0;
+    int failed = 0;
+    for (;;) {
+      std::unique_ptr<ReadBatch> b;
+      {
+        std::unique_lock<std::mutex> l(done_m);
+        done_cv.wait(l, [&] { return done.count(next) || (split_finished && next >= n_batches); });
+        if (!done.count(next)) break;
+        b = std::move(done[next]);
+        done.erase(next);
+      }
+      if (b->rc != SHK_OK) {
+        failed = b->rc;
+      } else {
+        ro(*b);
+      }
+      ++next;
+    }
+    splitter.join();
+    for (auto &t : analyzers) t.join();
+    fflush(stdout);
+    if (out1) fclose(out1);
+    if (out2) fclose(out2);
+    if (failed) {
+      std::cerr << "shark: classification failed: " << shk_strerror(failed) << std::endl;
+      return EXIT_FAILURE;
+    }
+  }
+  pelapsed("Sample completed");
+
+  for (auto *ctx : ctxs) shk_destroy(ctx);
+  pelapsed("Association done");
+  return 0;
+}

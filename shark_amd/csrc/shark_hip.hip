@@ -1,0 +1,474 @@
+// shark_hip.hip -- the C ABI of libsharkhip (include/shark_hip.h): context,
+// device memory, and the orchestration around the HIP kernels.  No CPU
+// implementation of any hot-path step lives here: without a device every
+// computing entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "device_scan.hpp"
+#include "shark_internal.hpp"
+
+namespace shk {
+
+int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
+{
+  if (ctx) {
+    ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  return e == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP;
+}
+
+static void free_index(DeviceIndex &ix)
+{
+  hipFree(ix.bf32); hipFree(ix.rank_blk); hipFree(ix.csr_off); hipFree(ix.csr_ids);
+  ix = DeviceIndex{};
+}
+
+static uint32_t slots_for_len(uint32_t len, uint32_t k, bool paired)
+{
+  const uint32_t per = len >= k ? len - k + 1 : 0;
+  return paired ? 2 * per : per;
+}
+
+// everything after the inputs are resident in HBM; batch pointers are device pointers
+static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, shk_result *res, shk_work_counters *wc = nullptr)
+{
+  hipStream_t st = ctx->stream;
+  const uint64_t n = b->n;
+  if (n >= 0xFFFFFFFFull) { ctx->last_error = "batch too large (n must be < 2^32-1)"; return SHK_ERR_ARG; }
+  int rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_count, &ctx->cap_count, n + 1))) return rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_inl, &ctx->cap_inl, n * SHK_INLINE_IDS + 8))) return rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_gene_off, &ctx->cap_gene_off, n + 1))) return rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_long_queue, &ctx->cap_long_queue, n + 1))) return rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_tie_queue, &ctx->cap_tie_queue, 3 * n + 3))) return rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_scan_temp, &ctx->cap_scan_temp, scan_temp_words(n + 1)))) return rc;
+
+  SHK_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
+  SHK_HIP(ctx, hipMemsetAsync(ctx->d_count + n, 0, sizeof(uint32_t), st));
+
+  ClassifyParams p{};
+  const DeviceIndex &ix = ctx->idx;
+  p.bf32 = ix.bf32; p.rank_blk = ix.rank_blk; p.csr_off = ix.csr_off; p.csr_ids = ix.csr_ids;
+  p.bf_bits = ix.bf_bits; p.bf_mask = ix.bf_bits - 1;
+  p.k = ctx->prm.k; p.c = ctx->prm.c; p.single = ctx->prm.single;
+  p.mq = ctx->prm.min_quality ? ctx->prm.min_quality + 33 : 0;  // FastqSplitter.hpp:70
+  p.n = n;
+  p.seq1 = (const uint8_t *)b->seq1; p.off1 = b->off1;
+  p.seq2 = (const uint8_t *)b->seq2; p.off2 = b->off2;
+  p.qual1 = (const uint8_t *)b->qual1; p.qual2 = (const uint8_t *)b->qual2;
+  p.count = ctx->d_count; p.inl = ctx->d_inl;
+  p.counters = ctx->d_counters; p.long_queue = ctx->d_long_queue; p.tie_queue = ctx->d_tie_queue;
+  p.gene_counts = ctx->d_gene_counts;
+  p.work_counters = nullptr;
+
+  const bool paired = b->seq2 != nullptr;
+  uint32_t max_slots = max_read_len ? slots_for_len(max_read_len, p.k, paired) : 0;
+  if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
+  const uint32_t fast_cap = 64 * fast_kernel_unroll(max_slots);
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->timing) {
+    if (ctx->ev_used == ctx->ev_start.size()) {
+      hipEvent_t a, c;
+      SHK_HIP(ctx, hipEventCreate(&a));
+      SHK_HIP(ctx, hipEventCreate(&c));
+      ctx->ev_start.push_back(a);
+      ctx->ev_stop.push_back(c);
+    }
+    e0 = ctx->ev_start[ctx->ev_used];
+    e1 = ctx->ev_stop[ctx->ev_used];
+    ctx->ev_used++;
+    SHK_HIP(ctx, hipEventRecord(e0, st));
+  }
+  if ((rc = launch_classify_fast(ctx, p, max_slots, st))) return rc;
+  if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
+
+  SHK_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  SHK_HIP(ctx, hipStreamSynchronize(st));
+  const uint32_t n_long = ctx->h_counters[CTR_LONG];
+  uint32_t gen_slots = fast_cap, gen_bases = fast_cap + 91;
+
+  auto size_scratch = [&](uint64_t n_items, unsigned *n_waves) -> int {
+    const uint32_t S = ((gen_slots + 63) / 64) * 64;
+    const uint32_t CW = (gen_bases + 31) / 32 + 2;
+    const uint32_t VW = CW / 2 + 2;
+    const uint64_t stride = (uint64_t)CW + VW + (3ull * S) / 2 + 2;
+    uint64_t waves = std::min<uint64_t>(n_items, 4096);
+    const uint64_t budget_words = (1ull << 31) / 8;  // at most 2 GiB of scratch
+    if (waves * stride > budget_words) waves = std::max<uint64_t>(1, budget_words / stride);
+    waves = ((waves + 3) / 4) * 4;
+    int r = ensure_capacity(ctx, &ctx->d_scratch, &ctx->cap_scratch, waves * stride);
+    if (r) return r;
+    p.scratch = ctx->d_scratch;
+    p.scratch_stride_words = stride;
+    p.scratch_slots = S;
+    p.scratch_code_words = CW;
+    *n_waves = (unsigned)waves;
+    return SHK_OK;
+  };
+
+  if (n_long) {
+    gen_slots = std::max(gen_slots, ctx->h_counters[CTR_MAX_SLOTS]);
+    gen_bases = std::max(gen_bases, ctx->h_counters[CTR_MAX_BASES]);
+    unsigned n_waves = 0;
+    if ((rc = size_scratch(n_long, &n_waves))) return rc;
+    p.work = ctx->d_long_queue;
+    p.n_work = n_long;
+    if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SHK_HIP(ctx, hipStreamSynchronize(st));
+  }
+  const uint32_t n_tie = ctx->h_counters[CTR_TIE];
+  const uint64_t n_assoc = (uint64_t)ctx->h_counters[CTR_ASSOC_LO] | ((uint64_t)ctx->h_counters[CTR_ASSOC_HI] << 32);
+  if (n_assoc >= 0xFFFFFFFFull) { ctx->last_error = "more than 2^32-1 associations in one batch"; return SHK_ERR_ARG; }
+
+  // associations -> CSR (gene_off, gene_ids)
+  if ((rc = ensure_capacity(ctx, &ctx->d_gene_ids, &ctx->cap_gene_ids, n_assoc + 8))) return rc;
+  exclusive_scan_u32(ctx->d_count, ctx->d_gene_off, n + 1, ctx->d_scan_temp, st);
+  SHK_HIP(ctx, hipGetLastError());
+  if ((rc = launch_gather_inline(ctx->d_count, ctx->d_inl, ctx->d_gene_off, ctx->d_gene_ids, n, st))) return rc;
+  if (n_tie) {
+    unsigned n_waves = 0;
+    if ((rc = size_scratch(n_tie, &n_waves))) return rc;
+    p.work = ctx->d_tie_queue;
+    p.n_work = n_tie;
+    p.gene_off = ctx->d_gene_off;
+    p.gene_ids = ctx->d_gene_ids;
+    if ((rc = launch_classify_general(ctx, p, true, n_waves, st))) return rc;
+  }
+  SHK_HIP(ctx, hipStreamSynchronize(st));
+
+  if (wc) {
+    // measurement only: re-run every read through the general kernel with the
+    // exact work counters switched on (results are rewritten with equal values)
+    unsigned n_waves = 0;
+    if ((rc = size_scratch(n, &n_waves))) return rc;
+    SHK_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
+    SHK_HIP(ctx, hipMemsetAsync(ctx->d_work_counters, 0, 4 * sizeof(unsigned long long), st));
+    p.work = nullptr;
+    p.n_work = n;
+    p.work_counters = ctx->d_work_counters;
+    if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    SHK_HIP(ctx, hipMemcpyAsync(h, ctx->d_work_counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    SHK_HIP(ctx, hipStreamSynchronize(st));
+    wc->n_kmers = h[0]; wc->n_hits = h[1]; wc->n_list_ids = h[2]; wc->n_bases = h[3];
+  }
+
+  ctx->last.last_n_reads = n;
+  ctx->last.last_n_long = n_long;
+  ctx->last.last_n_tie = n_tie;
+  ctx->last.last_n_assoc = n_assoc;
+  res->n = n;
+  res->gene_off = ctx->d_gene_off;
+  res->gene_ids = ctx->d_gene_ids;
+  res->n_assoc = n_assoc;
+  return SHK_OK;
+}
+
+}  // namespace shk
+
+using namespace shk;
+
+struct shk_ctx : public shk::Ctx {};
+
+extern "C" {
+
+const char *shk_version(void) { return "sharkhip 0.1 (gfx950)"; }
+
+const char *shk_strerror(int code)
+{
+  switch (code) {
+  case SHK_OK: return "ok";
+  case SHK_ERR_ARG: return "invalid argument";
+  case SHK_ERR_STATE: return "call not allowed in the current mode";
+  case SHK_ERR_HIP: return "HIP runtime error";
+  case SHK_ERR_NOMEM: return "out of memory";
+  case SHK_ERR_TOO_MANY_GENES: return "more than 65536 reference sequences";
+  case SHK_ERR_INDEX_TOO_LARGE: return "index exceeds the reference's 2^31 limits";
+  case SHK_ERR_NO_DEVICE: return "no HIP device";
+  default: return "unknown error";
+  }
+}
+
+const char *shk_last_error(const shk_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int shk_create(const shk_params *prm, shk_ctx **out)
+{
+  if (!prm || !out) return SHK_ERR_ARG;
+  *out = nullptr;
+  if (prm->k == 0 || prm->k > 31) return SHK_ERR_ARG;                  // argument_parser.hpp:115
+  if (!(prm->c >= 0.0 && prm->c <= 1.0)) return SHK_ERR_ARG;           // :124
+  if (prm->min_quality < 0 || prm->min_quality > 94) return SHK_ERR_ARG; // :138; Q+33 must fit a char
+  if (prm->bf_bits == 0) return SHK_ERR_ARG;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return SHK_ERR_NO_DEVICE;
+  if (prm->device < 0 || prm->device >= n_dev) return SHK_ERR_ARG;
+  shk_ctx *ctx = new (std::nothrow) shk_ctx();
+  if (!ctx) return SHK_ERR_NOMEM;
+  ctx->prm = *prm;
+  ctx->prm.single = prm->single ? 1 : 0;
+  auto fail = [&](int rc) { shk_destroy(ctx); return rc; };
+#define CR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP); } while (0)
+  CR_HIP(hipSetDevice(prm->device));
+  CR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  DeviceIndex &ix = ctx->idx;
+  ix.bf_bits = prm->bf_bits;
+  ix.pow2 = (prm->bf_bits & (prm->bf_bits - 1)) == 0;
+  ix.n_blocks = (prm->bf_bits + 511) / 512;
+  ix.bf_words32 = ix.n_blocks * 16;
+  // BF::BF(size): size zero bits (bloomfilter.h:48-53)
+  CR_HIP(hipMalloc((void **)&ix.bf32, ix.bf_words32 * sizeof(uint32_t)));
+  CR_HIP(hipMemsetAsync(ix.bf32, 0, ix.bf_words32 * sizeof(uint32_t), ctx->stream));
+  CR_HIP(hipMalloc((void **)&ctx->d_counters, CTR_WORDS * sizeof(uint32_t)));
+  CR_HIP(hipMalloc((void **)&ctx->d_gene_counts, 65536 * sizeof(unsigned long long)));
+  CR_HIP(hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
+  CR_HIP(hipMalloc((void **)&ctx->d_work_counters, 4 * sizeof(unsigned long long)));
+  CR_HIP(hipHostMalloc((void **)&ctx->h_counters, CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  CR_HIP(hipStreamSynchronize(ctx->stream));
+#undef CR_HIP
+  *out = ctx;
+  return SHK_OK;
+}
+
+void shk_destroy(shk_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->prm.device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_index(ctx->idx);
+  hipFree(ctx->d_seq1); hipFree(ctx->d_seq2); hipFree(ctx->d_qual1); hipFree(ctx->d_qual2);
+  hipFree(ctx->d_off1); hipFree(ctx->d_off2);
+  hipFree(ctx->d_count); hipFree(ctx->d_inl); hipFree(ctx->d_gene_off); hipFree(ctx->d_gene_ids);
+  hipFree(ctx->d_long_queue); hipFree(ctx->d_tie_queue); hipFree(ctx->d_counters);
+  hipFree(ctx->d_scan_temp); hipFree(ctx->d_scratch); hipFree(ctx->d_gene_counts); hipFree(ctx->d_work_counters);
+  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
+  for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int shk_ref_add(shk_ctx *ctx, const char *seq, uint64_t len)
+{
+  if (!ctx || (!seq && len)) return SHK_ERR_ARG;
+  if (ctx->mode != 0) return SHK_ERR_STATE;
+  if (ctx->n_records >= 0x7FFFFFFFull) return SHK_ERR_TOO_MANY_GENES;
+  try {
+    ctx->ref_bytes.insert(ctx->ref_bytes.end(), seq, seq + len);
+    ctx->ref_off.push_back(ctx->ref_bytes.size());
+  } catch (...) {
+    return SHK_ERR_NOMEM;
+  }
+  ctx->n_records++;
+  return SHK_OK;
+}
+
+int shk_ref_finalize(shk_ctx *ctx)
+{
+  if (!ctx) return SHK_ERR_ARG;
+  if (ctx->mode != 0) return SHK_ERR_STATE;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  const int rc = build_index(ctx);
+  if (rc != SHK_OK) return rc;
+  ctx->mode = 2;
+  std::vector<char>().swap(ctx->ref_bytes);
+  return SHK_OK;
+}
+
+int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info)
+{
+  if (!ctx || !info) return SHK_ERR_ARG;
+  info->n_records = ctx->n_records;
+  info->nidx = ctx->nidx;
+  info->bf_bits = ctx->idx.bf_bits;
+  info->n_set_bits = ctx->idx.n_set;
+  info->tot_idx = ctx->idx.tot_idx;
+  info->n_ref_kmers = ctx->n_ref_kmers;
+  return SHK_OK;
+}
+
+int shk_index_copy_bf(const shk_ctx *cctx, uint64_t *words, uint64_t n_words)
+{
+  shk_ctx *ctx = const_cast<shk_ctx *>(cctx);
+  if (!ctx || !words) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  const uint64_t have = (ctx->idx.bf_bits + 63) / 64;
+  if (n_words > have) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  SHK_HIP(ctx, hipMemcpy(words, ctx->idx.bf32, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return SHK_OK;
+}
+
+int shk_index_copy_lists(const shk_ctx *cctx, uint32_t *offsets, uint16_t *ids)
+{
+  shk_ctx *ctx = const_cast<shk_ctx *>(cctx);
+  if (!ctx || !offsets) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  SHK_HIP(ctx, hipMemcpy(offsets, ctx->idx.csr_off, (ctx->idx.n_set + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (ctx->idx.tot_idx && ids)
+    SHK_HIP(ctx, hipMemcpy(ids, ctx->idx.csr_ids, ctx->idx.tot_idx * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  return SHK_OK;
+}
+
+static int check_batch(const shk_ctx *ctx, const shk_batch *b)
+{
+  if (!b) return SHK_ERR_ARG;
+  if (b->n == 0) return SHK_OK;
+  if (!b->seq1 || !b->off1) return SHK_ERR_ARG;
+  if ((b->seq2 == nullptr) != (b->off2 == nullptr)) return SHK_ERR_ARG;
+  if (ctx->prm.min_quality != 0 && (!b->qual1 || (b->seq2 && !b->qual2))) return SHK_ERR_ARG;
+  return SHK_OK;
+}
+
+int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_len, shk_result *result)
+{
+  if (!ctx || !result) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  int rc = check_batch(ctx, batch);
+  if (rc) return rc;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  return classify_core(ctx, batch, max_read_len, result);
+}
+
+int shk_classify(shk_ctx *ctx, const shk_batch *b, shk_result *result)
+{
+  if (!ctx || !result) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  int rc = check_batch(ctx, b);
+  if (rc) return rc;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  hipStream_t st = ctx->stream;
+  const uint64_t n = b->n;
+  const uint64_t bytes1 = n ? b->off1[n] : 0;
+  const uint64_t bytes2 = (n && b->seq2) ? b->off2[n] : 0;
+  // longest mate: selects the kernel specialisation only
+  uint32_t max_len = 1;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (b->off1[i + 1] < b->off1[i]) return SHK_ERR_ARG;
+    max_len = std::max<uint64_t>(max_len, std::min<uint64_t>(b->off1[i + 1] - b->off1[i], 0xFFFFFFFFull));
+    if (b->seq2) {
+      if (b->off2[i + 1] < b->off2[i]) return SHK_ERR_ARG;
+      max_len = std::max<uint64_t>(max_len, std::min<uint64_t>(b->off2[i + 1] - b->off2[i], 0xFFFFFFFFull));
+    }
+  }
+  shk_batch d{};
+  d.n = n;
+  if ((rc = ensure_capacity(ctx, &ctx->d_seq1, &ctx->cap_seq1, bytes1 + 16))) return rc;
+  if ((rc = ensure_capacity(ctx, &ctx->d_off1, &ctx->cap_off1, n + 1))) return rc;
+  if (n) {
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_seq1, b->seq1, bytes1, hipMemcpyHostToDevice, st));
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_off1, b->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  }
+  d.seq1 = (const char *)ctx->d_seq1;
+  d.off1 = ctx->d_off1;
+  if (b->seq2 && n) {
+    if ((rc = ensure_capacity(ctx, &ctx->d_seq2, &ctx->cap_seq2, bytes2 + 16))) return rc;
+    if ((rc = ensure_capacity(ctx, &ctx->d_off2, &ctx->cap_off2, n + 1))) return rc;
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_seq2, b->seq2, bytes2, hipMemcpyHostToDevice, st));
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_off2, b->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    d.seq2 = (const char *)ctx->d_seq2;
+    d.off2 = ctx->d_off2;
+  }
+  if (ctx->prm.min_quality != 0 && n) {
+    if ((rc = ensure_capacity(ctx, &ctx->d_qual1, &ctx->cap_qual1, bytes1 + 16))) return rc;
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_qual1, b->qual1, bytes1, hipMemcpyHostToDevice, st));
+    d.qual1 = (const char *)ctx->d_qual1;
+    if (b->seq2) {
+      if ((rc = ensure_capacity(ctx, &ctx->d_qual2, &ctx->cap_qual2, bytes2 + 16))) return rc;
+      SHK_HIP(ctx, hipMemcpyAsync(ctx->d_qual2, b->qual2, bytes2, hipMemcpyHostToDevice, st));
+      d.qual2 = (const char *)ctx->d_qual2;
+    }
+  }
+  shk_result dr{};
+  if ((rc = classify_core(ctx, &d, max_len, &dr))) return rc;
+  try {
+    ctx->h_gene_off.resize(n + 1);
+    ctx->h_gene_ids.resize(dr.n_assoc + 1);
+  } catch (...) {
+    return SHK_ERR_NOMEM;
+  }
+  SHK_HIP(ctx, hipMemcpyAsync(ctx->h_gene_off.data(), dr.gene_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (dr.n_assoc)
+    SHK_HIP(ctx, hipMemcpyAsync(ctx->h_gene_ids.data(), dr.gene_ids, dr.n_assoc * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+  SHK_HIP(ctx, hipStreamSynchronize(st));
+  result->n = n;
+  result->gene_off = ctx->h_gene_off.data();
+  result->gene_ids = ctx->h_gene_ids.data();
+  result->n_assoc = dr.n_assoc;
+  return SHK_OK;
+}
+
+int shk_gene_counts(shk_ctx *ctx, uint64_t *counts, uint32_t n)
+{
+  if (!ctx || !counts || n > 65536) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SHK_HIP(ctx, hipMemcpy(counts, ctx->d_gene_counts, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return SHK_OK;
+}
+
+int shk_gene_counts_reset(shk_ctx *ctx)
+{
+  if (!ctx) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  SHK_HIP(ctx, hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
+  SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHK_OK;
+}
+
+int shk_timing_enable(shk_ctx *ctx, int enable)
+{
+  if (!ctx) return SHK_ERR_ARG;
+  ctx->timing = enable != 0;
+  ctx->ev_used = 0;
+  return SHK_OK;
+}
+
+int shk_timing_get(shk_ctx *ctx, shk_timing *t)
+{
+  if (!ctx || !t) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double total = 0.0;
+  for (size_t i = 0; i < ctx->ev_used; ++i) {
+    float ms = 0.f;
+    SHK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+    total += ms;
+  }
+  *t = ctx->last;
+  t->n_launches = ctx->ev_used;
+  t->total_ms = total;
+  return SHK_OK;
+}
+
+int shk_count_work(shk_ctx *ctx, const shk_batch *b, shk_work_counters *out)
+{
+  if (!ctx || !out) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  int rc = check_batch(ctx, b);
+  if (rc) return rc;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  shk_result tmp{};
+  return classify_core(ctx, b, 0, &tmp, out);
+}
+
+void *shk_alloc_pinned(size_t bytes)
+{
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void shk_free_pinned(void *p)
+{
+  if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// shark_internal.hpp -- context layout and kernel launch entry points shared
+// by the translation units of libsharkhip.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/shark_hip.h"
+
+namespace shk {
+
+// ---- device-resident index (immutable after shk_ref_finalize) -------------
+// HBM layout:
+//   bf32      : the Bloom filter, sdsl::bit_vector word layout (LSB-first
+//               64-bit words == LSB-first 32-bit words on a little-endian
+//               device), padded with zero words to a multiple of 512 bits.
+//   rank_blk  : uint32 ones-before-block directory, one entry per 512-bit
+//               (64-byte) block, + 1 sentinel = n_set.
+//   csr_off   : uint32[n_set+1], list r = ids[csr_off[r] .. csr_off[r+1])
+//   csr_ids   : uint16 gene indices, ascending and unique inside a list.
+struct DeviceIndex {
+  uint32_t *bf32 = nullptr;
+  uint64_t bf_bits = 0;
+  uint64_t bf_words32 = 0;   // padded
+  uint64_t n_blocks = 0;     // 512-bit blocks
+  bool pow2 = false;
+  uint32_t *rank_blk = nullptr;
+  uint32_t *csr_off = nullptr;
+  uint16_t *csr_ids = nullptr;
+  uint64_t n_set = 0;
+  uint64_t tot_idx = 0;
+};
+
+// ---- classify kernel parameters (passed by value) --------------------------
+struct ClassifyParams {
+  // index
+  const uint32_t *bf32;
+  const uint32_t *rank_blk;
+  const uint32_t *csr_off;
+  const uint16_t *csr_ids;
+  uint64_t bf_bits;
+  uint64_t bf_mask;
+  // options
+  uint32_t k;
+  int32_t mq;        // 0 = no masking, else min_quality + 33 (FastqSplitter.hpp:70)
+  int32_t single;
+  double c;
+  // batch
+  uint64_t n;
+  const uint8_t *seq1;
+  const uint64_t *off1;
+  const uint8_t *seq2;
+  const uint64_t *off2;
+  const uint8_t *qual1;
+  const uint8_t *qual2;
+  // per-read results
+  uint32_t *count;           // n : number of genes kept (exact)
+  uint16_t *inl;             // n * SHK_INLINE_IDS : first genes
+  // queues / counters (device)
+  uint32_t *counters;        // see CTR_*
+  uint32_t *long_queue;      // read indices that did not fit the fast kernel
+  uint32_t *tie_queue;       // 3 words per entry: read index, best cov, best nk
+  unsigned long long *gene_counts;  // 65536
+  // work list for the general kernel (nullptr => all reads 0..n)
+  const uint32_t *work;
+  uint64_t n_work;
+  // general-kernel scratch (per wave)
+  uint64_t *scratch;
+  uint64_t scratch_stride_words;   // per wave
+  uint32_t scratch_slots;          // slot capacity per wave
+  uint32_t scratch_code_words;     // code words capacity
+  // emit mode (general kernel): write every gene whose (cov,nk) equals the
+  // recorded best to gene_ids[gene_off[read] + i]
+  const uint32_t *gene_off;
+  uint16_t *gene_ids;
+  // work counters (count_work build only)
+  unsigned long long *work_counters;
+};
+
+enum {
+  CTR_LONG = 0,      // entries in long_queue
+  CTR_TIE = 1,       // entries in tie_queue
+  CTR_ASSOC_LO = 2,  // total associations (64-bit, two words)
+  CTR_ASSOC_HI = 3,
+  CTR_MAX_SLOTS = 4, // max k-mer slots over queued long reads
+  CTR_MAX_BASES = 5, // max packed length over queued long reads
+  CTR_WORDS = 8
+};
+
+struct Ctx;
+
+// index_build.hip
+int build_index(Ctx *ctx);
+
+// classify.hip
+int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream);
+int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream);
+int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n, hipStream_t stream);
+uint32_t fast_kernel_max_slots();
+uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
+
+struct Ctx {
+  shk_params prm{};
+  int mode = 0;  // 0 = accepting references, 2 = frozen (bloomfilter.h:104-110)
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // buffered reference records (host)
+  std::vector<char> ref_bytes;
+  std::vector<uint64_t> ref_off{0};
+
+  DeviceIndex idx;
+  uint64_t n_records = 0, nidx = 0, n_ref_kmers = 0;
+
+  // classify workspace (device), grown on demand
+  uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr, *d_qual1 = nullptr, *d_qual2 = nullptr;
+  uint64_t *d_off1 = nullptr, *d_off2 = nullptr;
+  size_t cap_seq1 = 0, cap_seq2 = 0, cap_qual1 = 0, cap_qual2 = 0, cap_off1 = 0, cap_off2 = 0;
+  uint32_t *d_count = nullptr;    size_t cap_count = 0;
+  uint16_t *d_inl = nullptr;      size_t cap_inl = 0;
+  uint32_t *d_gene_off = nullptr; size_t cap_gene_off = 0;
+  uint16_t *d_gene_ids = nullptr; size_t cap_gene_ids = 0;
+  uint32_t *d_long_queue = nullptr; size_t cap_long_queue = 0;
+  uint32_t *d_tie_queue = nullptr;  size_t cap_tie_queue = 0;
+  uint32_t *d_counters = nullptr;
+  uint64_t *d_scan_temp = nullptr; size_t cap_scan_temp = 0;
+  uint64_t *d_scratch = nullptr;   size_t cap_scratch = 0;
+  unsigned long long *d_gene_counts = nullptr;
+  unsigned long long *d_work_counters = nullptr;
+  uint32_t *h_counters = nullptr;  // pinned
+
+  // host result buffers
+  std::vector<uint32_t> h_gene_off;
+  std::vector<uint16_t> h_gene_ids;
+
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  size_t ev_used = 0;
+  shk_timing last{};
+};
+
+// error helpers
+int set_hip_error(Ctx *ctx, hipError_t e, const char *what);
+#define SHK_HIP(ctx, call)                                            \
+  do {                                                                \
+    hipError_t e__ = (call);                                          \
+    if (e__ != hipSuccess) return shk::set_hip_error(ctx, e__, #call); \
+  } while (0)
+
+template <typename T>
+int ensure_capacity(Ctx *ctx, T **ptr, size_t *cap, size_t need)
+{
+  if (need <= *cap && *ptr) return SHK_OK;
+  if (*ptr) {
+    hipError_t e = hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    if (e != hipSuccess) return set_hip_error(ctx, e, "hipFree");
+  }
+  size_t want = need + need / 4 + 64;
+  hipError_t e = hipMalloc((void **)ptr, want * sizeof(T));
+  if (e != hipSuccess) return set_hip_error(ctx, e, "hipMalloc");
+  *cap = want;
+  return SHK_OK;
+}
+
+}  // namespace shk

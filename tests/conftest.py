@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure); built on demand with gcc."""
+    from oracle import pyoracle
+    if not os.path.exists(pyoracle.LIB_PATH) or not os.path.exists(pyoracle.CLI_PATH):
+        pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def example_dir():
+    return os.path.join(ROOT, "tests", "golden", "example")

@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+reference's golden files.  Bit-exact: everything here is integer / byte work;
+the one fp64 compare (ReadAnalyzer.hpp:104) is evaluated identically.
+
+Run on the GPU box with `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(**kw):
+    from shark_amd import SharkHip
+    return SharkHip(**kw)
+
+
+def _build_both(oracle, genes, **kw):
+    o = oracle.Shark(k=kw.get("k", 17), c=kw.get("c", 0.6), bf_bits=kw.get("bf_bits", 1 << 33),
+                     min_quality=kw.get("min_quality", 0), single=kw.get("single", False))
+    nidx = o.build([bytes(g) for g in genes])
+    h = _hip(**kw)
+    info = h.build([bytes(g) for g in genes])
+    assert info["nidx"] == nidx
+    assert info["n_records"] == len(genes)
+    return o, h, info
+
+
+def _compare_index(o, h, info):
+    assert info["n_set_bits"] == o.num_kmer()
+    ow = o.bf_words()
+    hw = h.copy_bf()
+    assert np.array_equal(ow, hw), "Bloom filter words differ"
+    # lists: the oracle's select-encoded lists vs the explicit CSR
+    off, ids = h.copy_lists()
+    assert int(off[-1]) == len(ids) == len(o.index_kmer())
+    assert np.array_equal(ids, o.index_kmer())
+    assert np.all(np.diff(off.astype(np.int64)) >= 1), "every set bit owns a non-empty list"
+
+
+def _compare_classify(o, h, batch, nthreads=2):
+    og, oi = o.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"],
+                        nthreads=nthreads)
+    hg, hi = h.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"])
+    assert np.array_equal(og, hg), "gene_off differs at read %d" % int(np.argmax(og != hg))
+    assert np.array_equal(oi, hi)
+    return og, oi
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 1: the bundled example, k=17 c=0.6 bf=1GB
+# ---------------------------------------------------------------------------
+def test_example_bit_exact(oracle, example_dir, tmp_path):
+    fa = synth.read_fasta(os.path.join(example_dir, "ENSG00000277117.fa"))
+    r1 = synth.read_fastq(os.path.join(example_dir, "sample_1.fq"))
+    r2 = synth.read_fastq(os.path.join(example_dir, "sample_2.fq"))
+    h = _hip(k=17, c=0.6, bf_bits=1 << 33)
+    info = h.build([s for _, s in fa])
+    assert info["n_set_bits"] == 17483          # SURVEY.md 8a row 11 (k=17, B=2^33)
+    assert info["n_ref_kmers"] == 18158
+    batch = synth.batch_from_lists([s for _, s, _ in r1], [s for _, s, _ in r2])
+    goff, gids = h.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"])
+    # render ssv + FASTQ exactly as ReadOutput.hpp:37-50 does and compare with the truth files
+    names = [n for n, _ in fa]
+    ssv, fq1, fq2 = [], [], []
+    for i in range(len(r1)):
+        for j in range(goff[i], goff[i + 1]):
+            ssv.append(r1[i][0] + b" " + names[gids[j]] + b"\n")
+        if goff[i + 1] > goff[i]:
+            fq1.append(b"@" + r1[i][0] + b"\n" + r1[i][1] + b"\n+\n" + r1[i][2] + b"\n")
+            fq2.append(b"@" + r2[i][0] + b"\n" + r2[i][1] + b"\n+\n" + r2[i][2] + b"\n")
+    assert b"".join(ssv) == open(os.path.join(example_dir, "ENSG00000277117.truth.ssv"), "rb").read()
+    assert b"".join(fq1) == open(os.path.join(example_dir, "sharked.sample_1.truth.fq"), "rb").read()
+    assert b"".join(fq2) == open(os.path.join(example_dir, "sharked.sample_2.truth.fq"), "rb").read()
+    assert len(ssv) == 1929
+    # per-gene counts (the quantity all-reduced across GPUs)
+    assert int(h.gene_counts(4)[0]) == 1929
+    # and the oracle agrees on the index too
+    o = oracle.Shark(k=17, c=0.6, bf_bits=1 << 33)
+    o.build([s for _, s in fa])
+    _compare_index(o, h, info)
+
+
+# ---------------------------------------------------------------------------
+# synthetic multi-gene sets: ties, N, lowercase, collisions (small filter)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k,bf_bits,paired,read_len", [
+    (17, 1 << 26, True, 150),
+    (31, 1 << 26, True, 150),
+    (17, 1 << 18, True, 100),     # dense filter: cross-gene collisions, long lists
+    (5, 1 << 12, True, 60),       # tiny k: every k-mer in many genes
+    (1, 1 << 10, False, 40),
+    (17, 1000003, True, 150),     # non power-of-two size: true modulo
+    (21, 3 << 20, False, 120),
+])
+def test_synthetic_parity(oracle, k, bf_bits, paired, read_len):
+    rng = np.random.default_rng(1234 + k)
+    genes = synth.make_genes(rng, 40, 100, 1500, share_every=4)
+    o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits)
+    _compare_index(o, h, info)
+    batch = synth.make_reads(rng, genes, 3000, read_len=read_len, paired=paired, on_target=0.6,
+                             n_rate=0.01, lower_rate=0.05, var_len=True)
+    goff, _ = _compare_classify(o, h, batch)
+    assert goff[-1] > 0
+
+
+def test_quality_mask_and_single(oracle):
+    rng = np.random.default_rng(77)
+    genes = synth.make_genes(rng, 30, 300, 2000, share_every=3)
+    for single in (False, True):
+        for q in (20, 2, 41):
+            o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 24, min_quality=q, single=single, c=0.4)
+            batch = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.7, qual=True, var_len=True)
+            _compare_classify(o, h, batch)
+            batch = synth.make_reads(rng, genes, 500, read_len=90, paired=False, on_target=0.7, qual=True)
+            _compare_classify(o, h, batch)
+
+
+def test_confidence_edges(oracle):
+    rng = np.random.default_rng(5)
+    genes = synth.make_genes(rng, 10, 300, 800)
+    batch = synth.make_reads(rng, genes, 1500, read_len=100, paired=True, on_target=0.8, sub_rate=0.05)
+    for c in (0.0, 1.0, 0.5, 0.3333333333333333, 0.83):
+        o, h, _ = _build_both(oracle, genes, k=11, bf_bits=1 << 20, c=c)
+        _compare_classify(o, h, batch)
+
+
+def test_gene_numbering_quirk(oracle):
+    """main.cpp:165: a record >= k long without any valid k-mer does not
+    advance nidx; records shorter than k do."""
+    rng = np.random.default_rng(9)
+    g1, g2, g3 = (synth.random_seq(rng, 400) for _ in range(3))
+    recs = [bytes(g1), b"N" * 50, b"ACGT", bytes(g2), b"ACGTNACGTNACGTNACGTNACGTN", b"", bytes(g3)]
+    o, h, info = _build_both(oracle, recs, k=17, bf_bits=1 << 22)
+    assert info["nidx"] == 5 and info["n_records"] == 7
+    _compare_index(o, h, info)
+    batch = synth.make_reads(rng, [g1, g2, g3], 600, read_len=100, paired=True, on_target=0.9)
+    goff, gids = _compare_classify(o, h, batch)
+    assert set(int(x) for x in np.unique(gids)) == {0, 2, 4}
+
+
+def test_many_ties_overflow_inline(oracle):
+    """more than SHK_INLINE_IDS genes tie: the general kernel writes the list"""
+    rng = np.random.default_rng(11)
+    core = synth.random_seq(rng, 600)
+    genes = [np.concatenate([core, synth.random_seq(rng, 50 + 7 * i)]) for i in range(12)]
+    genes += synth.make_genes(rng, 5, 300, 600)
+    o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 24)
+    _compare_index(o, h, info)
+    batch = synth.make_reads(rng, [core], 400, read_len=120, paired=True, on_target=1.0, sub_rate=0.0, n_rate=0.0)
+    goff, gids = _compare_classify(o, h, batch)
+    assert (np.diff(goff.astype(np.int64)) == 12).sum() > 300
+    t = h.timing()
+    assert t["last_n_tie"] > 300
+    assert np.array_equal(h.gene_counts(20), np.bincount(gids, minlength=20)[:20].astype(np.uint64))
+
+
+def test_long_and_ragged_reads(oracle):
+    """reads beyond the LDS specialisation (general kernel), empty reads, reads
+    shorter than k, reads of only N"""
+    rng = np.random.default_rng(13)
+    genes = synth.make_genes(rng, 8, 3000, 9000, share_every=2)
+    o, h, info = _build_both(oracle, genes, k=19, bf_bits=1 << 25)
+    m1, m2 = [], []
+    for i in range(300):
+        g = genes[i % len(genes)]
+        L1 = int(rng.integers(0, 2500))
+        L2 = int(rng.integers(0, 2500))
+        st = int(rng.integers(0, len(g) - 2500))
+        a = g[st:st + L1].copy()
+        b = synth.revcomp(g[st:st + 2500])[:L2].copy()
+        if i % 7 == 0 and L1:
+            a[rng.integers(0, L1, size=max(1, L1 // 20))] = ord("N")
+        m1.append(a.tobytes())
+        m2.append(b.tobytes())
+    m1 += [b"", b"ACGT", b"N" * 100, b"A" * 18, bytes(genes[0][:19])]
+    m2 += [b"", b"", b"N" * 3, b"", b""]
+    batch = synth.batch_from_lists(m1, m2)
+    goff, _ = _compare_classify(o, h, batch)
+    assert h.timing()["last_n_long"] > 100
+    assert goff[-1] > 100
+
+
+def test_empty_batch_and_state_machine(oracle):
+    from shark_amd import SharkHip, SharkHipError
+    h = SharkHip(k=17, bf_bits=1 << 20)
+    with pytest.raises(SharkHipError):
+        h.classify(np.zeros(0, np.uint8), np.zeros(1, np.uint64))      # not finalized yet
+    h.build([b"ACGTACGTACGTACGTACGTACGTACGTAAAC"])
+    assert h.ref_add(b"ACGT") != 0                                      # no going back (bloomfilter.h:104-110)
+    goff, gids = h.classify(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert list(goff) == [0] and len(gids) == 0
+    # empty reference
+    h2 = SharkHip(k=17, bf_bits=1 << 20)
+    info = h2.build([])
+    assert info["n_set_bits"] == 0 and info["tot_idx"] == 0
+    b = synth.batch_from_lists([b"ACGTACGTACGTACGTACGTACGT"], [b"ACGTTGCATGCATGCATGCATGCA"])
+    goff, gids = h2.classify(b["seq1"], b["off1"], b["seq2"], b["off2"])
+    assert list(goff) == [0, 0]
+
+
+def test_device_resident_api_and_roundtrip_properties():
+    """size-independent properties at a larger scale (no oracle): reads cut
+    from a gene without errors are always assigned to it; random reads never are
+    (filter is sparse); results do not depend on batch splitting."""
+    import torch
+    rng = np.random.default_rng(21)
+    genes = synth.make_genes(rng, 3, 20000, 20000)
+    h = _hip(k=17, c=0.6, bf_bits=1 << 33)
+    h.build([bytes(g) for g in genes])
+    n = 200000
+    batch = synth.make_reads(rng, genes[:1], n, read_len=150, paired=True, on_target=0.5, sub_rate=0.0, n_rate=0.0)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for k, v in batch.items() if v is not None}
+    r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=150)
+    assert r.n == n
+    goff, gids = h.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"])
+    assert int(r.n_assoc) == int(goff[-1])
+    cnt = np.diff(goff.astype(np.int64))
+    assert 0.45 * n < (cnt == 1).sum() < 0.55 * n and (cnt > 1).sum() == 0
+    assert np.all(gids == 0)
+    # split invariance
+    half = n // 2
+    o1 = batch["off1"][:half + 1]
+    o2 = batch["off2"][:half + 1]
+    g1, i1 = h.classify(batch["seq1"][:int(o1[-1])], o1, batch["seq2"][:int(o2[-1])], o2)
+    assert np.array_equal(g1, goff[:half + 1]) and np.array_equal(i1, gids[:int(goff[half])])
+    # exact work counters agree with first principles: every valid k-mer is probed once
+    w = h.count_work(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr())
+    assert w["n_kmers"] == n * 2 * (150 - 17 + 1)
+    assert w["n_bases"] == n * 300
+    assert w["n_hits"] >= (cnt == 1).sum() * 2 * 134
