@@ -210,3 +210,18 @@ class SharkHip:
         t = ShkTiming()
         self._check(self.L.shk_timing_get(self.h, C.byref(t)), "shk_timing_get")
         return {f: getattr(t, f) for f, _ in ShkTiming._fields_}
+
+
+_hip = None
+
+
+def hip_memcpy_dtoh(dst, src_ptr, nbytes):
+    """copy nbytes from a device pointer into a numpy array (bench/test plumbing)"""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.restype = C.c_int
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = _hip.hipMemcpy(dst.ctypes.data_as(C.c_void_p), C.c_void_p(src_ptr), nbytes, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise SharkHipError("hipMemcpy D2H failed: %d" % rc)

@@ -1,0 +1,85 @@
+"""Seeded synthetic workloads generated directly in HBM (torch is plumbing:
+device memory + RNG).  Shapes follow SURVEY.md 8(d): uniform ACGT references,
+2x150 bp pairs, 50 % drawn from a gene (fragment 300-500 bp, mate 2 reverse
+complemented), 50 % uniform random, 1 % substitutions, 0.2 % N."""
+import numpy as np
+import torch
+
+SEED = 0x5A4B2020
+
+
+def make_reference(n_genes, gene_len, seed=SEED):
+    """list of numpy uint8 arrays (host; they go through shk_ref_add)"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    if np.isscalar(gene_len):
+        lens = [int(gene_len)] * n_genes
+    else:
+        lens = [int(x) for x in gene_len]
+    return [acgt[rng.integers(0, 4, size=L)] for L in lens]
+
+
+def make_pairs_device(n, genes, device, seed=SEED, read_len=150, on_target=0.5, sub_rate=0.01, n_rate=0.002,
+                      with_qual=False, chunk=1 << 20):
+    """n pairs of fixed-length mates resident on `device`.
+    returns dict(seq1, off1, seq2, off2, qual1, qual2) of torch tensors (uint8 / int64)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    # all genes concatenated; a read is drawn from one gene
+    cat = torch.from_numpy(np.concatenate(genes)).to(device)
+    glen = torch.tensor([len(x) for x in genes], dtype=torch.int64, device=device)
+    gstart = torch.cumsum(glen, 0) - glen
+    L = read_len
+    seq1 = torch.empty(n * L, dtype=torch.uint8, device=device)
+    seq2 = torch.empty(n * L, dtype=torch.uint8, device=device)
+    qual1 = torch.empty(n * L, dtype=torch.uint8, device=device) if with_qual else None
+    qual2 = torch.empty(n * L, dtype=torch.uint8, device=device) if with_qual else None
+    ar = torch.arange(L, device=device)
+    for b0 in range(0, n, chunk):
+        m = min(chunk, n - b0)
+        gi = torch.randint(0, len(genes), (m,), generator=g, device=device)
+        gl = glen[gi]
+        frag = torch.minimum(torch.randint(300, 501, (m,), generator=g, device=device), gl)
+        frag = torch.maximum(frag, torch.full_like(frag, 1))
+        st = (torch.rand(m, generator=g, device=device) * (gl - frag + 1).to(torch.float32)).to(torch.int64)
+        st = torch.minimum(st, gl - frag) + gstart[gi]
+        idx1 = torch.minimum(st[:, None] + ar[None, :], (gstart[gi] + gl - 1)[:, None])
+        idx2 = torch.maximum((st + frag - 1)[:, None] - ar[None, :], gstart[gi][:, None])
+        t1 = cat[idx1]
+        t2 = comp[cat[idx2].to(torch.int64)]
+        r1 = acgt[torch.randint(0, 4, (m, L), generator=g, device=device)]
+        r2 = acgt[torch.randint(0, 4, (m, L), generator=g, device=device)]
+        on = (torch.rand(m, generator=g, device=device) < on_target)[:, None]
+        m1 = torch.where(on, t1, r1)
+        m2 = torch.where(on, t2, r2)
+        for mm in (m1, m2):
+            sub = torch.rand(m, L, generator=g, device=device) < sub_rate
+            mm[sub] = acgt[torch.randint(0, 4, (int(sub.sum().item()),), generator=g, device=device)]
+            mm[torch.rand(m, L, generator=g, device=device) < n_rate] = ord("N")
+        seq1[b0 * L:(b0 + m) * L] = m1.reshape(-1)
+        seq2[b0 * L:(b0 + m) * L] = m2.reshape(-1)
+        if with_qual:
+            for qq in (qual1, qual2):
+                hi = torch.randint(30, 42, (m, L), generator=g, device=device)
+                lo = torch.randint(2, 30, (m, L), generator=g, device=device)
+                q = torch.where(torch.rand(m, L, generator=g, device=device) < 0.9, hi, lo) + 33
+                qq[b0 * L:(b0 + m) * L] = q.to(torch.uint8).reshape(-1)
+    off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=device)
+    return {"seq1": seq1, "off1": off, "seq2": seq2, "off2": off.clone(), "qual1": qual1, "qual2": qual2}
+
+
+def to_host_sample(batch, n_sample, read_len=150):
+    """first n_sample pairs as numpy arrays (same bytes the GPU classified)"""
+    L = read_len
+    out = {}
+    for key in ("seq1", "seq2", "qual1", "qual2"):
+        t = batch.get(key)
+        out[key] = t[:n_sample * L].cpu().numpy() if t is not None else None
+    off = np.arange(0, (n_sample + 1) * L, L, dtype=np.uint64)
+    out["off1"] = off
+    out["off2"] = off.copy() if batch.get("seq2") is not None else None
+    return out

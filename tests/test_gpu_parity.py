@@ -8,6 +8,11 @@ import os
 import numpy as np
 import pytest
 
+try:  # torch bundles its own HIP runtime: load it BEFORE libsharkhip so one runtime serves both
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 from tests import synth
 
 pytestmark = pytest.mark.gpu
@@ -206,7 +211,6 @@ def test_device_resident_api_and_roundtrip_properties():
     """size-independent properties at a larger scale (no oracle): reads cut
     from a gene without errors are always assigned to it; random reads never are
     (filter is sparse); results do not depend on batch splitting."""
-    import torch
     rng = np.random.default_rng(21)
     genes = synth.make_genes(rng, 3, 20000, 20000)
     h = _hip(k=17, c=0.6, bf_bits=1 << 33)
