@@ -48,21 +48,16 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
     from shark_amd import SharkHip
+    from shark_amd import dist as sdist
     from shark_amd import synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    rank, local_rank, world = sdist.env_rank()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sdist.init("nccl", dev)
 
     k, c, bf_bits = args.k, 0.6, 1 << args.bf_log2
     n = args.pairs
@@ -85,8 +80,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        sdist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -102,25 +96,19 @@ def main():
     dt = time.perf_counter() - t0
     tm = h.timing()
     h.timing_enable(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = sdist.max_over_ranks(dt, dev)
 
     # ---- per-gene counts: the one exchange step, RCCL all-reduce ----------------
     counts = torch.from_numpy(h.gene_counts(max(info["nidx"], 1)).astype(np.int64)).to(dev)
     n_assoc = torch.tensor([int(res.n_assoc)], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(n_assoc, op=dist.ReduceOp.SUM)
+    sdist.allreduce_sum_(counts)
+    sdist.allreduce_sum_(n_assoc)
 
     reads_per_step = 2 * n * world
     value = reads_per_step * args.steps / dt
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        sdist.finalize()
         return
 
     # ---- roofline of the dominant kernel (classify_fast_kernel) ------------------
@@ -150,7 +138,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference path) on this host -------
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bounded sample)
         from oracle import pyoracle
         cores = os.cpu_count() or 1
         try:
@@ -197,9 +185,7 @@ def main():
         "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    sdist.finalize()
 
 
 if __name__ == "__main__":
