@@ -69,7 +69,7 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p, uint32_t rem)
   return w;
 }
 
-template <int U, bool POW2, bool HASQ, bool FAST, bool EMIT>
+template <int U, bool POW2, bool SUM, bool HASQ, bool FAST, bool EMIT>
 __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
                                              const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk)
 {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   unsigned long long wk_kmers = 0, wk_hits = 0, wk_ids = 0;
   for (uint32_t base = 0; base < ns; base += 64 * U) {
     uint64_t pos[U];
-    uint32_t word[U];
+    uint64_t word[U];
     bool ok[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -159,20 +159,35 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       const uint64_t canon = canonical_from_top(top, k);
       pos[j] = bf_pos<POW2>(xxh64_u64(canon), P.bf_bits, P.bf_mask);
     }
-    // all probes of this lane are issued before the first use (bloomfilter.h:87-89)
+    if (P.work_counters) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) word[j] = ok[j] ? __builtin_nontemporal_load(P.bf32 + (pos[j] >> 5)) : 0u;
+      for (int j = 0; j < U; ++j) wk_kmers += ok[j];
+    }
+    // all probes of this lane are issued before the first use (bloomfilter.h:87-89)
+    if (SUM) {
+      // summary level first (cache resident): a clear bit proves the filter bit clear
+      uint32_t sw[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
+#pragma unroll
+      for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
+#pragma unroll
+      for (int j = 0; j < U; ++j) word[j] = ok[j] ? P.bf64[pos[j] >> 6] : 0ull;
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) word[j] = ok[j] ? __builtin_nontemporal_load(P.bf64 + (pos[j] >> 6)) : 0ull;
+    }
     bool hit[U];
     bool lane_any = false;
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      hit[j] = (word[j] >> (pos[j] & 31u)) & 1u;
+      hit[j] = (word[j] >> (pos[j] & 63u)) & 1ull;
       lane_any |= hit[j];
     }
     const bool round_any = __ballot(lane_any) != 0ull;
     if (P.work_counters) {
 #pragma unroll
-      for (int j = 0; j < U; ++j) { wk_kmers += ok[j]; wk_hits += hit[j]; }
+      for (int j = 0; j < U; ++j) wk_hits += hit[j];
     }
     if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
     any_hit |= round_any;
@@ -183,10 +198,11 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       if (t < ns) {
         uint32_t s = 0, e = 0, g = GENE_INF;
         if (hit[j]) {
-          const uint32_t r = bf_rank(P.bf32, P.rank_blk, pos[j]);
-          s = P.csr_off[r];
-          e = P.csr_off[r + 1];
-          g = P.csr_ids[s];
+          const uint32_t r = bf_rank(P.rank_w, word[j], pos[j]);
+          const ListEntry le = P.ent[r];
+          s = le.start;
+          e = le.len != 0xFFFFu ? s + le.len : P.ent[r + 1].start;
+          g = le.gene0;
           if (P.work_counters) wk_ids += e - s;
         }
         st.rec_start[t] = s;
@@ -240,7 +256,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
           // advance this slot's cursor past g
           const uint32_t s = st.rec_start[t] + 1u;
           st.rec_start[t] = s;
-          st.cur[t] = s < st.rec_end[t] ? (uint32_t)P.csr_ids[s] : GENE_INF;
+          st.cur[t] = s < st.rec_end[t] ? (uint32_t)P.ids[s] : GENE_INF;
         }
         hprev = H;
       }
@@ -249,7 +265,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
         if (cov == tie_cov && nk == tie_nk) {
           if (lane == 0) {
             P.gene_ids[out_base + n_emit] = (uint16_t)g;
-            atomicAdd(&P.gene_counts[g & 0xFFFFu], 1ull);
+            if (P.gene_counts) atomicAdd(&P.gene_counts[g & 0xFFFFu], 1ull);
           }
           ++n_emit;
         }
@@ -277,12 +293,10 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   uint32_t n_out = 0;
   if (n_best > 0 && (double)best_cov >= P.c * (double)len && (!P.single || n_best == 1)) n_out = n_best;
   if (lane == 0) {
+    // No same-address atomics here: the association total comes from the scan
+    // of `count`, the per-gene counts from gather_inline_kernel (wave-aggregated).
     P.count[read] = n_out;
     if (n_out > 0) {
-      if (!P.work_counters) {
-        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&P.counters[CTR_ASSOC_LO]), (unsigned long long)n_out);
-        (void)old;
-      }
       uint16_t *o = P.inl + read * SHK_INLINE_IDS;
 #pragma unroll
       for (int i = 0; i < SHK_INLINE_IDS; ++i)
@@ -292,10 +306,6 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
         P.tie_queue[3 * q + 0] = (uint32_t)read;
         P.tie_queue[3 * q + 1] = best_cov;
         P.tie_queue[3 * q + 2] = best_nk;
-      } else if (!P.work_counters) {
-#pragma unroll
-        for (int i = 0; i < SHK_INLINE_IDS; ++i)
-          if ((uint32_t)i < n_out) atomicAdd(&P.gene_counts[best_id[i] & 0xFFFFu], 1ull);
       }
     }
   }
@@ -304,7 +314,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 // ---------------------------------------------------------------------------
 // fast kernel: everything per wave lives in LDS; slot capacity 64*U
 // ---------------------------------------------------------------------------
-template <int U, bool POW2, bool HASQ>
+template <int U, bool POW2, bool SUM, bool HASQ>
 __global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const ClassifyParams P)
 {
   constexpr uint32_t S = 64 * U;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const Classif
   st.cur = st.rec_end + S;
   const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
   for (uint64_t read = (uint64_t)blockIdx.x * CF_WAVES + wave; read < P.n; read += stride)
-    process_read<U, POW2, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);
+    process_read<U, POW2, SUM, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------
@@ -358,20 +368,43 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
     } else if (P.work) {
       read = P.work[w];
     }
-    process_read<U, POW2, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn);
+    process_read<U, POW2, false, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn);
   }
 }
 
 // copy the inline ids of reads with 1..SHK_INLINE_IDS genes into the CSR result
+// and count assigned reads per gene.  Gene counters are hot (one gene can own
+// most reads), so equal genes inside a wave are combined into one atomic.
 __global__ __launch_bounds__(256) void gather_inline_kernel(const uint32_t *__restrict__ count, const uint16_t *__restrict__ inl,
-                                                            const uint32_t *__restrict__ gene_off, uint16_t *__restrict__ gene_ids, uint64_t n)
+                                                            const uint32_t *__restrict__ gene_off, uint16_t *__restrict__ gene_ids, uint64_t n,
+                                                            unsigned long long *__restrict__ gene_counts)
 {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t c = count[i];
-  if (c == 0 || c > SHK_INLINE_IDS) return;
-  const uint32_t o = gene_off[i];
-  for (uint32_t j = 0; j < c; ++j) gene_ids[o + j] = inl[i * SHK_INLINE_IDS + j];
+  const int lane = threadIdx.x & 63;
+  uint32_t c = 0, o = 0;
+  if (i < n) {
+    c = count[i];
+    if (c > SHK_INLINE_IDS) c = 0;  // written (and counted) by the general kernel in EMIT mode
+    o = gene_off[i];
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < SHK_INLINE_IDS; ++j) {
+    bool pending = j < c;
+    uint32_t g = 0;
+    if (pending) {
+      g = inl[i * SHK_INLINE_IDS + j];
+      gene_ids[o + j] = (uint16_t)g;
+    }
+    if (!gene_counts) continue;
+    unsigned long long todo = __ballot(pending);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t lg = __shfl(g, leader, 64);
+      const unsigned long long same = __ballot(pending && g == lg);
+      if (lane == leader) atomicAdd(&gene_counts[lg], (unsigned long long)__builtin_popcountll(same));
+      todo &= ~same;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -388,31 +421,29 @@ uint32_t fast_kernel_unroll(uint32_t max_slots)
 }
 
 template <int U>
-static void launch_fast_u(const ClassifyParams &p, bool pow2, bool hasq, unsigned grid, hipStream_t s)
+static void launch_fast_u(const ClassifyParams &p, bool pow2, bool sum, bool hasq, unsigned grid, hipStream_t s)
 {
-  if (pow2) {
-    if (hasq) hipLaunchKernelGGL((classify_fast_kernel<U, true, true>), dim3(grid), dim3(CF_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((classify_fast_kernel<U, true, false>), dim3(grid), dim3(CF_THREADS), 0, s, p);
-  } else {
-    if (hasq) hipLaunchKernelGGL((classify_fast_kernel<U, false, true>), dim3(grid), dim3(CF_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((classify_fast_kernel<U, false, false>), dim3(grid), dim3(CF_THREADS), 0, s, p);
-  }
+#define LF(P2_, SM_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, P2_, SM_, HQ_>), dim3(grid), dim3(CF_THREADS), 0, s, p)
+  if (pow2 && sum) { if (hasq) LF(true, true, true); else LF(true, true, false); }
+  else if (pow2) { if (hasq) LF(true, false, true); else LF(true, false, false); }
+  else { if (hasq) LF(false, false, true); else LF(false, false, false); }
+#undef LF
 }
 
 int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
 {
   if (p.n == 0) return SHK_OK;
-  const bool pow2 = ctx->idx.pow2, hasq = p.mq != 0;
+  const bool pow2 = ctx->idx.pow2, hasq = p.mq != 0, sum = p.sum32 != nullptr;
   // persistent grid: enough workgroups to fill 256 CUs several times over
   const uint64_t want = (p.n + CF_WAVES - 1) / CF_WAVES;
   const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
   const uint32_t u = fast_kernel_unroll(max_slots);
-  if (u == 2) launch_fast_u<2>(p, pow2, hasq, grid, stream);
-  else if (u == 3) launch_fast_u<3>(p, pow2, hasq, grid, stream);
-  else if (u == 4) launch_fast_u<4>(p, pow2, hasq, grid, stream);
-  else if (u == 5) launch_fast_u<5>(p, pow2, hasq, grid, stream);
-  else if (u == 6) launch_fast_u<6>(p, pow2, hasq, grid, stream);
-  else launch_fast_u<8>(p, pow2, hasq, grid, stream);
+  if (u == 2) launch_fast_u<2>(p, pow2, sum, hasq, grid, stream);
+  else if (u == 3) launch_fast_u<3>(p, pow2, sum, hasq, grid, stream);
+  else if (u == 4) launch_fast_u<4>(p, pow2, sum, hasq, grid, stream);
+  else if (u == 5) launch_fast_u<5>(p, pow2, sum, hasq, grid, stream);
+  else if (u == 6) launch_fast_u<6>(p, pow2, sum, hasq, grid, stream);
+  else launch_fast_u<8>(p, pow2, sum, hasq, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }
@@ -435,10 +466,11 @@ int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsign
   return SHK_OK;
 }
 
-int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n, hipStream_t stream)
+int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n,
+                         unsigned long long *gene_counts, hipStream_t stream)
 {
   if (n == 0) return SHK_OK;
-  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, inl, gene_off, gene_ids, n);
+  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, inl, gene_off, gene_ids, n, gene_counts);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

@@ -3,10 +3,11 @@
 // Replaces, with identical resulting content,
 //   pass 1   KmerBuilder.hpp:40-72 + BloomfilterFiller.hpp:38-46 + BF::add_at
 //            bloomfilter.h:57-59                    -> ref_kmer_kernel<MODE_SET>
-//   switch_mode(1)  bloomfilter.h:112-125 (rank)    -> bf_block_popcount + scan
+//   switch_mode(1)  bloomfilter.h:112-125 (rank)    -> bf_word_popcount + scan
 //   pass 2   main.cpp:154-189 + BF::add_to_kmer bloomfilter.h:61-75
 //                                                   -> ref_kmer_kernel<MODE_KEYS> + radix sort
-//   switch_mode(2)  bloomfilter.h:126-184           -> unique + CSR kernels
+//   switch_mode(2)  bloomfilter.h:126-184           -> unique + CSR + list-entry kernels
+// plus the summary level, which only restates the filter.
 //
 // The reference rolls k-mers serially and restarts after an invalid
 // character; here every base position is an independent thread: the k-mer
@@ -17,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "device_scan.hpp"
@@ -41,9 +43,9 @@ __device__ __forceinline__ uint32_t base_code(uint32_t c)
 template <int MODE>
 __global__ __launch_bounds__(RK_THREADS) void ref_kmer_kernel(const uint8_t *__restrict__ bytes, uint64_t total,
                                                               const uint64_t *__restrict__ rec_off, uint32_t n_rec, uint32_t k,
-                                                              uint32_t *__restrict__ bf32, uint64_t bf_bits, uint64_t bf_mask, int pow2,
+                                                              uint64_t *__restrict__ bf64, uint64_t bf_bits, uint64_t bf_mask, int pow2,
                                                               uint8_t *__restrict__ rec_has, unsigned long long *__restrict__ n_valid,
-                                                              const uint32_t *__restrict__ rank_blk, const uint32_t *__restrict__ rec_nidx,
+                                                              const uint32_t *__restrict__ rank_w, const uint32_t *__restrict__ rec_nidx,
                                                               uint64_t *__restrict__ keys, uint64_t sentinel)
 {
   __shared__ uint8_t codes[RK_THREADS + 32];
@@ -85,28 +87,38 @@ __global__ __launch_bounds__(RK_THREADS) void ref_kmer_kernel(const uint8_t *__r
   const uint64_t h = xxh64_u64(canon);
   const uint64_t pos = pow2 ? (h & bf_mask) : (h % bf_bits);
   if (MODE == MODE_SET) {
-    atomicOr(&bf32[pos >> 5], 1u << (pos & 31));   // BF::add_at, bloomfilter.h:57-59 (idempotent)
+    // BF::add_at, bloomfilter.h:57-59 (idempotent => the filter is order independent)
+    atomicOr(reinterpret_cast<uint32_t *>(bf64) + (pos >> 5), 1u << (pos & 31));
     rec_has[r] = 1;                                 // record owns >= 1 valid k-mer (main.cpp:165)
     atomicAdd(n_valid, 1ull);
   } else {
     // bloomfilter.h:70: kmer_rank = _brank(bf_idx); the list entry is (rank, gene)
-    const uint32_t rk = bf_rank(bf32, rank_blk, pos);
+    const uint32_t rk = bf_rank(rank_w, bf64[pos >> 6], pos);
     keys[i] = ((uint64_t)rk << 16) | (uint64_t)rec_nidx[r];
   }
 }
 
-// popcount of each 512-bit block: 4 lanes x 16 bytes per block, coalesced
-__global__ __launch_bounds__(256) void bf_block_popcount_kernel(const uint4 *__restrict__ bf, uint64_t n_vec, uint32_t *__restrict__ counts)
+// popcount of each 64-bit filter word (two words per lane, 16-byte loads)
+__global__ __launch_bounds__(256) void bf_word_popcount_kernel(const uint4 *__restrict__ bf, uint64_t n_vec, uint32_t *__restrict__ counts)
 {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t c = 0;
-  if (g < n_vec) {
-    const uint4 v = bf[g];
-    c = __builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w);
+  if (g >= n_vec) return;
+  const uint4 v = bf[g];
+  uint2 c;
+  c.x = __builtin_popcount(v.x) + __builtin_popcount(v.y);
+  c.y = __builtin_popcount(v.z) + __builtin_popcount(v.w);
+  reinterpret_cast<uint2 *>(counts)[g] = c;
+}
+
+// summary level: bit j = OR of filter bits [j<<shift, (j+1)<<shift); only non-empty words write
+__global__ __launch_bounds__(256) void bf_summary_kernel(const uint64_t *__restrict__ bf64, uint64_t n_words, uint32_t shift, uint32_t *__restrict__ sum32)
+{
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  if (bf64[w] != 0ull) {
+    const uint64_t sb = (w << 6) >> shift;
+    atomicOr(&sum32[sb >> 5], 1u << (sb & 31));
   }
-  c += __shfl_xor(c, 1, 64);
-  c += __shfl_xor(c, 2, 64);
-  if ((threadIdx.x & 3) == 0 && g < n_vec) counts[g >> 2] = c;
 }
 
 // sorted keys -> head flags (first occurrence of each distinct (rank, gene))
@@ -134,6 +146,24 @@ __global__ __launch_bounds__(256) void csr_write_kernel(const uint64_t *__restri
   if (i == 0 || (keys[i - 1] >> 16) != r) csr_off[r] = o;
 }
 
+// list entries: {start, len (clipped), first gene} per set bit
+__global__ __launch_bounds__(256) void list_entry_kernel(const uint32_t *__restrict__ csr_off, const uint16_t *__restrict__ ids, uint64_t n_set, uint32_t tot,
+                                                         ListEntry *__restrict__ ent)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_set) return;
+  ListEntry e;
+  if (r == n_set) {
+    e.start = tot; e.len = 0; e.gene0 = 0;
+  } else {
+    const uint32_t s0 = csr_off[r], s1 = csr_off[r + 1];
+    e.start = s0;
+    e.len = (uint16_t)((s1 - s0) > 0xFFFFu ? 0xFFFFu : (s1 - s0));
+    e.gene0 = ids[s0];
+  }
+  ent[r] = e;
+}
+
 static unsigned grid_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
 
 int build_index(Ctx *ctx)
@@ -154,11 +184,12 @@ int build_index(Ctx *ctx)
   uint32_t *d_flags = nullptr;
   void *d_sort_tmp = nullptr;
   uint64_t *d_scan_tmp = nullptr;
+  uint32_t *d_csr_off = nullptr;
   int rc = SHK_OK;
 
   auto cleanup = [&]() {
     (void)hipFree(d_bytes); (void)hipFree(d_rec_off); (void)hipFree(d_rec_has); (void)hipFree(d_n_valid); (void)hipFree(d_rec_nidx);
-    (void)hipFree(d_keys); (void)hipFree(d_keys_alt); (void)hipFree(d_flags); (void)hipFree(d_sort_tmp); (void)hipFree(d_scan_tmp);
+    (void)hipFree(d_keys); (void)hipFree(d_keys_alt); (void)hipFree(d_flags); (void)hipFree(d_sort_tmp); (void)hipFree(d_scan_tmp); (void)hipFree(d_csr_off);
   };
 #define BI_HIP(call)                                                   \
   do {                                                                 \
@@ -180,21 +211,21 @@ int build_index(Ctx *ctx)
 
     // ---- pass 1: set bits ---------------------------------------------------
     hipLaunchKernelGGL(ref_kmer_kernel<MODE_SET>, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st,
-                       d_bytes, total, d_rec_off, n_rec, k, ix.bf32, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
+                       d_bytes, total, d_rec_off, n_rec, k, ix.bf64, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
                        d_rec_has, d_n_valid, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0ull);
     BI_HIP(hipGetLastError());
     BI_HIP(hipMemcpyAsync(h_has.data(), d_rec_has, n_rec, hipMemcpyDeviceToHost, st));
   }
 
   // ---- switch_mode(1): rank directory -------------------------------------
-  const uint64_t n_blocks = ix.n_blocks;
-  BI_HIP(hipMalloc((void **)&ix.rank_blk, (n_blocks + 1) * sizeof(uint32_t)));
-  BI_HIP(hipMalloc((void **)&d_scan_tmp, scan_temp_words(std::max<uint64_t>(std::max<uint64_t>(n_blocks + 1, total), 1)) * sizeof(uint64_t)));
-  BI_HIP(hipMemsetAsync(ix.rank_blk + n_blocks, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(bf_block_popcount_kernel, dim3(grid_for(n_blocks * 4, 256)), dim3(256), 0, st,
-                     reinterpret_cast<const uint4 *>(ix.bf32), n_blocks * 4, ix.rank_blk);
+  const uint64_t n_words = ix.bf_words64;   // multiple of 8
+  BI_HIP(hipMalloc((void **)&ix.rank_w, (n_words + 2) * sizeof(uint32_t)));
+  BI_HIP(hipMalloc((void **)&d_scan_tmp, scan_temp_words(std::max<uint64_t>(std::max<uint64_t>(n_words + 1, total), 1)) * sizeof(uint64_t)));
+  BI_HIP(hipMemsetAsync(ix.rank_w + n_words, 0, 2 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(bf_word_popcount_kernel, dim3(grid_for(n_words / 2, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const uint4 *>(ix.bf64), n_words / 2, ix.rank_w);
   BI_HIP(hipGetLastError());
-  const uint64_t *d_total = exclusive_scan_u32(ix.rank_blk, ix.rank_blk, n_blocks + 1, d_scan_tmp, st);
+  const uint64_t *d_total = exclusive_scan_u32(ix.rank_w, ix.rank_w, n_words + 1, d_scan_tmp, st);
   uint64_t n_set = 0;
   unsigned long long n_valid = 0;
   BI_HIP(hipMemcpyAsync(&n_set, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -222,7 +253,7 @@ int build_index(Ctx *ctx)
     if (h_has[r] && h_nidx[r] > 0xFFFFu) { cleanup(); ctx->last_error = "more than 65536 genes"; return SHK_ERR_TOO_MANY_GENES; }
 
   // ---- pass 2 + switch_mode(2): (rank, gene) keys -> sort -> unique -> CSR ----
-  BI_HIP(hipMalloc((void **)&ix.csr_off, (n_set + 2) * sizeof(uint32_t)));
+  BI_HIP(hipMalloc((void **)&d_csr_off, (n_set + 2) * sizeof(uint32_t)));
   uint64_t tot_idx = 0;
   if (n_valid > 0) {
     const uint64_t sentinel = n_set << 16;
@@ -231,8 +262,8 @@ int build_index(Ctx *ctx)
     BI_HIP(hipMalloc((void **)&d_keys, total * sizeof(uint64_t)));
     BI_HIP(hipMalloc((void **)&d_keys_alt, total * sizeof(uint64_t)));
     hipLaunchKernelGGL(ref_kmer_kernel<MODE_KEYS>, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st,
-                       d_bytes, total, d_rec_off, n_rec, k, ix.bf32, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
-                       (uint8_t *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)ix.rank_blk, (const uint32_t *)d_rec_nidx, d_keys, sentinel);
+                       d_bytes, total, d_rec_off, n_rec, k, ix.bf64, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
+                       (uint8_t *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)ix.rank_w, (const uint32_t *)d_rec_nidx, d_keys, sentinel);
     BI_HIP(hipGetLastError());
 
     // bits needed to order keys up to and including the sentinel
@@ -251,16 +282,42 @@ int build_index(Ctx *ctx)
     BI_HIP(hipMemcpyAsync(&tot_idx, d_tot, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     BI_HIP(hipStreamSynchronize(st));
     if (tot_idx >= (1ull << 31)) { cleanup(); ctx->last_error = "index has >= 2^31 list entries (int tot_idx, bloomfilter.h:130)"; return SHK_ERR_INDEX_TOO_LARGE; }
-    BI_HIP(hipMalloc((void **)&ix.csr_ids, (tot_idx + 8) * sizeof(uint16_t)));
-    hipLaunchKernelGGL(csr_write_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, (const uint32_t *)d_flags, total, sentinel, ix.csr_off, ix.csr_ids);
+    BI_HIP(hipMalloc((void **)&ix.ids, (tot_idx + 8) * sizeof(uint16_t)));
+    hipLaunchKernelGGL(csr_write_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, (const uint32_t *)d_flags, total, sentinel, d_csr_off, ix.ids);
     BI_HIP(hipGetLastError());
   } else {
-    BI_HIP(hipMalloc((void **)&ix.csr_ids, 8 * sizeof(uint16_t)));
+    BI_HIP(hipMalloc((void **)&ix.ids, 8 * sizeof(uint16_t)));
   }
   const uint32_t tot32 = (uint32_t)tot_idx;
-  BI_HIP(hipMemcpyAsync(ix.csr_off + n_set, &tot32, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  BI_HIP(hipStreamSynchronize(st));
+  BI_HIP(hipMemcpyAsync(d_csr_off + n_set, &tot32, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  BI_HIP(hipMalloc((void **)&ix.ent, (n_set + 1) * sizeof(ListEntry)));
+  hipLaunchKernelGGL(list_entry_kernel, dim3(grid_for(n_set + 1, 256)), dim3(256), 0, st, (const uint32_t *)d_csr_off, (const uint16_t *)ix.ids, n_set, tot32, ix.ent);
+  BI_HIP(hipGetLastError());
   ix.tot_idx = tot_idx;
+
+  // ---- summary level (result preserving) -------------------------
+  // a clear summary bit proves 2^shift filter bits clear.  Use it when it can
+  // live in L2 (<= 2^24 bits) and passes <= 5 % of random probes, else when it
+  // fits the Infinity Cache (<= 2^30 bits) and passes <= 50 %; otherwise not.
+  ix.sum_shift = 0;
+  if (ix.pow2 && ix.bf_bits >= (1ull << 12) && n_set > 0) {
+    auto pass_rate = [&](uint32_t sh) { return 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits); };
+    uint32_t lg = 0;
+    while ((1ull << lg) < ix.bf_bits) ++lg;
+    const uint32_t sh_l2 = std::max<uint32_t>(6, lg > 24 ? lg - 24 : 6);
+    const uint32_t sh_ic = std::max<uint32_t>(6, lg > 30 ? lg - 30 : 6);
+    if (sh_l2 < lg && pass_rate(sh_l2) <= 0.05) ix.sum_shift = sh_l2;
+    else if (sh_ic < lg && pass_rate(sh_ic) <= 0.5) ix.sum_shift = sh_ic;
+  }
+  if (ix.sum_shift) {
+    ix.sum_bits = ix.bf_bits >> ix.sum_shift;
+    const uint64_t sw = (ix.sum_bits + 31) / 32 + 2;
+    BI_HIP(hipMalloc((void **)&ix.sum32, sw * sizeof(uint32_t)));
+    BI_HIP(hipMemsetAsync(ix.sum32, 0, sw * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(bf_summary_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words, ix.sum_shift, ix.sum32);
+    BI_HIP(hipGetLastError());
+  }
+  BI_HIP(hipStreamSynchronize(st));
   cleanup();
 #undef BI_HIP
   return SHK_OK;

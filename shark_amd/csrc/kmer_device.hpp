@@ -115,23 +115,12 @@ __device__ __forceinline__ uint64_t bf_pos(uint64_t h, uint64_t bits, uint64_t m
 }
 
 // rank of a set bit = number of ones in [0,pos) (bloomfilter.h:70 _brank(bf_idx);
-// :90 uses rank(pos+1) 1-based -- the same list).  512-bit blocks: one
-// directory word + the 64-byte line that holds the probed bit.
-__device__ __forceinline__ uint32_t bf_rank(const uint32_t *__restrict__ bf32, const uint32_t *__restrict__ rank_blk, uint64_t pos)
+// :90 uses rank(pos+1), 1-based -- the same list).  One directory word per
+// 64-bit filter word, so the word that was probed is all that is needed.
+__device__ __forceinline__ uint32_t bf_rank(const uint32_t *__restrict__ rank_w, uint64_t word, uint64_t pos)
 {
-  const uint64_t blk = pos >> 9;
-  const uint4 *bp = reinterpret_cast<const uint4 *>(bf32 + (blk << 4));
-  const uint4 q0 = bp[0], q1 = bp[1], q2 = bp[2], q3 = bp[3];
-  const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-  const uint32_t wi = (uint32_t)(pos >> 5) & 15u;
-  const uint32_t bit = (uint32_t)pos & 31u;
-  uint32_t r = rank_blk[blk];
-#pragma unroll
-  for (uint32_t i = 0; i < 16; ++i) {
-    const uint32_t m = i < wi ? 0xFFFFFFFFu : (i == wi ? ((1u << bit) - 1u) : 0u);
-    r += __builtin_popcount(w[i] & m);
-  }
-  return r;
+  const uint64_t below = word & ((1ull << (pos & 63u)) - 1ull);
+  return rank_w[pos >> 6] + (uint32_t)__builtin_popcountll(below);
 }
 
 // wave64 reductions (all 64 lanes must participate)

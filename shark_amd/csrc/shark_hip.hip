@@ -24,7 +24,7 @@ int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
 
 static void free_index(DeviceIndex &ix)
 {
-  hipFree(ix.bf32); hipFree(ix.rank_blk); hipFree(ix.csr_off); hipFree(ix.csr_ids);
+  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32);
   ix = DeviceIndex{};
 }
 
@@ -53,7 +53,8 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
 
   ClassifyParams p{};
   const DeviceIndex &ix = ctx->idx;
-  p.bf32 = ix.bf32; p.rank_blk = ix.rank_blk; p.csr_off = ix.csr_off; p.csr_ids = ix.csr_ids;
+  p.bf64 = ix.bf64; p.rank_w = ix.rank_w; p.ent = ix.ent; p.ids = ix.ids;
+  p.sum32 = ix.sum_shift ? ix.sum32 : nullptr; p.sum_shift = ix.sum_shift;
   p.bf_bits = ix.bf_bits; p.bf_mask = ix.bf_bits - 1;
   p.k = ctx->prm.k; p.c = ctx->prm.c; p.single = ctx->prm.single;
   p.mq = ctx->prm.min_quality ? ctx->prm.min_quality + 33 : 0;  // FastqSplitter.hpp:70
@@ -63,7 +64,7 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   p.qual1 = (const uint8_t *)b->qual1; p.qual2 = (const uint8_t *)b->qual2;
   p.count = ctx->d_count; p.inl = ctx->d_inl;
   p.counters = ctx->d_counters; p.long_queue = ctx->d_long_queue; p.tie_queue = ctx->d_tie_queue;
-  p.gene_counts = ctx->d_gene_counts;
+  p.gene_counts = wc ? nullptr : ctx->d_gene_counts;
   p.work_counters = nullptr;
 
   const bool paired = b->seq2 != nullptr;
@@ -124,14 +125,17 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
     SHK_HIP(ctx, hipStreamSynchronize(st));
   }
   const uint32_t n_tie = ctx->h_counters[CTR_TIE];
-  const uint64_t n_assoc = (uint64_t)ctx->h_counters[CTR_ASSOC_LO] | ((uint64_t)ctx->h_counters[CTR_ASSOC_HI] << 32);
-  if (n_assoc >= 0xFFFFFFFFull) { ctx->last_error = "more than 2^32-1 associations in one batch"; return SHK_ERR_ARG; }
 
-  // associations -> CSR (gene_off, gene_ids)
-  if ((rc = ensure_capacity(ctx, &ctx->d_gene_ids, &ctx->cap_gene_ids, n_assoc + 8))) return rc;
-  exclusive_scan_u32(ctx->d_count, ctx->d_gene_off, n + 1, ctx->d_scan_temp, st);
+  // associations -> CSR (gene_off, gene_ids); the grand total of the scan is the number of associations
+  const uint64_t *d_total = exclusive_scan_u32(ctx->d_count, ctx->d_gene_off, n + 1, ctx->d_scan_temp, st);
   SHK_HIP(ctx, hipGetLastError());
-  if ((rc = launch_gather_inline(ctx->d_count, ctx->d_inl, ctx->d_gene_off, ctx->d_gene_ids, n, st))) return rc;
+  uint64_t *h_total = reinterpret_cast<uint64_t *>(ctx->h_counters + CTR_WORDS);
+  SHK_HIP(ctx, hipMemcpyAsync(h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  SHK_HIP(ctx, hipStreamSynchronize(st));
+  const uint64_t n_assoc = *h_total;
+  if (n_assoc >= 0xFFFFFFFFull) { ctx->last_error = "more than 2^32-1 associations in one batch"; return SHK_ERR_ARG; }
+  if ((rc = ensure_capacity(ctx, &ctx->d_gene_ids, &ctx->cap_gene_ids, n_assoc + 8))) return rc;
+  if ((rc = launch_gather_inline(ctx->d_count, ctx->d_inl, ctx->d_gene_off, ctx->d_gene_ids, n, wc ? nullptr : ctx->d_gene_counts, st))) return rc;
   if (n_tie) {
     unsigned n_waves = 0;
     if ((rc = size_scratch(n_tie, &n_waves))) return rc;
@@ -220,16 +224,15 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   DeviceIndex &ix = ctx->idx;
   ix.bf_bits = prm->bf_bits;
   ix.pow2 = (prm->bf_bits & (prm->bf_bits - 1)) == 0;
-  ix.n_blocks = (prm->bf_bits + 511) / 512;
-  ix.bf_words32 = ix.n_blocks * 16;
+  ix.bf_words64 = ((prm->bf_bits + 511) / 512) * 8;
   // BF::BF(size): size zero bits (bloomfilter.h:48-53)
-  CR_HIP(hipMalloc((void **)&ix.bf32, ix.bf_words32 * sizeof(uint32_t)));
-  CR_HIP(hipMemsetAsync(ix.bf32, 0, ix.bf_words32 * sizeof(uint32_t), ctx->stream));
+  CR_HIP(hipMalloc((void **)&ix.bf64, ix.bf_words64 * sizeof(uint64_t)));
+  CR_HIP(hipMemsetAsync(ix.bf64, 0, ix.bf_words64 * sizeof(uint64_t), ctx->stream));
   CR_HIP(hipMalloc((void **)&ctx->d_counters, CTR_WORDS * sizeof(uint32_t)));
   CR_HIP(hipMalloc((void **)&ctx->d_gene_counts, 65536 * sizeof(unsigned long long)));
   CR_HIP(hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
   CR_HIP(hipMalloc((void **)&ctx->d_work_counters, 4 * sizeof(unsigned long long)));
-  CR_HIP(hipHostMalloc((void **)&ctx->h_counters, CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  CR_HIP(hipHostMalloc((void **)&ctx->h_counters, (CTR_WORDS + 2) * sizeof(uint32_t), hipHostMallocDefault));
   CR_HIP(hipStreamSynchronize(ctx->stream));
 #undef CR_HIP
   *out = ctx;
@@ -301,7 +304,7 @@ int shk_index_copy_bf(const shk_ctx *cctx, uint64_t *words, uint64_t n_words)
   const uint64_t have = (ctx->idx.bf_bits + 63) / 64;
   if (n_words > have) return SHK_ERR_ARG;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
-  SHK_HIP(ctx, hipMemcpy(words, ctx->idx.bf32, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  SHK_HIP(ctx, hipMemcpy(words, ctx->idx.bf64, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SHK_OK;
 }
 
@@ -311,9 +314,12 @@ int shk_index_copy_lists(const shk_ctx *cctx, uint32_t *offsets, uint16_t *ids)
   if (!ctx || !offsets) return SHK_ERR_ARG;
   if (ctx->mode != 2) return SHK_ERR_STATE;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
-  SHK_HIP(ctx, hipMemcpy(offsets, ctx->idx.csr_off, (ctx->idx.n_set + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<ListEntry> ent;
+  try { ent.resize(ctx->idx.n_set + 1); } catch (...) { return SHK_ERR_NOMEM; }
+  SHK_HIP(ctx, hipMemcpy(ent.data(), ctx->idx.ent, ent.size() * sizeof(ListEntry), hipMemcpyDeviceToHost));
+  for (size_t r = 0; r < ent.size(); ++r) offsets[r] = ent[r].start;
   if (ctx->idx.tot_idx && ids)
-    SHK_HIP(ctx, hipMemcpy(ids, ctx->idx.csr_ids, ctx->idx.tot_idx * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    SHK_HIP(ctx, hipMemcpy(ids, ctx->idx.ids, ctx->idx.tot_idx * sizeof(uint16_t), hipMemcpyDeviceToHost));
   return SHK_OK;
 }
 

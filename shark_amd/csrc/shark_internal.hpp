@@ -13,22 +13,38 @@ namespace shk {
 
 // ---- device-resident index (immutable after shk_ref_finalize) -------------
 // HBM layout:
-//   bf32      : the Bloom filter, sdsl::bit_vector word layout (LSB-first
-//               64-bit words == LSB-first 32-bit words on a little-endian
-//               device), padded with zero words to a multiple of 512 bits.
-//   rank_blk  : uint32 ones-before-block directory, one entry per 512-bit
-//               (64-byte) block, + 1 sentinel = n_set.
-//   csr_off   : uint32[n_set+1], list r = ids[csr_off[r] .. csr_off[r+1])
-//   csr_ids   : uint16 gene indices, ascending and unique inside a list.
+//   bf64     : the Bloom filter, sdsl::bit_vector layout (LSB-first 64-bit
+//              words), zero-padded to a multiple of 512 bits.
+//   rank_w   : uint32 ones-before-word directory, one entry per 64-bit word
+//              (+1 sentinel = n_set): rank(pos) = rank_w[pos>>6] +
+//              popcount(word & below(pos)) -- the probed word is all it needs.
+//   ent      : one 8-byte entry per set bit r (r = rank): {start, len, first
+//              gene} of its gene list; ids[start .. start+len) is the list.
+//              (+1 sentinel {tot_idx,0,0}).  Explicit form of
+//              _bv/_select_bv/_index_kmer (bloomfilter.h:142-167).
+//   ids      : uint16 gene indices, ascending and unique inside a list.
+//   sum32    : optional summary level: bit j = OR of filter bits
+//              [j<<sum_shift, (j+1)<<sum_shift).  A clear summary bit proves
+//              the filter bit clear, so the result of every probe is
+//              unchanged; sized to stay in L2 (sparse filters) or in the
+//              Infinity Cache.  Only for power-of-two filter sizes.
+struct ListEntry {
+  uint32_t start;
+  uint16_t len;     // clipped at 0xFFFF: then the true end is the next entry's start
+  uint16_t gene0;   // first gene of the list
+};
+
 struct DeviceIndex {
-  uint32_t *bf32 = nullptr;
+  uint64_t *bf64 = nullptr;
   uint64_t bf_bits = 0;
-  uint64_t bf_words32 = 0;   // padded
-  uint64_t n_blocks = 0;     // 512-bit blocks
+  uint64_t bf_words64 = 0;   // padded to whole 512-bit blocks
   bool pow2 = false;
-  uint32_t *rank_blk = nullptr;
-  uint32_t *csr_off = nullptr;
-  uint16_t *csr_ids = nullptr;
+  uint32_t *rank_w = nullptr;
+  ListEntry *ent = nullptr;
+  uint16_t *ids = nullptr;
+  uint32_t *sum32 = nullptr;
+  uint32_t sum_shift = 0;    // 0 = no summary level
+  uint64_t sum_bits = 0;
   uint64_t n_set = 0;
   uint64_t tot_idx = 0;
 };
@@ -36,10 +52,12 @@ struct DeviceIndex {
 // ---- classify kernel parameters (passed by value) --------------------------
 struct ClassifyParams {
   // index
-  const uint32_t *bf32;
-  const uint32_t *rank_blk;
-  const uint32_t *csr_off;
-  const uint16_t *csr_ids;
+  const uint64_t *bf64;
+  const uint32_t *rank_w;
+  const ListEntry *ent;
+  const uint16_t *ids;
+  const uint32_t *sum32;
+  uint32_t sum_shift;
   uint64_t bf_bits;
   uint64_t bf_mask;
   // options
@@ -82,8 +100,8 @@ struct ClassifyParams {
 enum {
   CTR_LONG = 0,      // entries in long_queue
   CTR_TIE = 1,       // entries in tie_queue
-  CTR_ASSOC_LO = 2,  // total associations (64-bit, two words)
-  CTR_ASSOC_HI = 3,
+  CTR_UNUSED2 = 2,
+  CTR_UNUSED3 = 3,
   CTR_MAX_SLOTS = 4, // max k-mer slots over queued long reads
   CTR_MAX_BASES = 5, // max packed length over queued long reads
   CTR_WORDS = 8
@@ -97,7 +115,8 @@ int build_index(Ctx *ctx);
 // classify.hip
 int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream);
 int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream);
-int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n, hipStream_t stream);
+int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n,
+                         unsigned long long *gene_counts, hipStream_t stream);
 uint32_t fast_kernel_max_slots();
 uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
 
@@ -129,7 +148,7 @@ struct Ctx {
   uint64_t *d_scratch = nullptr;   size_t cap_scratch = 0;
   unsigned long long *d_gene_counts = nullptr;
   unsigned long long *d_work_counters = nullptr;
-  uint32_t *h_counters = nullptr;  // pinned
+  uint32_t *h_counters = nullptr;  // pinned, CTR_WORDS + 2 (the scan total lands behind the counters)
 
   // host result buffers
   std::vector<uint32_t> h_gene_off;
