@@ -129,8 +129,6 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     reinterpret_cast<uint8_t *>(st.vbits)[gi] = (uint8_t)valid8;
     my_valid += __builtin_popcount(valid8);
   }
-  // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49)
-  const uint32_t len = wave_sum_u32(my_valid);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -139,6 +137,11 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   const uint64_t kmask = (1ull << k) - 1ull;
   bool any_hit = false;
   unsigned long long wk_kmers = 0, wk_hits = 0, wk_ids = 0;
+  // slot records of the (single) round of the fast kernel live in registers
+  uint32_t cur[U], rs[U], re[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) { cur[j] = GENE_INF; rs[j] = 0; re[j] = 0; }
+
   for (uint32_t base = 0; base < ns; base += 64 * U) {
     uint64_t pos[U];
     uint64_t word[U];
@@ -191,23 +194,40 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     }
     if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
     any_hit |= round_any;
-    // ---- hits: rank -> list range (bloomfilter.h:90-94) ----------------------
+    // ---- hits: rank -> list entry (bloomfilter.h:90-94).  Unconditional loads
+    // from safe addresses (entry 0 for non-hits) so the U chains overlap. ----
+    if (round_any) {
+      uint32_t rw[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const uint32_t t = base + lane + 64 * j;
-      if (t < ns) {
-        uint32_t s = 0, e = 0, g = GENE_INF;
+      for (int j = 0; j < U; ++j) rw[j] = P.rank_w[hit[j] ? (pos[j] >> 6) : 0ull];
+      ListEntry le[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint64_t below = word[j] & ((1ull << (pos[j] & 63u)) - 1ull);
+        const uint32_t r = hit[j] ? rw[j] + (uint32_t)__builtin_popcountll(below) : 0u;
+        rw[j] = r;
+        le[j] = P.ent[r];
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
         if (hit[j]) {
-          const uint32_t r = bf_rank(P.rank_w, word[j], pos[j]);
-          const ListEntry le = P.ent[r];
-          s = le.start;
-          e = le.len != 0xFFFFu ? s + le.len : P.ent[r + 1].start;
-          g = le.gene0;
-          if (P.work_counters) wk_ids += e - s;
+          rs[j] = le[j].start;
+          re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : P.ent[rw[j] + 1].start;
+          cur[j] = le[j].gene0;
+          if (P.work_counters) wk_ids += re[j] - rs[j];
+        } else {
+          rs[j] = 0; re[j] = 0; cur[j] = GENE_INF;
         }
-        st.rec_start[t] = s;
-        st.rec_end[t] = e;
-        st.cur[t] = g;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = GENE_INF; }
+    }
+    if (!FAST) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t t = base + lane + 64 * j;
+        if (t < ns) { st.rec_start[t] = rs[j]; st.rec_end[t] = re[j]; st.cur[t] = cur[j]; }
       }
     }
   }
@@ -224,41 +244,62 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   uint32_t best_cov = 0, best_nk = 0, n_best = 0;
   uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
   uint32_t n_emit = 0;
+  uint32_t len = 0;
   if (any_hit) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49);
+    // only needed for the threshold, i.e. when something hit
+    len = wave_sum_u32(my_valid);
+    if (!FAST) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     const uint32_t out_base = EMIT ? P.gene_off[read] : 0u;
     // ---- k-way merge over the hit lists, ascending gene id -------------------
     for (;;) {
       uint32_t mymin = GENE_INF;
-      for (uint32_t t = lane; t < ns; t += 64) {
-        const uint32_t g = st.cur[t];
-        mymin = g < mymin ? g : mymin;
+      if (FAST) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) mymin = cur[j] < mymin ? cur[j] : mymin;
+      } else {
+        for (uint32_t t = lane; t < ns; t += 64) {
+          const uint32_t g = st.cur[t];
+          mymin = g < mymin ? g : mymin;
+        }
       }
       const uint32_t g = wave_min_u32(mymin);
       if (g == GENE_INF) break;
       uint32_t contrib = 0, nk = 0;
       uint64_t hprev = 0;
-      for (uint32_t tb = 0; tb < ns; tb += 64) {
-        const uint32_t t = tb + lane;
-        const bool h = t < ns && st.cur[t] == g;
+      // one 64-slot chunk: hit mask by ballot, distance to the previous hit by clz
+      auto chunk = [&](const bool h, const uint32_t t, uint32_t &c_rs, const uint32_t c_re, uint32_t &c_cur) {
         const uint64_t H = __ballot(h);
         nk += (uint32_t)__builtin_popcountll(H);
         if (h) {
-          // distance (in slots = bases) to the previous k-mer of this gene
           const uint64_t below = H & ((1ull << lane) - 1ull);
           uint32_t d = k;
           if (below) d = lane - (63u - (uint32_t)__builtin_clzll(below));
           else if (hprev) d = lane + 1u + (uint32_t)__builtin_clzll(hprev);
           if (t >= nk1 && t - d < nk1) d = k;  // previous hit is in the other mate
           contrib += d < k ? d : k;            // min(k, pos - last)  ReadAnalyzer.hpp:81
-          // advance this slot's cursor past g
-          const uint32_t s = st.rec_start[t] + 1u;
-          st.rec_start[t] = s;
-          st.cur[t] = s < st.rec_end[t] ? (uint32_t)P.ids[s] : GENE_INF;
+          c_rs += 1u;                          // advance this slot's cursor past g
+          c_cur = c_rs < c_re ? (uint32_t)P.ids[c_rs] : GENE_INF;
         }
         hprev = H;
+      };
+      if (FAST) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) chunk(cur[j] == g, (uint32_t)lane + 64u * j, rs[j], re[j], cur[j]);
+      } else {
+        for (uint32_t tb = 0; tb < ns; tb += 64) {
+          const uint32_t t = tb + lane;
+          const bool in = t < ns;
+          uint32_t c_rs = in ? st.rec_start[t] : 0u, c_cur = in ? st.cur[t] : GENE_INF;
+          const uint32_t c_re = in ? st.rec_end[t] : 0u;
+          const bool h = c_cur == g;
+          chunk(h, t, c_rs, c_re, c_cur);
+          if (h) { st.rec_start[t] = c_rs; st.cur[t] = c_cur; }
+        }
       }
       const uint32_t cov = wave_sum_u32(contrib);
       if (EMIT) {
@@ -270,20 +311,18 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
           ++n_emit;
         }
       } else {
-        // arg-max with ties in ascending gene order (ReadAnalyzer.hpp:90-102)
-        if (cov > best_cov || (cov == best_cov && nk > best_nk)) {
-          best_cov = cov;
-          best_nk = nk;
-          n_best = 1;
-          best_id[0] = g;
-        } else if (cov == best_cov && nk == best_nk) {
-          if (n_best < SHK_INLINE_IDS) {
+        // arg-max with ties in ascending gene order (ReadAnalyzer.hpp:90-102).
+        // Written as selects on two predicates: hipcc (ROCm 7.2) drops the
+        // best_id[0] update on the `cov == best && nk > best_nk` edge when this
+        // is an if/else-if chain over wave-uniform (SGPR) values.
+        const bool gt = (cov > best_cov) | ((cov == best_cov) & (nk > best_nk));
+        const bool eq = (cov == best_cov) & (nk == best_nk);
+        best_id[0] = gt ? g : best_id[0];
 #pragma unroll
-            for (int i = 1; i < SHK_INLINE_IDS; ++i)
-              if ((int)n_best == i) best_id[i] = g;
-          }
-          ++n_best;
-        }
+        for (int i = 1; i < SHK_INLINE_IDS; ++i) best_id[i] = (eq & (n_best == (uint32_t)i)) ? g : best_id[i];
+        n_best = gt ? 1u : (eq ? n_best + 1u : n_best);
+        best_cov = gt ? cov : best_cov;
+        best_nk = gt ? nk : best_nk;
       }
     }
   }
@@ -319,7 +358,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const Classif
 {
   constexpr uint32_t S = 64 * U;
   constexpr uint32_t CW = code_words_for(S), VW = vbit_words_for(S);
-  constexpr uint32_t WORDS = CW + VW + (3 * S) / 2;
+  constexpr uint32_t WORDS = CW + VW;   // slot records stay in registers
   __shared__ uint64_t lds[CF_WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -327,9 +366,9 @@ __global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const Classif
   WaveStore st;
   st.codes = base;
   st.vbits = base + CW;
-  st.rec_start = reinterpret_cast<uint32_t *>(base + CW + VW);
-  st.rec_end = st.rec_start + S;
-  st.cur = st.rec_end + S;
+  st.rec_start = nullptr;
+  st.rec_end = nullptr;
+  st.cur = nullptr;
   const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
   for (uint64_t read = (uint64_t)blockIdx.x * CF_WAVES + wave; read < P.n; read += stride)
     process_read<U, POW2, SUM, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);

@@ -123,21 +123,32 @@ __device__ __forceinline__ uint32_t bf_rank(const uint32_t *__restrict__ rank_w,
   return rank_w[pos >> 6] + (uint32_t)__builtin_popcountll(below);
 }
 
-// wave64 reductions (all 64 lanes must participate)
+// wave64 reductions on the DPP network (no LDS traffic; all 64 lanes must be
+// active).  quad_perm swaps, row mirrors, then row_bcast15 / row_bcast31 fold
+// the four 16-lane rows; lane 63 ends up with the result.
+#define SHK_DPP(old_, v_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((int)(old_), (int)(v_), (ctrl_), (rmask_), 0xF, false)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = __shfl_xor(v, o, 64);
-    v = t < v ? t : v;
-  }
-  return v;
+  constexpr uint32_t I = 0xFFFFFFFFu;
+  uint32_t t;
+  t = (uint32_t)SHK_DPP(I, v, 0xB1, 0xF); v = t < v ? t : v;    // quad_perm [1,0,3,2]
+  t = (uint32_t)SHK_DPP(I, v, 0x4E, 0xF); v = t < v ? t : v;    // quad_perm [2,3,0,1]
+  t = (uint32_t)SHK_DPP(I, v, 0x141, 0xF); v = t < v ? t : v;   // row_half_mirror
+  t = (uint32_t)SHK_DPP(I, v, 0x140, 0xF); v = t < v ? t : v;   // row_mirror
+  t = (uint32_t)SHK_DPP(I, v, 0x142, 0xA); v = t < v ? t : v;   // row_bcast15 -> rows 1,3
+  t = (uint32_t)SHK_DPP(I, v, 0x143, 0xC); v = t < v ? t : v;   // row_bcast31 -> rows 2,3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += (uint32_t)SHK_DPP(0, v, 0xB1, 0xF);
+  v += (uint32_t)SHK_DPP(0, v, 0x4E, 0xF);
+  v += (uint32_t)SHK_DPP(0, v, 0x141, 0xF);
+  v += (uint32_t)SHK_DPP(0, v, 0x140, 0xF);
+  v += (uint32_t)SHK_DPP(0, v, 0x142, 0xA);
+  v += (uint32_t)SHK_DPP(0, v, 0x143, 0xC);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+#undef SHK_DPP
 
 }  // namespace shk
