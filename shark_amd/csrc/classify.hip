@@ -193,6 +193,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       for (int j = 0; j < U; ++j) wk_hits += hit[j];
     }
     if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
+    if (P.ablate & 1u) break;       // ablation: stop after the probes
     any_hit |= round_any;
     // ---- hits: rank -> list entry (bloomfilter.h:90-94).  Unconditional loads
     // from safe addresses (entry 0 for non-hits) so the U chains overlap. ----
@@ -245,7 +246,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
   uint32_t n_emit = 0;
   uint32_t len = 0;
-  if (any_hit) {
+  if (any_hit && !(P.ablate & 2u)) {   // ablation 2: skip the vote
     // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49);
     // only needed for the threshold, i.e. when something hit
     len = wave_sum_u32(my_valid);

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "device_scan.hpp"
@@ -300,7 +301,7 @@ int build_index(Ctx *ctx)
   // live in L2 (<= 2^24 bits) and passes <= 5 % of random probes, else when it
   // fits the Infinity Cache (<= 2^30 bits) and passes <= 50 %; otherwise not.
   ix.sum_shift = 0;
-  if (ix.pow2 && ix.bf_bits >= (1ull << 12) && n_set > 0) {
+  if (ix.pow2 && ix.bf_bits >= (1ull << 12) && n_set > 0 && !getenv("SHK_NO_SUMMARY")) {
     auto pass_rate = [&](uint32_t sh) { return 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits); };
     uint32_t lg = 0;
     while ((1ull << lg) < ix.bf_bits) ++lg;

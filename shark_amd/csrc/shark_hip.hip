@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -66,6 +67,7 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   p.counters = ctx->d_counters; p.long_queue = ctx->d_long_queue; p.tie_queue = ctx->d_tie_queue;
   p.gene_counts = wc ? nullptr : ctx->d_gene_counts;
   p.work_counters = nullptr;
+  p.ablate = getenv("SHK_ABLATE") ? (uint32_t)atoi(getenv("SHK_ABLATE")) : 0u;
 
   const bool paired = b->seq2 != nullptr;
   uint32_t max_slots = max_read_len ? slots_for_len(max_read_len, p.k, paired) : 0;

@@ -95,6 +95,8 @@ struct ClassifyParams {
   uint16_t *gene_ids;
   // work counters (count_work build only)
   unsigned long long *work_counters;
+  // timing-only ablation switches (env SHK_ABLATE; results are wrong when set; never set in tests/bench)
+  uint32_t ablate;
 };
 
 enum {
