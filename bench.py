@@ -180,7 +180,7 @@ def main():
                    "pairs_per_step_per_gpu": n, "reads_per_step": reads_per_step, "on_target": args.on_target,
                    "seed": synth.SEED, "index_build_s": round(t_build, 3), "n_set_bits": int(info["n_set_bits"]),
                    "assoc_per_step": int(n_assoc.item()), "gene_count_checksum": int(counts.sum().item()),
-                   "long_reads": int(tm["last_n_long"]), "tie_reads": int(tm["last_n_tie"])},
+                   "long_reads": int(tm["last_n_long"]), "tie_reads": int(tm["last_n_tie"]), "probe_mode": h.probe_mode()},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

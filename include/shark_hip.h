@@ -80,6 +80,11 @@ typedef struct shk_index_info {
   uint64_t n_ref_kmers;  /* valid reference k-mer occurrences hashed */
 } shk_index_info;
 int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
+/* How the classify kernels look a k-mer's filter position up on this index:
+ * "bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table"
+ * (every mode returns exactly the filter's bit).  Environment
+ * SHK_PROBE=bitvector at finalize time disables the table (tests use it). */
+const char *shk_probe_mode(const shk_ctx *ctx);
 
 /* Parity introspection: copy the device-resident index to host buffers.
  * words: (bf_bits+63)/64 uint64_t in sdsl::bit_vector layout, bit i =

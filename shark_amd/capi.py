@@ -48,7 +48,7 @@ EXPORTS = [
     "shk_create", "shk_destroy", "shk_strerror", "shk_last_error", "shk_ref_add", "shk_ref_finalize",
     "shk_index_info_get", "shk_index_copy_bf", "shk_index_copy_lists", "shk_classify", "shk_classify_device",
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
-    "shk_alloc_pinned", "shk_free_pinned", "shk_version",
+    "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode",
 ]
 
 _lib = None
@@ -88,6 +88,7 @@ def load():
     L.shk_alloc_pinned.restype = p; L.shk_alloc_pinned.argtypes = [C.c_size_t]
     L.shk_free_pinned.restype = None; L.shk_free_pinned.argtypes = [p]
     L.shk_version.restype = C.c_char_p; L.shk_version.argtypes = []
+    L.shk_probe_mode.restype = C.c_char_p; L.shk_probe_mode.argtypes = [p]
     _lib = L
     return L
 
@@ -150,6 +151,9 @@ class SharkHip:
         info = ShkIndexInfo()
         self._check(self.L.shk_index_info_get(self.h, C.byref(info)), "shk_index_info_get")
         return {f: getattr(info, f) for f, _ in ShkIndexInfo._fields_}
+
+    def probe_mode(self):
+        return self.L.shk_probe_mode(self.h).decode()
 
     def copy_bf(self):
         nw = (self.bf_bits + 63) // 64

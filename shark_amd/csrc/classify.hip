@@ -42,6 +42,15 @@ constexpr int CF_WAVES = 4;              // wavefronts per workgroup
 constexpr int CF_THREADS = CF_WAVES * 64;
 constexpr uint32_t GENE_INF = 0xFFFFFFFFu;
 
+// how a k-mer's filter position is looked up (chosen per index at finalize time)
+enum ProbeMode {
+  PM_BV_MOD = 0,   // filter word, position = hash % size (non power-of-two sizes)
+  PM_BV = 1,       // filter word, position = hash & (size-1)
+  PM_BV_SUM = 2,   // summary level, then filter word
+  PM_TAB = 3,      // position table (exact sparse encoding of the set bits)
+  PM_TAB_SUM = 4   // summary level, then position table
+};
+
 // per-wave storage sizes (in 64-bit words) for a slot capacity S
 __host__ __device__ constexpr uint32_t code_words_for(uint32_t S) { return (S + 91 + 31) / 32 + 1; }
 __host__ __device__ constexpr uint32_t vbit_words_for(uint32_t S) { return (S + 91 + 63) / 64 + 2; }
@@ -69,10 +78,13 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p, uint32_t rem)
   return w;
 }
 
-template <int U, bool POW2, bool SUM, bool HASQ, bool FAST, bool EMIT>
+template <int U, int MODE, bool HASQ, bool FAST, bool EMIT>
 __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
                                              const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk)
 {
+  constexpr bool POW2 = MODE != PM_BV_MOD;
+  constexpr bool SUM = MODE == PM_BV_SUM || MODE == PM_TAB_SUM;
+  constexpr bool TAB = MODE == PM_TAB || MODE == PM_TAB_SUM;
   const uint32_t k = P.k;
   const uint64_t o1 = P.off1[read];
   const uint32_t L1 = (uint32_t)(P.off1[read + 1] - o1);
@@ -174,55 +186,137 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       for (int j = 0; j < U; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
 #pragma unroll
       for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
-#pragma unroll
-      for (int j = 0; j < U; ++j) word[j] = ok[j] ? P.bf64[pos[j] >> 6] : 0ull;
-    } else {
-#pragma unroll
-      for (int j = 0; j < U; ++j) word[j] = ok[j] ? __builtin_nontemporal_load(P.bf64 + (pos[j] >> 6)) : 0ull;
     }
     bool hit[U];
     bool lane_any = false;
+    if (TAB) {
+      // ---- position table: one 16-byte bucket answers membership AND the list ----
+      const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
+      const uint64_t bmask = (1ull << P.tab_lg) - 1ull;
+      uint4 bk[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      hit[j] = (word[j] >> (pos[j] & 63u)) & 1ull;
-      lane_any |= hit[j];
-    }
-    const bool round_any = __ballot(lane_any) != 0ull;
-    if (P.work_counters) {
-#pragma unroll
-      for (int j = 0; j < U; ++j) wk_hits += hit[j];
-    }
-    if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
-    if (P.ablate & 1u) break;       // ablation: stop after the probes
-    any_hit |= round_any;
-    // ---- hits: rank -> list entry (bloomfilter.h:90-94).  Unconditional loads
-    // from safe addresses (entry 0 for non-hits) so the U chains overlap. ----
-    if (round_any) {
-      uint32_t rw[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) rw[j] = P.rank_w[hit[j] ? (pos[j] >> 6) : 0ull];
-      ListEntry le[U];
+      for (int j = 0; j < U; ++j) bk[j] = tab16[ok[j] ? (pos[j] & bmask) : 0ull];
+      uint32_t payload[U];
+      bool multi[U], more[U];
+      bool lane_more = false;
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint64_t below = word[j] & ((1ull << (pos[j] & 63u)) - 1ull);
-        const uint32_t r = hit[j] ? rw[j] + (uint32_t)__builtin_popcountll(below) : 0u;
-        rw[j] = r;
-        le[j] = P.ent[r];
+        const uint32_t want = ((uint32_t)(pos[j] >> P.tab_lg) << 8) | 0x80u;   // tag, valid, displacement 0
+        const bool m0 = (bk[j].y & ~0x40u) == want, m1 = (bk[j].w & ~0x40u) == want;
+        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);                   // valid bit lives in the high word
+        hit[j] = ok[j] & (m0 | m1);
+        payload[j] = m0 ? bk[j].x : bk[j].z;
+        multi[j] = ((m0 ? bk[j].y : bk[j].w) >> 6) & 1u;
+        more[j] = ok[j] & !(m0 | m1) & !empty;
+        lane_more |= more[j];
       }
+      // rare: the home bucket was full of other keys -> walk the probe path
+      if (__ballot(lane_more)) {
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        if (hit[j]) {
-          rs[j] = le[j].start;
-          re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : P.ent[rw[j] + 1].start;
-          cur[j] = le[j].gene0;
-          if (P.work_counters) wk_ids += re[j] - rs[j];
-        } else {
-          rs[j] = 0; re[j] = 0; cur[j] = GENE_INF;
+        for (int j = 0; j < U; ++j) {
+          uint32_t d = 0;
+          while (more[j]) {
+            ++d;
+            const uint4 b2 = tab16[(pos[j] + d) & bmask];
+            const uint32_t want = ((uint32_t)(pos[j] >> P.tab_lg) << 8) | 0x80u | d;
+            const bool m0 = (b2.y & ~0x40u) == want, m1 = (b2.w & ~0x40u) == want;
+            if (m0 | m1) {
+              hit[j] = true;
+              payload[j] = m0 ? b2.x : b2.z;
+              multi[j] = ((m0 ? b2.y : b2.w) >> 6) & 1u;
+              more[j] = false;
+            } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
+              more[j] = false;
+            }
+          }
         }
       }
-    } else {
 #pragma unroll
-      for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = GENE_INF; }
+      for (int j = 0; j < U; ++j) lane_any |= hit[j];
+      const bool round_any = __ballot(lane_any) != 0ull;
+      if (P.work_counters) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) wk_hits += hit[j];
+      }
+      if (FAST && !round_any) break;
+      if (P.ablate & 1u) break;
+      any_hit |= round_any;
+      // multi-gene lists (rare): entry r gives start/len/first gene
+      bool lane_multi = false;
+#pragma unroll
+      for (int j = 0; j < U; ++j) lane_multi |= hit[j] & multi[j];
+      if (__ballot(lane_multi)) {
+        ListEntry le[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) le[j] = P.ent[(hit[j] & multi[j]) ? payload[j] : 0u];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (hit[j] & multi[j]) {
+            rs[j] = le[j].start;
+            re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : P.ent[payload[j] + 1].start;
+            cur[j] = le[j].gene0;
+          } else {
+            rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
+      }
+      if (P.work_counters) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) wk_ids += hit[j] ? (multi[j] ? re[j] - rs[j] : 1u) : 0u;
+      }
+    } else {
+      if (SUM) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) word[j] = ok[j] ? P.bf64[pos[j] >> 6] : 0ull;
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) word[j] = ok[j] ? __builtin_nontemporal_load(P.bf64 + (pos[j] >> 6)) : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        hit[j] = (word[j] >> (pos[j] & 63u)) & 1ull;
+        lane_any |= hit[j];
+      }
+      const bool round_any = __ballot(lane_any) != 0ull;
+      if (P.work_counters) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) wk_hits += hit[j];
+      }
+      if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
+      if (P.ablate & 1u) break;       // ablation: stop after the probes
+      any_hit |= round_any;
+      // ---- hits: rank -> list entry (bloomfilter.h:90-94).  Unconditional loads
+      // from safe addresses (entry 0 for non-hits) so the U chains overlap. ----
+      if (round_any) {
+        uint32_t rw[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) rw[j] = P.rank_w[hit[j] ? (pos[j] >> 6) : 0ull];
+        ListEntry le[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const uint64_t below = word[j] & ((1ull << (pos[j] & 63u)) - 1ull);
+          const uint32_t r = hit[j] ? rw[j] + (uint32_t)__builtin_popcountll(below) : 0u;
+          rw[j] = r;
+          le[j] = P.ent[r];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (hit[j]) {
+            rs[j] = le[j].start;
+            re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : P.ent[rw[j] + 1].start;
+            cur[j] = le[j].gene0;
+            if (P.work_counters) wk_ids += re[j] - rs[j];
+          } else {
+            rs[j] = 0; re[j] = 0; cur[j] = GENE_INF;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = GENE_INF; }
+      }
     }
     if (!FAST) {
 #pragma unroll
@@ -354,7 +448,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 // ---------------------------------------------------------------------------
 // fast kernel: everything per wave lives in LDS; slot capacity 64*U
 // ---------------------------------------------------------------------------
-template <int U, bool POW2, bool SUM, bool HASQ>
+template <int U, int MODE, bool HASQ>
 __global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const ClassifyParams P)
 {
   constexpr uint32_t S = 64 * U;
@@ -372,7 +466,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const Classif
   st.cur = nullptr;
   const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
   for (uint64_t read = (uint64_t)blockIdx.x * CF_WAVES + wave; read < P.n; read += stride)
-    process_read<U, POW2, SUM, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);
+    process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------
@@ -408,7 +502,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
     } else if (P.work) {
       read = P.work[w];
     }
-    process_read<U, POW2, false, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn);
+    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn);
   }
 }
 
@@ -460,30 +554,48 @@ uint32_t fast_kernel_unroll(uint32_t max_slots)
   return 8;
 }
 
-template <int U>
-static void launch_fast_u(const ClassifyParams &p, bool pow2, bool sum, bool hasq, unsigned grid, hipStream_t s)
+static int probe_mode(const DeviceIndex &ix)
 {
-#define LF(P2_, SM_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, P2_, SM_, HQ_>), dim3(grid), dim3(CF_THREADS), 0, s, p)
-  if (pow2 && sum) { if (hasq) LF(true, true, true); else LF(true, true, false); }
-  else if (pow2) { if (hasq) LF(true, false, true); else LF(true, false, false); }
-  else { if (hasq) LF(false, false, true); else LF(false, false, false); }
+  if (!ix.pow2) return PM_BV_MOD;
+  if (ix.tab_lg) return ix.tab_with_summary ? PM_TAB_SUM : PM_TAB;
+  return ix.sum_shift ? PM_BV_SUM : PM_BV;
+}
+
+const char *probe_mode_name(const Ctx *ctx)
+{
+  static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table"};
+  return names[probe_mode(ctx->idx)];
+}
+
+template <int U>
+static void launch_fast_u(const ClassifyParams &p, int mode, bool hasq, unsigned grid, hipStream_t s)
+{
+#define LF(M_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, M_, HQ_>), dim3(grid), dim3(CF_THREADS), 0, s, p)
+  switch (mode) {
+  case PM_BV_MOD: if (hasq) LF(PM_BV_MOD, true); else LF(PM_BV_MOD, false); break;
+  case PM_BV: if (hasq) LF(PM_BV, true); else LF(PM_BV, false); break;
+  case PM_BV_SUM: if (hasq) LF(PM_BV_SUM, true); else LF(PM_BV_SUM, false); break;
+  case PM_TAB: if (hasq) LF(PM_TAB, true); else LF(PM_TAB, false); break;
+  default: if (hasq) LF(PM_TAB_SUM, true); else LF(PM_TAB_SUM, false); break;
+  }
 #undef LF
 }
 
 int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
 {
   if (p.n == 0) return SHK_OK;
-  const bool pow2 = ctx->idx.pow2, hasq = p.mq != 0, sum = p.sum32 != nullptr;
+  const bool hasq = p.mq != 0;
+  const int mode = probe_mode(ctx->idx);
   // persistent grid: enough workgroups to fill 256 CUs several times over
   const uint64_t want = (p.n + CF_WAVES - 1) / CF_WAVES;
   const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
   const uint32_t u = fast_kernel_unroll(max_slots);
-  if (u == 2) launch_fast_u<2>(p, pow2, sum, hasq, grid, stream);
-  else if (u == 3) launch_fast_u<3>(p, pow2, sum, hasq, grid, stream);
-  else if (u == 4) launch_fast_u<4>(p, pow2, sum, hasq, grid, stream);
-  else if (u == 5) launch_fast_u<5>(p, pow2, sum, hasq, grid, stream);
-  else if (u == 6) launch_fast_u<6>(p, pow2, sum, hasq, grid, stream);
-  else launch_fast_u<8>(p, pow2, sum, hasq, grid, stream);
+  if (u == 2) launch_fast_u<2>(p, mode, hasq, grid, stream);
+  else if (u == 3) launch_fast_u<3>(p, mode, hasq, grid, stream);
+  else if (u == 4) launch_fast_u<4>(p, mode, hasq, grid, stream);
+  else if (u == 5) launch_fast_u<5>(p, mode, hasq, grid, stream);
+  else if (u == 6) launch_fast_u<6>(p, mode, hasq, grid, stream);
+  else launch_fast_u<8>(p, mode, hasq, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }

@@ -165,6 +165,39 @@ __global__ __launch_bounds__(256) void list_entry_kernel(const uint32_t *__restr
   ent[r] = e;
 }
 
+// position table: one thread per 64-bit filter word inserts its set bits.
+// slot claim by 64-bit CAS; an entry sits in the first bucket with a free slot
+// on its probe path, so an empty slot ends every unsuccessful search.
+__global__ __launch_bounds__(256) void table_build_kernel(const uint64_t *__restrict__ bf64, uint64_t n_words, const uint32_t *__restrict__ rank_w,
+                                                          const ListEntry *__restrict__ ent, unsigned long long *__restrict__ tab, uint32_t tab_lg,
+                                                          uint32_t *__restrict__ fail)
+{
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t word = bf64[w];
+  if (word == 0ull) return;
+  uint32_t r = rank_w[w];
+  const uint64_t bmask = (1ull << tab_lg) - 1ull;
+  while (word) {
+    const uint32_t b = (uint32_t)__builtin_ctzll(word);
+    word &= word - 1ull;
+    const uint64_t pos = (w << 6) | b;
+    const ListEntry le = ent[r];
+    const bool multi = le.len != 1;
+    const uint64_t base = ((pos >> tab_lg) << 40) | (1ull << 39) | ((uint64_t)multi << 38) | (uint64_t)(multi ? r : (uint32_t)le.gene0);
+    uint64_t bkt = pos & bmask;
+    bool done = false;
+    for (uint32_t d = 0; d < 64 && !done; ++d) {
+      const unsigned long long e = base | ((unsigned long long)d << 32);
+      for (int sidx = 0; sidx < 2 && !done; ++sidx)
+        done = atomicCAS(&tab[2 * bkt + sidx], 0ull, e) == 0ull;
+      bkt = (bkt + 1) & bmask;
+    }
+    if (!done) atomicAdd(fail, 1u);
+    ++r;
+  }
+}
+
 static unsigned grid_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
 
 int build_index(Ctx *ctx)
@@ -319,6 +352,40 @@ int build_index(Ctx *ctx)
     BI_HIP(hipGetLastError());
   }
   BI_HIP(hipStreamSynchronize(st));
+
+  // ---- position table: exact sparse encoding of the set bits -----
+  ix.tab_lg = 0;
+  const char *force = getenv("SHK_PROBE");   // "bitvector" disables the table (tests exercise both paths)
+  if (ix.pow2 && n_set > 0 && !(force && force[0] == 'b')) {
+    uint32_t lgB = 0;
+    while ((1ull << lgB) < ix.bf_bits) ++lgB;
+    uint32_t lg = 9;                                        // >= 512 buckets
+    while ((2ull << lg) < 4ull * n_set) ++lg;               // load factor <= 1/4
+    if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
+    if (lg < lgB) {
+      const uint64_t slots = 2ull << lg;
+      uint32_t *d_fail = nullptr;
+      BI_HIP(hipMalloc((void **)&ix.tab, slots * sizeof(uint64_t)));
+      BI_HIP(hipMemsetAsync(ix.tab, 0, slots * sizeof(uint64_t), st));
+      BI_HIP(hipMalloc((void **)&d_fail, sizeof(uint32_t)));
+      BI_HIP(hipMemsetAsync(d_fail, 0, sizeof(uint32_t), st));
+      hipLaunchKernelGGL(table_build_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words,
+                         (const uint32_t *)ix.rank_w, (const ListEntry *)ix.ent, reinterpret_cast<unsigned long long *>(ix.tab), lg, d_fail);
+      BI_HIP(hipGetLastError());
+      uint32_t h_fail = 0;
+      BI_HIP(hipMemcpyAsync(&h_fail, d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      BI_HIP(hipStreamSynchronize(st));
+      (void)hipFree(d_fail);
+      if (h_fail == 0) {
+        ix.tab_lg = lg;
+        // a table that stays in L2 needs no summary in front of it
+        ix.tab_with_summary = ix.sum_shift != 0 && slots * sizeof(uint64_t) > (4ull << 20);
+      } else {
+        (void)hipFree(ix.tab);   // displacement overflow: keep the bit-vector path
+        ix.tab = nullptr;
+      }
+    }
+  }
   cleanup();
 #undef BI_HIP
   return SHK_OK;

@@ -25,7 +25,7 @@ int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
 
 static void free_index(DeviceIndex &ix)
 {
-  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32);
+  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab);
   ix = DeviceIndex{};
 }
 
@@ -56,6 +56,7 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   const DeviceIndex &ix = ctx->idx;
   p.bf64 = ix.bf64; p.rank_w = ix.rank_w; p.ent = ix.ent; p.ids = ix.ids;
   p.sum32 = ix.sum_shift ? ix.sum32 : nullptr; p.sum_shift = ix.sum_shift;
+  p.tab = ix.tab_lg ? ix.tab : nullptr; p.tab_lg = ix.tab_lg;
   p.bf_bits = ix.bf_bits; p.bf_mask = ix.bf_bits - 1;
   p.k = ctx->prm.k; p.c = ctx->prm.c; p.single = ctx->prm.single;
   p.mq = ctx->prm.min_quality ? ctx->prm.min_quality + 33 : 0;  // FastqSplitter.hpp:70
@@ -296,6 +297,12 @@ int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info)
   info->tot_idx = ctx->idx.tot_idx;
   info->n_ref_kmers = ctx->n_ref_kmers;
   return SHK_OK;
+}
+
+const char *shk_probe_mode(const shk_ctx *ctx)
+{
+  if (!ctx || ctx->mode != 2) return "";
+  return probe_mode_name(ctx);
 }
 
 int shk_index_copy_bf(const shk_ctx *cctx, uint64_t *words, uint64_t n_words)

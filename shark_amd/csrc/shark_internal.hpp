@@ -28,6 +28,18 @@ namespace shk {
 //              the filter bit clear, so the result of every probe is
 //              unchanged; sized to stay in L2 (sparse filters) or in the
 //              Infinity Cache.  Only for power-of-two filter sizes.
+//   tab      : optional POSITION TABLE (power-of-two filter sizes): an exact
+//              sparse encoding of the filter's set bits -- bit `pos` is set iff
+//              `pos` is a key of the table -- with the list entry inline, so a
+//              probe answers "is the bit set" AND "which list" with one
+//              16-byte load instead of filter word + rank word + entry.
+//              Buckets of two 8-byte slots, linear probing over buckets, home
+//              bucket = pos & (n_buckets-1) (pos is already a hash).  Slot:
+//                [63:40] tag = pos >> tab_lg   [39] valid   [38] multi
+//                [37:32] displacement (buckets from home)
+//                [31:0]  gene (single-gene list) or rank r (multi: ent[r])
+//              The filter itself stays in HBM as the ground truth (it defines
+//              rank, is exported, and is what the tests compare bit for bit).
 struct ListEntry {
   uint32_t start;
   uint16_t len;     // clipped at 0xFFFF: then the true end is the next entry's start
@@ -45,6 +57,9 @@ struct DeviceIndex {
   uint32_t *sum32 = nullptr;
   uint32_t sum_shift = 0;    // 0 = no summary level
   uint64_t sum_bits = 0;
+  uint64_t *tab = nullptr;   // 2 slots per bucket
+  uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
+  bool tab_with_summary = false;
   uint64_t n_set = 0;
   uint64_t tot_idx = 0;
 };
@@ -58,6 +73,8 @@ struct ClassifyParams {
   const uint16_t *ids;
   const uint32_t *sum32;
   uint32_t sum_shift;
+  const uint64_t *tab;
+  uint32_t tab_lg;
   uint64_t bf_bits;
   uint64_t bf_mask;
   // options
@@ -116,6 +133,7 @@ int build_index(Ctx *ctx);
 
 // classify.hip
 int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream);
+const char *probe_mode_name(const Ctx *ctx);
 int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream);
 int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n,
                          unsigned long long *gene_counts, hipStream_t stream);

@@ -18,6 +18,17 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "bitvector"])
+def probe(request, monkeypatch):
+    """run a test once with the index's automatic probe structure (position table where possible)
+    and once forced onto the plain filter words (+rank directory)"""
+    if request.param == "bitvector":
+        monkeypatch.setenv("SHK_PROBE", "bitvector")
+    else:
+        monkeypatch.delenv("SHK_PROBE", raising=False)
+    return request.param
+
+
 def _hip(**kw):
     from shark_amd import SharkHip
     return SharkHip(**kw)
@@ -58,7 +69,7 @@ def _compare_classify(o, h, batch, nthreads=2):
 # ---------------------------------------------------------------------------
 # BASELINE config 1: the bundled example, k=17 c=0.6 bf=1GB
 # ---------------------------------------------------------------------------
-def test_example_bit_exact(oracle, example_dir, tmp_path):
+def test_example_bit_exact(oracle, probe, example_dir, tmp_path):
     fa = synth.read_fasta(os.path.join(example_dir, "ENSG00000277117.fa"))
     r1 = synth.read_fastq(os.path.join(example_dir, "sample_1.fq"))
     r2 = synth.read_fastq(os.path.join(example_dir, "sample_2.fq"))
@@ -101,10 +112,14 @@ def test_example_bit_exact(oracle, example_dir, tmp_path):
     (17, 1000003, True, 150),     # non power-of-two size: true modulo
     (21, 3 << 20, False, 120),
 ])
-def test_synthetic_parity(oracle, k, bf_bits, paired, read_len):
+def test_synthetic_parity(oracle, probe, k, bf_bits, paired, read_len):
     rng = np.random.default_rng(1234 + k)
     genes = synth.make_genes(rng, 40, 100, 1500, share_every=4)
     o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits)
+    if probe == "bitvector" or bf_bits & (bf_bits - 1):
+        assert "table" not in h.probe_mode()
+    else:
+        assert "table" in h.probe_mode()
     _compare_index(o, h, info)
     batch = synth.make_reads(rng, genes, 3000, read_len=read_len, paired=paired, on_target=0.6,
                              n_rate=0.01, lower_rate=0.05, var_len=True)
@@ -147,7 +162,7 @@ def test_gene_numbering_quirk(oracle):
     assert set(int(x) for x in np.unique(gids)) == {0, 2, 4}
 
 
-def test_many_ties_overflow_inline(oracle):
+def test_many_ties_overflow_inline(oracle, probe):
     """more than SHK_INLINE_IDS genes tie: the general kernel writes the list"""
     rng = np.random.default_rng(11)
     core = synth.random_seq(rng, 600)
@@ -163,7 +178,7 @@ def test_many_ties_overflow_inline(oracle):
     assert np.array_equal(h.gene_counts(20), np.bincount(gids, minlength=20)[:20].astype(np.uint64))
 
 
-def test_long_and_ragged_reads(oracle):
+def test_long_and_ragged_reads(oracle, probe):
     """reads beyond the LDS specialisation (general kernel), empty reads, reads
     shorter than k, reads of only N"""
     rng = np.random.default_rng(13)
