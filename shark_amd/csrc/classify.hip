@@ -48,7 +48,8 @@ enum ProbeMode {
   PM_BV = 1,       // filter word, position = hash & (size-1)
   PM_BV_SUM = 2,   // summary level, then filter word
   PM_TAB = 3,      // position table (exact sparse encoding of the set bits)
-  PM_TAB_SUM = 4   // summary level, then position table
+  PM_TAB_SUM = 4,  // summary level, then position table
+  PM_LDS_TAB = 5   // 2^19-bit summary held in LDS, then position table (small indices)
 };
 
 // per-wave storage sizes (in 64-bit words) for a slot capacity S
@@ -80,11 +81,13 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p, uint32_t rem)
 
 template <int U, int MODE, bool HASQ, bool FAST, bool EMIT>
 __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
-                                             const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk)
+                                             const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk,
+                                             const uint32_t *lsum = nullptr)
 {
   constexpr bool POW2 = MODE != PM_BV_MOD;
   constexpr bool SUM = MODE == PM_BV_SUM || MODE == PM_TAB_SUM;
-  constexpr bool TAB = MODE == PM_TAB || MODE == PM_TAB_SUM;
+  constexpr bool LSUM = MODE == PM_LDS_TAB;
+  constexpr bool TAB = MODE == PM_TAB || MODE == PM_TAB_SUM || MODE == PM_LDS_TAB;
   const uint32_t k = P.k;
   const uint64_t o1 = P.off1[read];
   const uint32_t L1 = (uint32_t)(P.off1[read + 1] - o1);
@@ -186,6 +189,20 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       for (int j = 0; j < U; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
 #pragma unroll
       for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
+    }
+    if (LSUM) {
+      // LDS-resident summary: same proof, no memory-system traffic for a miss
+      uint32_t sw[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) sw[j] = ok[j] ? lsum[(uint32_t)(pos[j] >> P.lsum_shift) >> 5] : 0u;
+#pragma unroll
+      for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.lsum_shift) & 31u)) & 1u;
+    }
+    if (FAST && (SUM || LSUM) && !P.work_counters) {
+      bool lane_ok = false;
+#pragma unroll
+      for (int j = 0; j < U; ++j) lane_ok |= ok[j];
+      if (!__ballot(lane_ok)) break;   // every probe of this read is proven clear
     }
     bool hit[U];
     bool lane_any = false;
@@ -448,25 +465,44 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 // ---------------------------------------------------------------------------
 // fast kernel: everything per wave lives in LDS; slot capacity 64*U
 // ---------------------------------------------------------------------------
+template <int MODE>
+struct FastGeom {
+  static constexpr int WAVES = MODE == PM_LDS_TAB ? 16 : CF_WAVES;   // 1024-thread workgroups share one LDS summary
+  static constexpr int THREADS = WAVES * 64;
+  // two 1024-thread workgroups per CU need 8 waves per SIMD, i.e. <= 64 VGPRs
+  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? 8 : 1;
+  static constexpr uint32_t SUM_WORDS64 = MODE == PM_LDS_TAB ? LDS_SUM_BITS / 64 : 0;
+};
+
 template <int U, int MODE, bool HASQ>
-__global__ __launch_bounds__(CF_THREADS) void classify_fast_kernel(const ClassifyParams P)
+__global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_PER_SIMD) void classify_fast_kernel(const ClassifyParams P)
 {
+  using G = FastGeom<MODE>;
   constexpr uint32_t S = 64 * U;
   constexpr uint32_t CW = code_words_for(S), VW = vbit_words_for(S);
   constexpr uint32_t WORDS = CW + VW;   // slot records stay in registers
-  __shared__ uint64_t lds[CF_WAVES * WORDS];
+  __shared__ uint64_t lds[G::SUM_WORDS64 + G::WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint64_t *base = lds + wave * WORDS;
+  const uint32_t *lsum = nullptr;
+  if (MODE == PM_LDS_TAB) {
+    // stage the summary: 64 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = threadIdx.x; i < LDS_SUM_BITS / 128; i += G::THREADS) dst[i] = src[i];
+    __syncthreads();
+    lsum = reinterpret_cast<const uint32_t *>(lds);
+  }
+  uint64_t *base = lds + G::SUM_WORDS64 + wave * WORDS;
   WaveStore st;
   st.codes = base;
   st.vbits = base + CW;
   st.rec_start = nullptr;
   st.rec_end = nullptr;
   st.cur = nullptr;
-  const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
-  for (uint64_t read = (uint64_t)blockIdx.x * CF_WAVES + wave; read < P.n; read += stride)
-    process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u);
+  const uint64_t stride = (uint64_t)gridDim.x * G::WAVES;
+  for (uint64_t read = (uint64_t)blockIdx.x * G::WAVES + wave; read < P.n; read += stride)
+    process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u, lsum);
 }
 
 // ---------------------------------------------------------------------------
@@ -557,25 +593,27 @@ uint32_t fast_kernel_unroll(uint32_t max_slots)
 static int probe_mode(const DeviceIndex &ix)
 {
   if (!ix.pow2) return PM_BV_MOD;
+  if (ix.tab_lg && ix.lsum_shift) return PM_LDS_TAB;
   if (ix.tab_lg) return ix.tab_with_summary ? PM_TAB_SUM : PM_TAB;
   return ix.sum_shift ? PM_BV_SUM : PM_BV;
 }
 
 const char *probe_mode_name(const Ctx *ctx)
 {
-  static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table"};
+  static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table"};
   return names[probe_mode(ctx->idx)];
 }
 
 template <int U>
 static void launch_fast_u(const ClassifyParams &p, int mode, bool hasq, unsigned grid, hipStream_t s)
 {
-#define LF(M_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, M_, HQ_>), dim3(grid), dim3(CF_THREADS), 0, s, p)
+#define LF(M_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, M_, HQ_>), dim3(grid), dim3(FastGeom<M_>::THREADS), 0, s, p)
   switch (mode) {
   case PM_BV_MOD: if (hasq) LF(PM_BV_MOD, true); else LF(PM_BV_MOD, false); break;
   case PM_BV: if (hasq) LF(PM_BV, true); else LF(PM_BV, false); break;
   case PM_BV_SUM: if (hasq) LF(PM_BV_SUM, true); else LF(PM_BV_SUM, false); break;
   case PM_TAB: if (hasq) LF(PM_TAB, true); else LF(PM_TAB, false); break;
+  case PM_LDS_TAB: if (hasq) LF(PM_LDS_TAB, true); else LF(PM_LDS_TAB, false); break;
   default: if (hasq) LF(PM_TAB_SUM, true); else LF(PM_TAB_SUM, false); break;
   }
 #undef LF
@@ -587,8 +625,11 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   const bool hasq = p.mq != 0;
   const int mode = probe_mode(ctx->idx);
   // persistent grid: enough workgroups to fill 256 CUs several times over
-  const uint64_t want = (p.n + CF_WAVES - 1) / CF_WAVES;
-  const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+  // persistent workgroups; the LDS-summary mode runs 2 x 1024-thread workgroups per CU
+  const uint64_t wpb = mode == PM_LDS_TAB ? 16 : CF_WAVES;
+  const uint64_t cap = mode == PM_LDS_TAB ? 512 : 4096;
+  const uint64_t want = (p.n + wpb - 1) / wpb;
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
   const uint32_t u = fast_kernel_unroll(max_slots);
   if (u == 2) launch_fast_u<2>(p, mode, hasq, grid, stream);
   else if (u == 3) launch_fast_u<3>(p, mode, hasq, grid, stream);

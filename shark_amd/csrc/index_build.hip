@@ -378,6 +378,21 @@ int build_index(Ctx *ctx)
       (void)hipFree(d_fail);
       if (h_fail == 0) {
         ix.tab_lg = lg;
+        // small indices: a 2^19-bit summary that the table kernel keeps in LDS answers
+        // almost every miss without touching the memory system (same proof as sum32)
+        ix.lsum_shift = 0;
+        if (lgB > LDS_SUM_LOG2 && !getenv("SHK_NO_LDS_SUMMARY")) {
+          const uint32_t sh = lgB - LDS_SUM_LOG2;
+          const double pass = 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits);
+          if (sh >= 6 && pass <= 0.30) {
+            BI_HIP(hipMalloc((void **)&ix.lsum32, (LDS_SUM_BITS / 32 + 2) * sizeof(uint32_t)));
+            BI_HIP(hipMemsetAsync(ix.lsum32, 0, (LDS_SUM_BITS / 32 + 2) * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(bf_summary_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words, sh, ix.lsum32);
+            BI_HIP(hipGetLastError());
+            BI_HIP(hipStreamSynchronize(st));
+            ix.lsum_shift = sh;
+          }
+        }
         // a table that stays in L2 needs no summary in front of it
         ix.tab_with_summary = ix.sum_shift != 0 && slots * sizeof(uint64_t) > (4ull << 20);
       } else {

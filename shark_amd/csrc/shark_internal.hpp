@@ -40,6 +40,9 @@ namespace shk {
 //                [31:0]  gene (single-gene list) or rank r (multi: ent[r])
 //              The filter itself stays in HBM as the ground truth (it defines
 //              rank, is exported, and is what the tests compare bit for bit).
+constexpr uint32_t LDS_SUM_LOG2 = 19;                 // 2^19 bits = 64 KiB of LDS per workgroup
+constexpr uint32_t LDS_SUM_BITS = 1u << LDS_SUM_LOG2;
+
 struct ListEntry {
   uint32_t start;
   uint16_t len;     // clipped at 0xFFFF: then the true end is the next entry's start
@@ -57,6 +60,8 @@ struct DeviceIndex {
   uint32_t *sum32 = nullptr;
   uint32_t sum_shift = 0;    // 0 = no summary level
   uint64_t sum_bits = 0;
+  uint32_t *lsum32 = nullptr; // 2^19-bit summary staged into LDS by the table kernel (small indices only)
+  uint32_t lsum_shift = 0;    // 0 = not used
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
   bool tab_with_summary = false;
@@ -75,6 +80,8 @@ struct ClassifyParams {
   uint32_t sum_shift;
   const uint64_t *tab;
   uint32_t tab_lg;
+  const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
+  uint32_t lsum_shift;
   uint64_t bf_bits;
   uint64_t bf_mask;
   // options
