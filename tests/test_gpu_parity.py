@@ -252,3 +252,66 @@ def test_device_resident_api_and_roundtrip_properties():
     assert w["n_kmers"] == n * 2 * (150 - 17 + 1)
     assert w["n_bases"] == n * 300
     assert w["n_hits"] >= (cnt == 1).sum() * 2 * 134
+
+
+# ---------------------------------------------------------------------------
+# the drop-in CLI: same flags, byte-identical ssv + FASTQ (README.md:63-69)
+# ---------------------------------------------------------------------------
+def _run_shark(args, cwd):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
+    return subprocess.run([exe] + args, cwd=cwd, capture_output=True)
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch", "777"], ["-t", "4", "--batch", "50000"]])
+def test_cli_example_byte_identical(example_dir, tmp_path, extra):
+    o1, o2 = tmp_path / "o1.fq", tmp_path / "o2.fq"
+    r = _run_shark(["-r", os.path.join(example_dir, "ENSG00000277117.fa"), "-1", os.path.join(example_dir, "sample_1.fq"),
+                    "-2", os.path.join(example_dir, "sample_2.fq"), "-o", str(o1), "-p", str(o2)] + extra, str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == open(os.path.join(example_dir, "ENSG00000277117.truth.ssv"), "rb").read()
+    assert o1.read_bytes() == open(os.path.join(example_dir, "sharked.sample_1.truth.fq"), "rb").read()
+    assert o2.read_bytes() == open(os.path.join(example_dir, "sharked.sample_2.truth.fq"), "rb").read()
+    assert b"[shark/Association done] Time elapsed" in r.stderr
+
+
+def test_cli_matches_oracle_cli_on_options(oracle, tmp_path):
+    """-q / -s / -k / single-end / gz / multi-gene with the numbering quirk: the HIP CLI and the oracle CLI
+    must print the same bytes (ssv on stdout, FASTQ files)"""
+    import gzip
+    rng = np.random.default_rng(4242)
+    genes = synth.make_genes(rng, 12, 300, 1500, share_every=3)
+    fa = tmp_path / "g.fa"
+    with open(fa, "w") as f:
+        for i, g in enumerate(genes):
+            if i == 4:
+                f.write(">skipme no valid kmer\n" + "N" * 70 + "\n")
+            f.write(">gene%d some description\n" % i)
+            s = bytes(g).decode()
+            for j in range(0, len(s), 60):
+                f.write(s[j:j + 60] + "\n")
+    b = synth.make_reads(rng, genes, 4000, read_len=120, paired=True, on_target=0.7, qual=True, var_len=True, lower_rate=0.02)
+
+    def write_fq(path, seq, off, qual, tag, gz=False):
+        op = gzip.open if gz else open
+        with op(path, "wb") as f:
+            for i in range(len(off) - 1):
+                s = bytes(seq[int(off[i]):int(off[i + 1])])
+                q = bytes(qual[int(off[i]):int(off[i + 1])])
+                f.write(b"@read%d/%s extra\n%s\n+\n%s\n" % (i, tag, s, q))
+    f1, f2 = tmp_path / "r1.fq.gz", tmp_path / "r2.fq"
+    write_fq(f1, b["seq1"], b["off1"], b["qual1"], b"1", gz=True)
+    write_fq(f2, b["seq2"], b["off2"], b["qual2"], b"2")
+    for opts in (["-k", "17", "-c", "0.5"], ["-k", "21", "-q", "20", "-s"], ["-k", "13", "-q", "10", "-c", "0.3"]):
+        for paired in (True, False):
+            files = ["-r", str(fa), "-1", str(f1)] + (["-2", str(f2)] if paired else [])
+            ho1, ho2, oo1, oo2 = (tmp_path / n for n in ("h1.fq", "h2.fq", "o1.fq", "o2.fq"))
+            r = _run_shark(files + opts + ["-o", str(ho1), "-p", str(ho2), "--batch", "1500"], str(tmp_path))
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            ossv = tmp_path / "o.ssv"
+            oracle.run_cli(files + opts + ["-o", str(oo1), "-p", str(oo2)], str(ossv))
+            assert r.stdout == ossv.read_bytes(), (opts, paired)
+            assert len(r.stdout) > 1000
+            assert ho1.read_bytes() == oo1.read_bytes()
+            if paired:
+                assert ho2.read_bytes() == oo2.read_bytes()
