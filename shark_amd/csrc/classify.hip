@@ -544,37 +544,64 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
 
 // copy the inline ids of reads with 1..SHK_INLINE_IDS genes into the CSR result
 // and count assigned reads per gene.  Gene counters are hot (one gene can own
-// most reads), so equal genes inside a wave are combined into one atomic.
-__global__ __launch_bounds__(256) void gather_inline_kernel(const uint32_t *__restrict__ count, const uint16_t *__restrict__ inl,
-                                                            const uint32_t *__restrict__ gene_off, uint16_t *__restrict__ gene_ids, uint64_t n,
-                                                            unsigned long long *__restrict__ gene_counts)
+// most reads) and same-address global atomics serialise at ~12 ns each, so the
+// counts are combined twice before they reach HBM: equal genes inside a wave
+// by ballot, then per workgroup in an LDS hash table that is flushed once.
+constexpr int GI_THREADS = 256;
+constexpr uint32_t GI_TABLE = 2048;   // LDS histogram slots per workgroup
+__global__ __launch_bounds__(GI_THREADS) void gather_inline_kernel(const uint32_t *__restrict__ count, const uint16_t *__restrict__ inl,
+                                                                   const uint32_t *__restrict__ gene_off, uint16_t *__restrict__ gene_ids, uint64_t n,
+                                                                   unsigned long long *__restrict__ gene_counts)
 {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t h_key[GI_TABLE];
+  __shared__ uint32_t h_cnt[GI_TABLE];
+  for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS) { h_key[i] = 0xFFFFFFFFu; h_cnt[i] = 0; }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  uint32_t c = 0, o = 0;
-  if (i < n) {
-    c = count[i];
-    if (c > SHK_INLINE_IDS) c = 0;  // written (and counted) by the general kernel in EMIT mode
-    o = gene_off[i];
-  }
+  const uint64_t n_round = (n + GI_THREADS - 1) / GI_THREADS * GI_THREADS;   // keep whole waves in the loop (ballots)
+  for (uint64_t i = (uint64_t)blockIdx.x * GI_THREADS + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * GI_THREADS) {
+    uint32_t c = 0, o = 0;
+    if (i < n) {
+      c = count[i];
+      if (c > SHK_INLINE_IDS) c = 0;  // written (and counted) by the general kernel in EMIT mode
+      o = gene_off[i];
+    }
 #pragma unroll
-  for (uint32_t j = 0; j < SHK_INLINE_IDS; ++j) {
-    bool pending = j < c;
-    uint32_t g = 0;
-    if (pending) {
-      g = inl[i * SHK_INLINE_IDS + j];
-      gene_ids[o + j] = (uint16_t)g;
-    }
-    if (!gene_counts) continue;
-    unsigned long long todo = __ballot(pending);
-    while (todo) {
-      const int leader = __builtin_ctzll(todo);
-      const uint32_t lg = __shfl(g, leader, 64);
-      const unsigned long long same = __ballot(pending && g == lg);
-      if (lane == leader) atomicAdd(&gene_counts[lg], (unsigned long long)__builtin_popcountll(same));
-      todo &= ~same;
+    for (uint32_t j = 0; j < SHK_INLINE_IDS; ++j) {
+      const bool pending = j < c;
+      uint32_t g = 0;
+      if (pending) {
+        g = inl[i * SHK_INLINE_IDS + j];
+        gene_ids[o + j] = (uint16_t)g;
+      }
+      if (!gene_counts) continue;
+      unsigned long long todo = __ballot(pending);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t lg = __shfl(g, leader, 64);
+        const unsigned long long same = __ballot(pending && g == lg);
+        if (lane == leader) {
+          const uint32_t add = (uint32_t)__builtin_popcountll(same);
+          uint32_t slot = (lg * 2654435761u) >> 21;   // 11 bits
+          bool done = false;
+          for (uint32_t probe = 0; probe < 16 && !done; ++probe) {
+            const uint32_t old = atomicCAS(&h_key[slot], 0xFFFFFFFFu, lg);
+            if (old == 0xFFFFFFFFu || old == lg) {
+              atomicAdd(&h_cnt[slot], add);
+              done = true;
+            }
+            slot = (slot + 1) & (GI_TABLE - 1);
+          }
+          if (!done) atomicAdd(&gene_counts[lg], (unsigned long long)add);   // table crowded: straight to HBM
+        }
+        todo &= ~same;
+      }
     }
   }
+  if (!gene_counts) return;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS)
+    if (h_cnt[i]) atomicAdd(&gene_counts[h_key[i]], (unsigned long long)h_cnt[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -663,7 +690,8 @@ int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint3
                          unsigned long long *gene_counts, hipStream_t stream)
 {
   if (n == 0) return SHK_OK;
-  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, count, inl, gene_off, gene_ids, n, gene_counts);
+  const uint64_t want = (n + GI_THREADS - 1) / GI_THREADS;
+  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(GI_THREADS), 0, stream, count, inl, gene_off, gene_ids, n, gene_counts);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 
