@@ -55,9 +55,10 @@ def main():
     rank, local_rank, world = sdist.env_rank()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    local_rank %= max(torch.cuda.device_count(), 1)   # (a gloo dry run may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    sdist.init("nccl", dev)
+    sdist.init(sdist.backend_name(), dev)
 
     k, c, bf_bits = args.k, 0.6, 1 << args.bf_log2
     n = args.pairs

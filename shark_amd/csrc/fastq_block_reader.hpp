@@ -1,0 +1,168 @@
+// fastq_block_reader.hpp -- block-parallel FASTQ ingest for the shark CLI
+// (the reference's FastqSplitter parses under one mutex,
+// FastqSplitter.hpp:48, kseq.h:177-218, which caps the whole tool at a few
+// million reads/s).
+//
+// Fast path: a PLAIN (not gzip'd) file of STRICT four-line records is mmap'd,
+// newline positions are indexed by several threads at once, and the records
+// of a batch are copied into the structure-of-arrays batch in parallel.  The
+// record rules are kseq's: name = header up to the first whitespace
+// (kseq.h:188); sequence and quality are one line each of equal length.
+// Anything else -- gzip input, CR/LF, multi-line records, a quality line of a
+// different length, stray text between records -- is handed to the serial
+// FastxReader from the first irregular record on, so the bytes delivered are
+// always those the reference's parser would deliver.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace shk {
+
+template <typename F>
+inline void parallel_for(unsigned n_threads, size_t n, F f)
+{
+  if (n == 0) return;
+  n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>(n_threads, n));
+  if (n_threads == 1) { f(0, n, 0u); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + n_threads - 1) / n_threads;
+  for (unsigned t = 0; t < n_threads; ++t) {
+    const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+    if (b < e) th.emplace_back([=] { f(b, e, t); });
+  }
+  for (auto &x : th) x.join();
+}
+
+// a view of the next `n` strict records of one file
+struct RecordBlock {
+  const char *base = nullptr;          // mmap base
+  std::vector<uint64_t> nl;            // offsets of the 4*n newlines (record r: lines 4r..4r+3)
+  uint64_t first = 0;                  // offset of the first record's '@'
+  size_t n = 0;
+  // line i spans [begin(i), nl[i])
+  uint64_t begin(size_t i) const { return i == 0 ? first : nl[i - 1] + 1; }
+};
+
+class FastqMmap {
+ public:
+  explicit FastqMmap(const std::string &path, unsigned threads) : threads_(threads)
+  {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) return;
+    struct stat st;
+    if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return;
+    size_ = (uint64_t)st.st_size;
+    if (size_ == 0) { ok_ = true; return; }
+    void *p = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (p == MAP_FAILED) return;
+    base_ = (const char *)p;
+    madvise(p, size_, MADV_SEQUENTIAL);
+    // gzip magic -> not for the fast path
+    ok_ = !(size_ >= 2 && (unsigned char)base_[0] == 0x1f && (unsigned char)base_[1] == 0x8b);
+  }
+  ~FastqMmap()
+  {
+    if (base_) munmap((void *)base_, size_);
+    if (fd_ >= 0) ::close(fd_);
+  }
+  FastqMmap(const FastqMmap &) = delete;
+  FastqMmap &operator=(const FastqMmap &) = delete;
+
+  bool usable() const { return ok_; }
+  uint64_t cursor() const { return cur_; }
+  uint64_t size() const { return size_; }
+
+  // Index up to `want` strict records starting at the cursor.  Returns the
+  // number of records that are certainly regular (may be < want at the end of
+  // the file or at the first irregular record; `irregular` tells which).
+  size_t next_block(size_t want, RecordBlock &blk, bool &irregular)
+  {
+    irregular = false;
+    blk.base = base_;
+    blk.nl.clear();
+    blk.n = 0;
+    blk.first = cur_;
+    if (cur_ >= size_) return 0;
+    if (base_[cur_] != '@') { irregular = true; return 0; }   // kseq would skip to the next '@' / '>'
+    const size_t need = want * 4;
+    uint64_t scan = cur_;
+    double bytes_per_line = est_line_;
+    while (blk.nl.size() < need && scan < size_) {
+      const size_t missing = need - blk.nl.size();
+      uint64_t win = (uint64_t)(missing * bytes_per_line * 1.05) + (1u << 16);
+      const uint64_t end = std::min<uint64_t>(size_, scan + win);
+      const unsigned T = threads_;
+      std::vector<std::vector<uint64_t>> parts(T);
+      parallel_for(T, (size_t)(end - scan), [&](size_t b, size_t e, unsigned t) {
+        std::vector<uint64_t> &v = parts[t];
+        v.reserve((size_t)((e - b) / std::max(1.0, bytes_per_line)) + 16);
+        const char *p = base_ + scan + b, *pe = base_ + scan + e;
+        while (p < pe) {
+          const char *q = (const char *)memchr(p, '\n', (size_t)(pe - p));
+          if (!q) break;
+          v.push_back((uint64_t)(q - base_));
+          p = q + 1;
+        }
+      });
+      for (auto &v : parts) {
+        const size_t take = std::min(v.size(), need - blk.nl.size());
+        blk.nl.insert(blk.nl.end(), v.begin(), v.begin() + take);
+        if (blk.nl.size() == need) break;
+      }
+      scan = end;
+      if (!blk.nl.empty()) bytes_per_line = std::max(8.0, (double)(blk.nl.back() - cur_) / (double)blk.nl.size());
+    }
+    est_line_ = bytes_per_line;
+    // a last record without a trailing newline is left to the serial reader
+    size_t n = blk.nl.size() / 4;
+    // validate in parallel: '@', '+', equal lengths, no '\r'
+    std::vector<size_t> bad(threads_, (size_t)-1);
+    parallel_for(threads_, n, [&](size_t b, size_t e, unsigned t) {
+      for (size_t r = b; r < e; ++r) {
+        const uint64_t h0 = blk.begin(4 * r), h1 = blk.nl[4 * r];
+        const uint64_t s0 = h1 + 1, s1 = blk.nl[4 * r + 1];
+        const uint64_t p0 = s1 + 1, p1 = blk.nl[4 * r + 2];
+        const uint64_t q0 = p1 + 1, q1 = blk.nl[4 * r + 3];
+        bool good = base_[h0] == '@' && p1 > p0 - 0 && base_[p0] == '+' && (s1 - s0) == (q1 - q0) && h1 > h0;
+        // characters kseq treats specially at the start of a sequence line, CR/LF, embedded NULs
+        if (good && s1 > s0 && (base_[s0] == '@' || base_[s0] == '>' || base_[s0] == '+')) good = false;
+        if (good && (base_[h1 - 1] == '\r' || (s1 > s0 && base_[s1 - 1] == '\r') || (q1 > q0 && base_[q1 - 1] == '\r'))) good = false;
+        if (good && (memchr(base_ + s0, 0, (size_t)(s1 - s0)) || memchr(base_ + q0, 0, (size_t)(q1 - q0)) || memchr(base_ + h0, 0, (size_t)(h1 - h0)))) good = false;
+        if (good && s1 == s0) good = false;   // empty sequence line: let kseq's rules decide
+        if (!good) { bad[t] = r; break; }
+      }
+    });
+    size_t first_bad = n;
+    for (size_t v : bad) if (v != (size_t)-1) first_bad = std::min(first_bad, v);
+    if (first_bad < n) { irregular = true; n = first_bad; }
+    else if (n < want && (n * 4 < blk.nl.size() || (n ? blk.nl[4 * n - 1] + 1 : cur_) < size_)) irregular = true;   // trailing partial record
+    blk.nl.resize(n * 4);
+    blk.n = n;
+    return n;
+  }
+
+  // consume the first n records of the last block
+  void advance(const RecordBlock &blk, size_t n)
+  {
+    if (n) cur_ = blk.nl[4 * n - 1] + 1;
+  }
+
+ private:
+  int fd_ = -1;
+  const char *base_ = nullptr;
+  uint64_t size_ = 0, cur_ = 0;
+  bool ok_ = false;
+  unsigned threads_;
+  double est_line_ = 80.0;
+};
+
+}  // namespace shk

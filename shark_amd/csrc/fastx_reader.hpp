@@ -38,6 +38,17 @@ class FastxReader {
   FastxReader &operator=(const FastxReader &) = delete;
   bool ok() const { return f_ != nullptr; }
 
+  // restart parsing at a byte offset of the (uncompressed) input -- used when the block-parallel
+  // reader hands an irregular tail over; the offset must be a record boundary
+  bool seek(uint64_t off)
+  {
+    if (!f_ || gzseek(f_, (z_off_t)off, SEEK_SET) < 0) return false;
+    pos_ = end_ = 0;
+    eof_ = false;
+    last_ = 0;
+    return true;
+  }
+
   // returns the sequence length, or <0 at end of stream / malformed record
   int read(FastxRecord &r)
   {

@@ -26,9 +26,12 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/shark_hip.h"
+#include "fastq_block_reader.hpp"
 #include "fastx_reader.hpp"
 
 namespace {
@@ -56,7 +59,8 @@ const char *USAGE_MESSAGE =
     "\n"
     "MI355X build only:\n"
     "          --gpus N                      number of GPUs to shard the reads over (default:1)\n"
-    "          --batch N                     reads per device batch (default:1048576)\n";
+    "          --batch N                     reads per device batch (default:1048576)\n"
+    "      -t N also sets the number of host threads that parse FASTQ / format output (default: up to 16)\n";
 
 struct Options {
   std::string fasta_path, sample1_path, sample2_path, out1_path, out2_path;
@@ -160,8 +164,16 @@ void pelapsed(const std::string &s)  // main.cpp:47-54
 }
 
 // ---- one batch of reads, structure of arrays ---------------------------------
+// allocator that leaves chars uninitialised on resize (the parallel filler overwrites every byte)
+template <typename T>
+struct default_init_allocator : std::allocator<T> {
+  template <typename U> struct rebind { using other = default_init_allocator<U>; };
+  template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+  template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+
 struct Strings {
-  std::vector<char> bytes;
+  std::vector<char, default_init_allocator<char>> bytes;
   std::vector<uint64_t> off{0};
   void push(const std::string &s) { bytes.insert(bytes.end(), s.begin(), s.end()); off.push_back(bytes.size()); }
   void push(const char *p, size_t n) { bytes.insert(bytes.end(), p, p + n); off.push_back(bytes.size()); }
@@ -180,33 +192,59 @@ struct ReadBatch {
   int rc = 0;
 };
 
-// FastqSplitter role (FastqSplitter.hpp:47-93): batches of reads in input order
+// FastqSplitter role (FastqSplitter.hpp:47-93): batches of reads in input order.
+// Plain four-line FASTQ goes through the block-parallel reader; everything else
+// (gzip, multi-line records, CR/LF, ...) through the serial kseq-rule reader.
 class BatchSplitter {
  public:
-  BatchSplitter(const Options &o) : r1_(o.sample1_path), paired_(o.paired_flag), maxnum_(o.batch)
+  BatchSplitter(const Options &o, unsigned threads) : r1_(o.sample1_path), paired_(o.paired_flag), maxnum_(o.batch), threads_(threads)
   {
     if (paired_) r2_.reset(new shk::FastxReader(o.sample2_path));
+    m1_.reset(new shk::FastqMmap(o.sample1_path, threads));
+    if (paired_) m2_.reset(new shk::FastqMmap(o.sample2_path, threads));
+    fast_ = m1_->usable() && (!paired_ || m2_->usable()) && !getenv("SHARK_SERIAL_READER");
   }
   bool ok() const { return r1_.ok() && (!paired_ || r2_->ok()); }
+  bool fast_path() const { return fast_; }
   std::unique_ptr<ReadBatch> operator()()
   {
     std::unique_ptr<ReadBatch> b(new ReadBatch());
     b->index = next_index_++;
     b->first_read = n_reads_;
-    shk::FastxRecord a, c;
-    while (b->seq1.size() < maxnum_) {
-      if (r1_.read(a) < 0) break;
-      if (paired_ && r2_->read(c) < 0) break;
-      // the reference builds std::string from C strings (FastqSplitter.hpp:55,63): stop at NUL
-      const size_t l1 = strnlen(a.seq.data(), a.seq.size());
-      b->id1.push(a.name.c_str(), strlen(a.name.c_str()));
-      b->seq1.push(a.seq.data(), l1);
-      b->qual1.push(a.qual.data(), std::min(strnlen(a.qual.data(), a.qual.size()), a.qual.size()));
-      if (paired_) {
-        const size_t l2 = strnlen(c.seq.data(), c.seq.size());
-        b->id2.push(c.name.c_str(), strlen(c.name.c_str()));
-        b->seq2.push(c.seq.data(), l2);
-        b->qual2.push(c.qual.data(), std::min(strnlen(c.qual.data(), c.qual.size()), c.qual.size()));
+    if (fast_) {
+      shk::RecordBlock k1, k2;
+      bool irr1 = false, irr2 = false;
+      size_t n = m1_->next_block(maxnum_, k1, irr1);
+      if (paired_) n = std::min(n, m2_->next_block(maxnum_, k2, irr2));
+      if (n) {
+        fill(k1, n, b->id1, b->seq1, b->qual1);
+        m1_->advance(k1, n);
+        if (paired_) {
+          fill(k2, n, b->id2, b->seq2, b->qual2);
+          m2_->advance(k2, n);
+        }
+      }
+      if (n < maxnum_) {
+        // end of a file or an irregular record: the serial reader takes over from here
+        fast_ = false;
+        r1_.seek(m1_->cursor());
+        if (paired_) r2_->seek(m2_->cursor());
+      }
+    }
+    if (!fast_) {
+      shk::FastxRecord a, c;
+      while (b->seq1.size() < maxnum_) {
+        if (r1_.read(a) < 0) break;
+        if (paired_ && r2_->read(c) < 0) break;
+        // the reference builds std::string from C strings (FastqSplitter.hpp:55,63): stop at NUL
+        b->id1.push(a.name.c_str(), strlen(a.name.c_str()));
+        b->seq1.push(a.seq.data(), strnlen(a.seq.data(), a.seq.size()));
+        b->qual1.push(a.qual.data(), strnlen(a.qual.data(), a.qual.size()));
+        if (paired_) {
+          b->id2.push(c.name.c_str(), strlen(c.name.c_str()));
+          b->seq2.push(c.seq.data(), strnlen(c.seq.data(), c.seq.size()));
+          b->qual2.push(c.qual.data(), strnlen(c.qual.data(), c.qual.size()));
+        }
       }
     }
     n_reads_ += b->seq1.size();
@@ -215,10 +253,46 @@ class BatchSplitter {
   }
 
  private:
+  // copy n strict records into the structure-of-arrays strings, in parallel
+  void fill(const shk::RecordBlock &k, size_t n, Strings &id, Strings &seq, Strings &qual)
+  {
+    std::vector<uint32_t> idl(n), sql(n);
+    shk::parallel_for(threads_, n, [&](size_t b, size_t e, unsigned) {
+      for (size_t r = b; r < e; ++r) {
+        const uint64_t h0 = k.begin(4 * r) + 1, h1 = k.nl[4 * r];
+        uint64_t p = h0;
+        while (p < h1 && !isspace((unsigned char)k.base[p])) ++p;   // name = up to the first whitespace (kseq.h:188)
+        idl[r] = (uint32_t)(p - h0);
+        sql[r] = (uint32_t)(k.nl[4 * r + 1] - (k.nl[4 * r] + 1));
+      }
+    });
+    id.off.resize(n + 1);
+    seq.off.resize(n + 1);
+    qual.off.resize(n + 1);
+    uint64_t ai = 0, as = 0;
+    for (size_t r = 0; r < n; ++r) {
+      id.off[r] = ai; seq.off[r] = as; qual.off[r] = as;
+      ai += idl[r]; as += sql[r];
+    }
+    id.off[n] = ai; seq.off[n] = as; qual.off[n] = as;
+    id.bytes.resize(ai);
+    seq.bytes.resize(as);
+    qual.bytes.resize(as);
+    shk::parallel_for(threads_, n, [&](size_t b, size_t e, unsigned) {
+      for (size_t r = b; r < e; ++r) {
+        memcpy(id.bytes.data() + id.off[r], k.base + k.begin(4 * r) + 1, idl[r]);
+        memcpy(seq.bytes.data() + seq.off[r], k.base + k.nl[4 * r] + 1, sql[r]);
+        memcpy(qual.bytes.data() + qual.off[r], k.base + k.nl[4 * r + 2] + 1, sql[r]);
+      }
+    });
+  }
+
   shk::FastxReader r1_;
   std::unique_ptr<shk::FastxReader> r2_;
-  bool paired_;
+  std::unique_ptr<shk::FastqMmap> m1_, m2_;
+  bool paired_, fast_ = false;
   uint64_t maxnum_;
+  unsigned threads_;
   uint64_t next_index_ = 0, n_reads_ = 0;
 };
 
@@ -253,47 +327,77 @@ class ReadAnalyzer {
   bool need_qual_;
 };
 
-// ReadOutput role (ReadOutput.hpp:37-50)
+// ReadOutput role (ReadOutput.hpp:37-50).  The reference starts a new output
+// call -- and clears previd -- every 50 000 input reads (main.cpp:215,
+// ReadOutput.hpp:39), so 50 000-read chunks are independent and are formatted
+// in parallel; the text is then written in input order.
 class ReadOutput {
  public:
-  ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend) : out1_(out1), out2_(out2), legend_(legend) {}
+  ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend, unsigned threads)
+      : out1_(out1), out2_(out2), legend_(legend), threads_(threads) {}
   void operator()(const ReadBatch &b)
   {
     const size_t n = b.seq1.size();
-    for (size_t i = 0; i < n; ++i) {
-      // the reference starts a new output call -- and clears previd -- every
-      // 50 000 input reads (main.cpp:215, ReadOutput.hpp:39)
-      if ((b.first_read + i) % 50000 == 0) previd_.clear();
-      for (uint32_t j = b.gene_off[i]; j < b.gene_off[i + 1]; ++j) {
-        const std::string &gene = legend_[b.gene_ids[j]];
-        fwrite(b.id1.at(i), 1, b.id1.len(i), stdout);
-        fputc(' ', stdout);
-        fwrite(gene.data(), 1, gene.size(), stdout);
-        fputc('\n', stdout);
-        const bool same = previd_.size() == b.id1.len(i) && memcmp(previd_.data(), b.id1.at(i), previd_.size()) == 0;
-        if (!same) {
-          if (out1_) record(out1_, b.id1, b.seq1, b.qual1, i);
-          if (out2_) record(out2_, b.id2, b.seq2, b.qual2, i);
-        }
-        previd_.assign(b.id1.at(i), b.id1.len(i));
-      }
+    // segments: [first, last) read ranges that do not cross a 50 000 boundary
+    std::vector<std::pair<size_t, size_t>> segs;
+    for (size_t i = 0; i < n;) {
+      const uint64_t g = b.first_read + i;
+      const size_t e = (size_t)std::min<uint64_t>(n, i + (50000 - g % 50000));
+      segs.emplace_back(i, e);
+      i = e;
     }
+    std::vector<std::string> ssv(segs.size()), fq1(segs.size()), fq2(segs.size()), last_id(segs.size());
+    std::vector<char> any(segs.size(), 0);
+    shk::parallel_for(threads_, segs.size(), [&](size_t sb, size_t se, unsigned) {
+      for (size_t si = sb; si < se; ++si) {
+        std::string previd;
+        bool have = false;
+        const bool carries = (b.first_read + segs[si].first) % 50000 != 0;   // continues the previous batch's chunk
+        if (carries) { previd = carry_; have = true; }
+        for (size_t i = segs[si].first; i < segs[si].second; ++i) {
+          for (uint32_t j = b.gene_off[i]; j < b.gene_off[i + 1]; ++j) {
+            const std::string &gene = legend_[b.gene_ids[j]];
+            ssv[si].append(b.id1.at(i), b.id1.len(i));
+            ssv[si].push_back(' ');
+            ssv[si].append(gene);
+            ssv[si].push_back('\n');
+            const bool same = previd.size() == b.id1.len(i) && memcmp(previd.data(), b.id1.at(i), previd.size()) == 0;
+            if (!same) {
+              if (out1_) record(fq1[si], b.id1, b.seq1, b.qual1, i);
+              if (out2_) record(fq2[si], b.id2, b.seq2, b.qual2, i);
+            }
+            previd.assign(b.id1.at(i), b.id1.len(i));
+            have = true;
+          }
+        }
+        (void)have;
+        last_id[si] = previd;
+        any[si] = 1;
+      }
+    });
+    for (size_t si = 0; si < segs.size(); ++si) {
+      fwrite(ssv[si].data(), 1, ssv[si].size(), stdout);
+      if (out1_) fwrite(fq1[si].data(), 1, fq1[si].size(), out1_);
+      if (out2_) fwrite(fq2[si].data(), 1, fq2[si].size(), out2_);
+    }
+    if (!segs.empty()) carry_ = last_id.back();
   }
 
  private:
-  static void record(FILE *f, const Strings &id, const Strings &seq, const Strings &qual, size_t i)
+  static void record(std::string &f, const Strings &id, const Strings &seq, const Strings &qual, size_t i)
   {
-    fputc('@', f);
-    if (i < id.size()) fwrite(id.at(i), 1, id.len(i), f);
-    fputc('\n', f);
-    if (i < seq.size()) fwrite(seq.at(i), 1, seq.len(i), f);
-    fputs("\n+\n", f);
-    if (i < qual.size()) fwrite(qual.at(i), 1, qual.len(i), f);
-    fputc('\n', f);
+    f.push_back('@');
+    if (i < id.size()) f.append(id.at(i), id.len(i));
+    f.push_back('\n');
+    if (i < seq.size()) f.append(seq.at(i), seq.len(i));
+    f.append("\n+\n");
+    if (i < qual.size()) f.append(qual.at(i), qual.len(i));
+    f.push_back('\n');
   }
   FILE *out1_, *out2_;
   const std::vector<std::string> &legend_;
-  std::string previd_;
+  unsigned threads_;
+  std::string carry_;   // previd at the end of the previous batch (only used when a batch starts mid-chunk)
 };
 
 template <typename T>
@@ -403,14 +507,18 @@ int main(int argc, char *argv[])
 
   // ---- 3. sample ---------------------------------------------------------------
   {
-    BatchSplitter fs(opt);
+    unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    BatchSplitter fs(opt, io_threads);
     if (!fs.ok()) {
       std::cerr << "shark: cannot open the sample" << std::endl;
       return EXIT_FAILURE;
     }
     FILE *out1 = fopen(opt.out1_path.c_str(), "w");
     FILE *out2 = (opt.paired_flag && opt.out2_path != "") ? fopen(opt.out2_path.c_str(), "w") : nullptr;
-    ReadOutput ro(out1, out2, legend_ID);
+    ReadOutput ro(out1, out2, legend_ID, io_threads);
+    if (out1) setvbuf(out1, nullptr, _IOFBF, 1 << 22);
+    if (out2) setvbuf(out2, nullptr, _IOFBF, 1 << 22);
+    setvbuf(stdout, nullptr, _IOFBF, 1 << 22);
 
     BoundedQueue<std::unique_ptr<ReadBatch>> todo((size_t)n_gpus * 2);
     std::mutex done_m;

@@ -39,16 +39,31 @@ def shard_batches(n_reads, batch_size, rank, world):
     return out
 
 
+def backend_name():
+    """"nccl" (= RCCL on ROCm) unless SHARK_DIST_BACKEND overrides it (CPU tests / single-GPU dry runs use gloo)"""
+    return os.environ.get("SHARK_DIST_BACKEND", "nccl")
+
+
+def _reduce(t, op):
+    if dist.get_backend() == "gloo" and t.is_cuda:   # gloo dry run on a GPU box: reduce a host copy
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def allreduce_sum_(t):
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _reduce(t, dist.ReduceOp.SUM)
     return t
 
 
 def max_over_ranks(seconds, device):
     if dist.is_initialized() and dist.get_world_size() > 1:
         t = torch.tensor([seconds], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _reduce(t, dist.ReduceOp.MAX)
         return float(t.item())
     return seconds
 

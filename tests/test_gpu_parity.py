@@ -315,3 +315,83 @@ def test_cli_matches_oracle_cli_on_options(oracle, tmp_path):
             assert ho1.read_bytes() == oo1.read_bytes()
             if paired:
                 assert ho2.read_bytes() == oo2.read_bytes()
+
+
+def test_non_ascii_and_control_bytes_are_invalid(oracle):
+    """bytes outside ACGTacgt -- including >= 128, NUL and '@' -- break k-mers exactly like 'N' (to_int == 0)"""
+    rng = np.random.default_rng(31)
+    genes = synth.make_genes(rng, 6, 400, 900)
+    o, h, _ = _build_both(oracle, genes, k=15, bf_bits=1 << 22)
+    b = synth.make_reads(rng, genes, 1500, read_len=110, paired=True, on_target=0.9, sub_rate=0.0, n_rate=0.0)
+    for key in ("seq1", "seq2"):
+        a = b[key]
+        idx = rng.integers(0, len(a), size=len(a) // 40)
+        a[idx] = rng.choice(np.array([0, 1, 10, 13, 32, 64, 91, 96, 123, 127, 128, 193, 225, 255], dtype=np.uint8), size=len(idx))
+    goff, _ = _compare_classify(o, h, b)
+    assert 200 < goff[-1] < 1500
+
+
+def test_bench_two_ranks_dry_run(tmp_path):
+    """the N>1 code path of bench.py (rank env, barrier, MAX over ranks, count all-reduce) with two ranks sharing
+    the one GPU of the test box over gloo; the real multi-GPU run uses RCCL"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SHARK_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--pairs", "500000"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["reads_per_step"] == 2 * 2 * 500000
+    assert j["cpu_baseline"] is None and j["scaling"] == "weak"
+    assert j["config"]["gene_count_checksum"] == 2 * j["config"]["assoc_per_step"]   # 2 steps, both ranks summed
+
+
+def test_cli_block_reader_handover_on_irregular_records(oracle, tmp_path):
+    """the block-parallel FASTQ reader must deliver exactly what kseq's rules deliver: strict records fast,
+    then a multi-line record, CR/LF records, junk between records and a last record without newline"""
+    rng = np.random.default_rng(77)
+    genes = synth.make_genes(rng, 5, 500, 1500)
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">g%d\n%s\n" % (i, bytes(g).decode()) for i, g in enumerate(genes)))
+
+    def rec(i, g, L, style):
+        st = int(rng.integers(0, len(g) - L))
+        s = bytes(g[st:st + L]).decode()
+        q = "".join(chr(int(x)) for x in rng.integers(35, 74, size=L))
+        if style == "strict":
+            return "@r%d desc\n%s\n+\n%s\n" % (i, s, q)
+        if style == "multi":
+            return "@r%d\n%s\n%s\n+r%d\n%s\n%s\n" % (i, s[:40], s[40:], i, q[:40], q[40:])
+        if style == "crlf":
+            return "@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, s, q)
+        if style == "junk":
+            return "junk line\n\n@r%d\n%s\n+\n%s\n" % (i, s, q)
+        return "@r%d\n%s\n+\n%s" % (i, s, q)   # no trailing newline
+
+    styles = ["strict"] * 1300 + ["multi"] + ["strict"] * 50 + ["crlf"] * 3 + ["junk"] + ["strict"] * 20 + ["last"]
+    t1 = "".join(rec(i, genes[i % 5], 100, st) for i, st in enumerate(styles))
+    t2 = "".join(rec(i, genes[i % 5], 90, "strict" if st in ("multi", "junk", "last") else st) for i, st in enumerate(styles))
+    f1, f2 = tmp_path / "a.fq", tmp_path / "b.fq"
+    f1.write_text(t1, newline="")
+    f2.write_text(t2, newline="")
+    args = ["-r", str(fa), "-1", str(f1), "-2", str(f2), "-k", "15"]
+    ossv = tmp_path / "o.ssv"
+    oracle.run_cli(args + ["-o", str(tmp_path / "o1.fq"), "-p", str(tmp_path / "o2.fq")], str(ossv))
+    assert ossv.read_bytes().count(b"\n") > 1000
+    for env_serial in (False, True):
+        for batch in ("333", "1000000"):
+            env = dict(os.environ)
+            if env_serial:
+                env["SHARK_SERIAL_READER"] = "1"
+            import subprocess
+            exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
+            r = subprocess.run([exe] + args + ["-o", str(tmp_path / "h1.fq"), "-p", str(tmp_path / "h2.fq"), "--batch", batch],
+                               capture_output=True, env=env, cwd=str(tmp_path))
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            assert r.stdout == ossv.read_bytes(), (env_serial, batch)
+            assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
+            assert (tmp_path / "h2.fq").read_bytes() == (tmp_path / "o2.fq").read_bytes()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs."""
+import json, os, subprocess, sys, time, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from shark_amd import synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+extra = sys.argv[2:]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rng = np.random.default_rng(5)
+gene = synth.make_reference(1, 20000)[0]
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+L = 150
+td = tempfile.mkdtemp(dir="/tmp")
+open(os.path.join(td, "g.fa"), "wb").write(b">gene0\n" + gene.tobytes() + b"\n")
+
+
+def write_fastq(path, mate):
+    # vectorised record assembly: "@r<id>/m\n" + seq + "\n+\n" + qual + "\n"
+    on = rng.random(n) < 0.5
+    st = rng.integers(0, len(gene) - 400, size=n)
+    idx = st[:, None] + np.arange(L)[None, :]
+    seqs = np.where(on[:, None], gene[idx], acgt[rng.integers(0, 4, size=(n, L))])
+    ids = np.char.add(np.char.add("@r", np.arange(n).astype(str)), "/%d" % mate)
+    with open(path, "wb") as f:
+        q = b"I" * L
+        for i in range(n):
+            f.write(ids[i].encode()); f.write(b"\n"); f.write(seqs[i].tobytes()); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
+
+
+t0 = time.time()
+write_fastq(os.path.join(td, "r1.fq"), 1)
+write_fastq(os.path.join(td, "r2.fq"), 2)
+gen_s = time.time() - t0
+t0 = time.time()
+with open(os.path.join(td, "out.ssv"), "wb") as so:
+    r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"),
+                        "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq")] + extra,
+                       stdout=so, stderr=subprocess.PIPE)
+dt = time.time() - t0
+print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
+                  "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "extra": extra,
+                  "stderr_tail": r.stderr.decode()[-300:]}))
+subprocess.run(["rm", "-rf", td])
