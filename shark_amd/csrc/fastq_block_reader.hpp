@@ -19,10 +19,14 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cctype>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace shk {
@@ -42,17 +46,26 @@ inline void parallel_for(unsigned n_threads, size_t n, F f)
   for (auto &x : th) x.join();
 }
 
+// allocator that leaves chars uninitialised on resize (every byte is overwritten)
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+  template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+  template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+
 // a view of the next `n` strict records of one file
 struct RecordBlock {
   const char *base = nullptr;          // mmap base
   std::vector<uint64_t> nl;            // offsets of the 4*n newlines (record r: lines 4r..4r+3)
+  std::vector<uint32_t> id_len, seq_len;  // per record: name length (up to the first whitespace), sequence length
   uint64_t first = 0;                  // offset of the first record's '@'
   size_t n = 0;
   // line i spans [begin(i), nl[i])
   uint64_t begin(size_t i) const { return i == 0 ? first : nl[i - 1] + 1; }
 };
 
-class FastqMmap {
+class FastqMmap {   // (historic name: the window is now filled with parallel pread, see populate note below)
  public:
   explicit FastqMmap(const std::string &path, unsigned threads) : threads_(threads)
   {
@@ -62,44 +75,64 @@ class FastqMmap {
     if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return;
     size_ = (uint64_t)st.st_size;
     if (size_ == 0) { ok_ = true; return; }
-    void *p = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
-    if (p == MAP_FAILED) return;
-    base_ = (const char *)p;
-    madvise(p, size_, MADV_SEQUENTIAL);
-    // gzip magic -> not for the fast path
-    ok_ = !(size_ >= 2 && (unsigned char)base_[0] == 0x1f && (unsigned char)base_[1] == 0x8b);
+    unsigned char magic[2] = {0, 0};
+    if (pread(fd_, magic, 2, 0) < 0) return;
+    ok_ = !(size_ >= 2 && magic[0] == 0x1f && magic[1] == 0x8b);   // gzip -> not for the fast path
+    (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
   }
   ~FastqMmap()
   {
-    if (base_) munmap((void *)base_, size_);
     if (fd_ >= 0) ::close(fd_);
   }
   FastqMmap(const FastqMmap &) = delete;
   FastqMmap &operator=(const FastqMmap &) = delete;
 
+  double t_read = 0, t_scan = 0, t_merge = 0, t_valid = 0;   // seconds per stage (verbose report)
   bool usable() const { return ok_; }
+  bool at_end() const { return cur_ >= size_; }
   uint64_t cursor() const { return cur_; }
   uint64_t size() const { return size_; }
 
   // Index up to `want` strict records starting at the cursor.  Returns the
   // number of records that are certainly regular (may be < want at the end of
   // the file or at the first irregular record; `irregular` tells which).
+  // The block points into this reader's window buffer: consume it before the
+  // next call.
   size_t next_block(size_t want, RecordBlock &blk, bool &irregular)
   {
     irregular = false;
-    blk.base = base_;
     blk.nl.clear();
     blk.n = 0;
     blk.first = cur_;
+    blk.base = nullptr;
     if (cur_ >= size_) return 0;
-    if (base_[cur_] != '@') { irregular = true; return 0; }   // kseq would skip to the next '@' / '>'
     const size_t need = want * 4;
     uint64_t scan = cur_;
     double bytes_per_line = est_line_;
+    win_start_ = cur_;
     while (blk.nl.size() < need && scan < size_) {
       const size_t missing = need - blk.nl.size();
       uint64_t win = (uint64_t)(missing * bytes_per_line * 1.05) + (1u << 16);
       const uint64_t end = std::min<uint64_t>(size_, scan + win);
+      // window [win_start_, end) must be resident: read [scan, end) with all threads.
+      // (An mmap of the file costs one minor fault per 4 KiB page -- ~0.6 us each, serialised on
+      // the address-space lock -- which capped indexing at ~5 GB/s; pread into a reused buffer does not.)
+      if (buf_.size() < end - win_start_) buf_.resize((size_t)((end - win_start_) * 1.25) + (1u << 20));
+      char *const wbase = buf_.data() - win_start_;   // wbase[file offset] is the byte at that offset
+      auto c0 = std::chrono::steady_clock::now();
+      parallel_for(threads_, (size_t)(end - scan), [&](size_t b, size_t e, unsigned) {
+        uint64_t off = scan + b;
+        const uint64_t stop = scan + e;
+        while (off < stop) {
+          const ssize_t got = pread(fd_, wbase + off, (size_t)std::min<uint64_t>(stop - off, 1u << 30), (off_t)off);
+          if (got <= 0) { memset(wbase + off, 0, (size_t)(stop - off)); break; }   // I/O error: NULs make the records irregular
+          off += (uint64_t)got;
+        }
+      });
+      base_ = wbase;
+      auto c1 = std::chrono::steady_clock::now();
+      t_read += std::chrono::duration<double>(c1 - c0).count();
+      if (scan == cur_ && base_[cur_] != '@') { irregular = true; blk.base = base_; return 0; }   // kseq would skip to the next '@' / '>'
       const unsigned T = threads_;
       std::vector<std::vector<uint64_t>> parts(T);
       parallel_for(T, (size_t)(end - scan), [&](size_t b, size_t e, unsigned t) {
@@ -113,34 +146,54 @@ class FastqMmap {
           p = q + 1;
         }
       });
-      for (auto &v : parts) {
-        const size_t take = std::min(v.size(), need - blk.nl.size());
-        blk.nl.insert(blk.nl.end(), v.begin(), v.begin() + take);
-        if (blk.nl.size() == need) break;
+      auto c2 = std::chrono::steady_clock::now();
+      t_scan += std::chrono::duration<double>(c2 - c1).count();
+      {
+        // concatenate the per-thread offset lists (in order) with all threads
+        std::vector<size_t> at(T + 1, blk.nl.size());
+        for (unsigned t = 0; t < T; ++t) at[t + 1] = std::min(need, at[t] + parts[t].size());
+        blk.nl.resize(at[T]);
+        parallel_for(T, T, [&](size_t b, size_t e, unsigned) {
+          for (size_t t = b; t < e; ++t)
+            if (at[t + 1] > at[t]) memcpy(blk.nl.data() + at[t], parts[t].data(), (at[t + 1] - at[t]) * sizeof(uint64_t));
+        });
       }
+      t_merge += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
       scan = end;
       if (!blk.nl.empty()) bytes_per_line = std::max(8.0, (double)(blk.nl.back() - cur_) / (double)blk.nl.size());
     }
     est_line_ = bytes_per_line;
+    blk.base = base_;
     // a last record without a trailing newline is left to the serial reader
     size_t n = blk.nl.size() / 4;
     // validate in parallel: '@', '+', equal lengths, no '\r'
+    auto c3 = std::chrono::steady_clock::now();
     std::vector<size_t> bad(threads_, (size_t)-1);
+    blk.id_len.resize(n);
+    blk.seq_len.resize(n);
     parallel_for(threads_, n, [&](size_t b, size_t e, unsigned t) {
       for (size_t r = b; r < e; ++r) {
         const uint64_t h0 = blk.begin(4 * r), h1 = blk.nl[4 * r];
         const uint64_t s0 = h1 + 1, s1 = blk.nl[4 * r + 1];
         const uint64_t p0 = s1 + 1, p1 = blk.nl[4 * r + 2];
         const uint64_t q0 = p1 + 1, q1 = blk.nl[4 * r + 3];
-        bool good = base_[h0] == '@' && p1 > p0 - 0 && base_[p0] == '+' && (s1 - s0) == (q1 - q0) && h1 > h0;
+        bool good = base_[h0] == '@' && p1 > p0 && base_[p0] == '+' && (s1 - s0) == (q1 - q0) && h1 > h0 && s1 > s0;
         // characters kseq treats specially at the start of a sequence line, CR/LF, embedded NULs
-        if (good && s1 > s0 && (base_[s0] == '@' || base_[s0] == '>' || base_[s0] == '+')) good = false;
-        if (good && (base_[h1 - 1] == '\r' || (s1 > s0 && base_[s1 - 1] == '\r') || (q1 > q0 && base_[q1 - 1] == '\r'))) good = false;
-        if (good && (memchr(base_ + s0, 0, (size_t)(s1 - s0)) || memchr(base_ + q0, 0, (size_t)(q1 - q0)) || memchr(base_ + h0, 0, (size_t)(h1 - h0)))) good = false;
-        if (good && s1 == s0) good = false;   // empty sequence line: let kseq's rules decide
+        if (good && (base_[s0] == '@' || base_[s0] == '>' || base_[s0] == '+')) good = false;
+        if (good && (base_[h1 - 1] == '\r' || base_[s1 - 1] == '\r' || base_[q1 - 1] == '\r')) good = false;
+        if (good && (memchr(base_ + s0, 0, (size_t)(s1 - s0)) || memchr(base_ + q0, 0, (size_t)(q1 - q0)))) good = false;
+        if (good) {
+          // name = header up to the first whitespace (kseq.h:188); a NUL in it is irregular too
+          uint64_t p = h0 + 1;
+          while (p < h1 && !isspace((unsigned char)base_[p]) && base_[p] != 0) ++p;
+          if (p < h1 && base_[p] == 0) good = false;
+          blk.id_len[r] = (uint32_t)(p - (h0 + 1));
+          blk.seq_len[r] = (uint32_t)(s1 - s0);
+        }
         if (!good) { bad[t] = r; break; }
       }
     });
+    t_valid += std::chrono::duration<double>(std::chrono::steady_clock::now() - c3).count();
     size_t first_bad = n;
     for (size_t v : bad) if (v != (size_t)-1) first_bad = std::min(first_bad, v);
     if (first_bad < n) { irregular = true; n = first_bad; }
@@ -158,8 +211,9 @@ class FastqMmap {
 
  private:
   int fd_ = -1;
-  const char *base_ = nullptr;
-  uint64_t size_ = 0, cur_ = 0;
+  const char *base_ = nullptr;   // window buffer biased by the window's file offset
+  std::vector<char, NoInitAlloc<char>> buf_;
+  uint64_t size_ = 0, cur_ = 0, win_start_ = 0;
   bool ok_ = false;
   unsigned threads_;
   double est_line_ = 80.0;

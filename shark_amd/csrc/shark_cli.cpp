@@ -206,16 +206,27 @@ class BatchSplitter {
   }
   bool ok() const { return r1_.ok() && (!paired_ || r2_->ok()); }
   bool fast_path() const { return fast_; }
+  std::string stage_report() const
+  {
+    std::ostringstream o;
+    o << "read " << m1_->t_read + (m2_ ? m2_->t_read : 0) << " scan " << m1_->t_scan + (m2_ ? m2_->t_scan : 0) << " merge "
+      << m1_->t_merge + (m2_ ? m2_->t_merge : 0) << " validate " << m1_->t_valid + (m2_ ? m2_->t_valid : 0);
+    return o.str();
+  }
+  double t_index = 0, t_fill = 0, t_serial = 0;   // seconds spent (verbose report)
   std::unique_ptr<ReadBatch> operator()()
   {
     std::unique_ptr<ReadBatch> b(new ReadBatch());
     b->index = next_index_++;
     b->first_read = n_reads_;
     if (fast_) {
-      shk::RecordBlock k1, k2;
+      shk::RecordBlock &k1 = blk1_, &k2 = blk2_;   // reused: their buffers keep their capacity
       bool irr1 = false, irr2 = false;
+      auto ta = std::chrono::steady_clock::now();
       size_t n = m1_->next_block(maxnum_, k1, irr1);
       if (paired_) n = std::min(n, m2_->next_block(maxnum_, k2, irr2));
+      auto tb = std::chrono::steady_clock::now();
+      t_index += std::chrono::duration<double>(tb - ta).count();
       if (n) {
         fill(k1, n, b->id1, b->seq1, b->qual1);
         m1_->advance(k1, n);
@@ -224,14 +235,20 @@ class BatchSplitter {
           m2_->advance(k2, n);
         }
       }
+      t_fill += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
       if (n < maxnum_) {
         // end of a file or an irregular record: the serial reader takes over from here
         fast_ = false;
-        r1_.seek(m1_->cursor());
-        if (paired_) r2_->seek(m2_->cursor());
+        if (m1_->at_end() || (paired_ && m2_->at_end())) {
+          done_ = true;   // a mate file is exhausted: the reference's read loop ends here too (FastqSplitter.hpp:53,60)
+        } else {
+          r1_.seek(m1_->cursor());
+          if (paired_) r2_->seek(m2_->cursor());
+        }
       }
     }
-    if (!fast_) {
+    if (!fast_ && !done_) {
+      auto ts = std::chrono::steady_clock::now();
       shk::FastxRecord a, c;
       while (b->seq1.size() < maxnum_) {
         if (r1_.read(a) < 0) break;
@@ -246,6 +263,7 @@ class BatchSplitter {
           b->qual2.push(c.qual.data(), strnlen(c.qual.data(), c.qual.size()));
         }
       }
+      t_serial += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
     }
     n_reads_ += b->seq1.size();
     if (b->seq1.size() == 0) return nullptr;
@@ -256,16 +274,7 @@ class BatchSplitter {
   // copy n strict records into the structure-of-arrays strings, in parallel
   void fill(const shk::RecordBlock &k, size_t n, Strings &id, Strings &seq, Strings &qual)
   {
-    std::vector<uint32_t> idl(n), sql(n);
-    shk::parallel_for(threads_, n, [&](size_t b, size_t e, unsigned) {
-      for (size_t r = b; r < e; ++r) {
-        const uint64_t h0 = k.begin(4 * r) + 1, h1 = k.nl[4 * r];
-        uint64_t p = h0;
-        while (p < h1 && !isspace((unsigned char)k.base[p])) ++p;   // name = up to the first whitespace (kseq.h:188)
-        idl[r] = (uint32_t)(p - h0);
-        sql[r] = (uint32_t)(k.nl[4 * r + 1] - (k.nl[4 * r] + 1));
-      }
-    });
+    const std::vector<uint32_t> &idl = k.id_len, &sql = k.seq_len;   // measured while the block was validated
     id.off.resize(n + 1);
     seq.off.resize(n + 1);
     qual.off.resize(n + 1);
@@ -290,7 +299,8 @@ class BatchSplitter {
   shk::FastxReader r1_;
   std::unique_ptr<shk::FastxReader> r2_;
   std::unique_ptr<shk::FastqMmap> m1_, m2_;
-  bool paired_, fast_ = false;
+  shk::RecordBlock blk1_, blk2_;
+  bool paired_, fast_ = false, done_ = false;
   uint64_t maxnum_;
   unsigned threads_;
   uint64_t next_index_ = 0, n_reads_ = 0;
@@ -527,6 +537,7 @@ int main(int argc, char *argv[])
     uint64_t n_batches = 0;
     bool split_finished = false;
 
+    std::vector<double> t_gpu((size_t)n_gpus, 0.0);
     std::thread splitter([&] {
       for (;;) {
         auto b = fs();
@@ -548,7 +559,9 @@ int main(int argc, char *argv[])
         ReadAnalyzer ra(ctxs[(size_t)g], opt.min_quality != 0);
         std::unique_ptr<ReadBatch> b;
         while (todo.pop(b)) {
+          auto t0 = std::chrono::steady_clock::now();
           ra(*b);
+          t_gpu[(size_t)g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           std::lock_guard<std::mutex> l(done_m);
           done[b->index] = std::move(b);
           done_cv.notify_all();
@@ -558,6 +571,7 @@ int main(int argc, char *argv[])
     // ordered drain
     uint64_t next = 0;
     int failed = 0;
+    double t_out = 0;
     for (;;) {
       std::unique_ptr<ReadBatch> b;
       {
@@ -570,13 +584,19 @@ int main(int argc, char *argv[])
       if (b->rc != SHK_OK) {
         failed = b->rc;
       } else {
+        auto t0 = std::chrono::steady_clock::now();
         ro(*b);
+        t_out += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       ++next;
     }
     splitter.join();
     for (auto &t : analyzers) t.join();
     fflush(stdout);
+    if (opt.verbose) {
+      std::cerr << "[shark/io] threads " << io_threads << (fs.t_serial > 0 ? " serial-reader " : " block-reader ") << "index " << fs.t_index
+                << " s (" << fs.stage_report() << "), fill " << fs.t_fill << " s, serial " << fs.t_serial << " s, classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
+    }
     if (out1) fclose(out1);
     if (out2) fclose(out2);
     if (failed) {

@@ -6,6 +6,7 @@ import numpy as np
 from shark_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+on_target = float(os.environ.get('ON_TARGET', '0.5'))
 extra = sys.argv[2:]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rng = np.random.default_rng(5)
@@ -18,7 +19,7 @@ open(os.path.join(td, "g.fa"), "wb").write(b">gene0\n" + gene.tobytes() + b"\n")
 
 def write_fastq(path, mate):
     # vectorised record assembly: "@r<id>/m\n" + seq + "\n+\n" + qual + "\n"
-    on = rng.random(n) < 0.5
+    on = rng.random(n) < on_target
     st = rng.integers(0, len(gene) - 400, size=n)
     idx = st[:, None] + np.arange(L)[None, :]
     seqs = np.where(on[:, None], gene[idx], acgt[rng.integers(0, 4, size=(n, L))])
