@@ -64,39 +64,126 @@ struct WaveStore {
   uint32_t *cur;        // per slot: gene at the cursor, GENE_INF when exhausted / no hit
 };
 
-// 8 bytes starting at p, of which only `rem` (>= 1) belong to the read.  The
-// full-width load is used only when all 8 bytes are inside the read, so no
-// byte outside the caller's buffers is ever touched.
+// 8 bytes starting at p, of which only `rem` (>= 1) belong to the read.  Reads are packed back
+// to back, so p has no alignment.  Unaligned 8-byte loads are slow on this path and a byte loop for
+// the tail of a mate serialises one memory latency per byte (measured: 4.5 of 15 ms on the all-miss
+// workload), so the bytes are fetched as up to three ALIGNED dwords and realigned with
+// v_alignbyte_b32.  An aligned dword that contains at least one byte of the read cannot leave the
+// caller's allocation, so nothing outside the buffers is ever touched.
 __device__ __forceinline__ uint64_t load8(const uint8_t *p, uint32_t rem)
 {
-  if (rem >= 8) {
-    uint64_t w;
-    __builtin_memcpy(&w, p, 8);
-    return w;
-  }
-  uint64_t w = 0;
-  for (uint32_t i = 0; i < rem; ++i) w |= (uint64_t)p[i] << (8 * i);
+  const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
+  const uint32_t nbytes = rem < 8u ? rem : 8u;
+  const uint32_t last = sh + nbytes - 1u;            // index of the last wanted byte relative to q
+  const uint32_t d0 = q[0];
+  const uint32_t d1 = last >= 4u ? q[1] : 0u;
+  const uint32_t d2 = last >= 8u ? q[2] : 0u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  uint64_t w = ((uint64_t)hi << 32) | lo;
+  if (nbytes < 8u) w &= (1ull << (8u * nbytes)) - 1ull;
   return w;
+}
+
+// offsets / lengths of one read (pair)
+struct ReadMeta {
+  uint64_t o1, o2;
+  uint32_t L1, L2;
+};
+
+// a wave-uniform 64-bit value, forced into SGPRs so that loads addressed by it are scalar loads
+// (a vector load of the offsets would put an s_waitcnt vmcnt(0) right behind the prefetched bases)
+__device__ __forceinline__ uint64_t uniform64(uint64_t x)
+{
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ ReadMeta fetch_meta(const ClassifyParams &P, uint64_t read_in)
+{
+  const uint64_t read = uniform64(read_in);
+  ReadMeta m;
+  m.o1 = P.off1[read];
+  m.L1 = (uint32_t)(P.off1[read + 1] - m.o1);
+  m.o2 = 0;
+  m.L2 = 0;
+  if (P.seq2) {
+    m.o2 = P.off2[read];
+    m.L2 = (uint32_t)(P.off2[read + 1] - m.o2);
+  }
+  return m;
+}
+
+// Offsets of a read fetched with explicit SCALAR loads.  hipcc turns these uniform loads into
+// vector loads once the kernel has stored anything (it cannot prove the offsets invariant), and a
+// vector load behind the prefetched bases forces `s_waitcnt vmcnt(0)` -- the prefetch would be
+// waited for immediately.  s_load uses the lgkm counter instead.  The compiler does not track
+// asm loads, so meta_wait() must run before the values are used (cdna_hip_programming.md 5.7).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct ReadMetaRaw {
+  u32x4 a, b;   // off1[read], off1[read+1] ; off2[read], off2[read+1]
+};
+
+__device__ __forceinline__ ReadMetaRaw fetch_meta_async(const ClassifyParams &P, uint64_t read_in)
+{
+  const uint64_t read = uniform64(read_in);
+  ReadMetaRaw r;
+  const uint64_t *p1 = P.off1 + read;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r.a) : "s"(p1));
+  if (P.seq2) {
+    const uint64_t *p2 = P.off2 + read;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r.b) : "s"(p2));
+  } else {
+    r.b = u32x4{0, 0, 0, 0};
+  }
+  return r;
+}
+
+__device__ __forceinline__ ReadMeta meta_wait(ReadMetaRaw r)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b));
+  ReadMeta m;
+  m.o1 = ((uint64_t)r.a.y << 32) | r.a.x;
+  m.L1 = (uint32_t)((((uint64_t)r.a.w << 32) | r.a.z) - m.o1);
+  m.o2 = ((uint64_t)r.b.y << 32) | r.b.x;
+  m.L2 = (uint32_t)((((uint64_t)r.b.w << 32) | r.b.z) - m.o2);
+  return m;
+}
+
+// the 8 bases (and qualities) that lane `gi` stages for this read: group gi of the packed layout
+template <bool HASQ>
+__device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadMeta &m, uint32_t gi, uint64_t &w, uint64_t &q)
+{
+  const uint32_t g2 = (((m.L1 + 31) >> 5) << 5) >> 3;
+  const uint32_t n_groups = g2 + ((m.L2 + 7) >> 3);
+  w = 0;
+  q = 0;
+  if (P.ablate & 4u) { w = 0x4341544743414754ull ^ ((uint64_t)(gi * 0x9E3779B9u + m.o1) & 0x0606060606060606ull); return; }   // ablation 4: no base loads
+  if (gi < n_groups) {
+    const bool m2 = gi >= g2;
+    const uint32_t b = (m2 ? gi - g2 : gi) << 3;
+    const uint32_t L = m2 ? m.L2 : m.L1;
+    if (b < L) {
+      w = load8((m2 ? P.seq2 + m.o2 : P.seq1 + m.o1) + b, L - b);
+      if (HASQ) q = load8((m2 ? P.qual2 + m.o2 : P.qual1 + m.o1) + b, L - b);
+    }
+  }
 }
 
 template <int U, int MODE, bool HASQ, bool FAST, bool EMIT>
 __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
                                              const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk,
-                                             const uint32_t *lsum = nullptr)
+                                             const uint32_t *lsum, const ReadMeta meta, const bool pre, const uint64_t pre_w, const uint64_t pre_q)
 {
   constexpr bool POW2 = MODE != PM_BV_MOD;
   constexpr bool SUM = MODE == PM_BV_SUM || MODE == PM_TAB_SUM;
   constexpr bool LSUM = MODE == PM_LDS_TAB;
   constexpr bool TAB = MODE == PM_TAB || MODE == PM_TAB_SUM || MODE == PM_LDS_TAB;
   const uint32_t k = P.k;
-  const uint64_t o1 = P.off1[read];
-  const uint32_t L1 = (uint32_t)(P.off1[read + 1] - o1);
-  uint64_t o2 = 0;
-  uint32_t L2 = 0;
-  if (P.seq2) {
-    o2 = P.off2[read];
-    L2 = (uint32_t)(P.off2[read + 1] - o2);
-  }
+  const uint64_t o1 = meta.o1, o2 = meta.o2;
+  const uint32_t L1 = meta.L1, L2 = meta.L2;
   const uint32_t nk1 = L1 >= k ? L1 - k + 1 : 0;
   const uint32_t nk2 = L2 >= k ? L2 - k + 1 : 0;
   const uint32_t ns = nk1 + nk2;
@@ -119,23 +206,20 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   const uint32_t g2 = P2 >> 3;
   const uint32_t n_groups = g2 + ((L2 + 7) >> 3);
   uint32_t my_valid = 0;
-  for (uint32_t gi = lane; gi < n_groups; gi += 64) {
+  // classify + pack the 8 bases of group gi (already in registers) and write them to LDS
+  auto stage_group = [&](const uint32_t gi, const uint64_t w, const uint64_t q) {
     const bool m2 = gi >= g2;
     const uint32_t b = (m2 ? gi - g2 : gi) << 3;
     const uint32_t L = m2 ? L2 : L1;
     uint32_t code16 = 0, valid8 = 0;
     if (b < L) {
       const uint32_t rem = L - b;
-      const uint64_t w = load8((m2 ? P.seq2 + o2 : P.seq1 + o1) + b, rem);
       uint32_t c_lo, c_hi, i_lo, i_hi;
       classify4((uint32_t)w, c_lo, i_lo);
       classify4((uint32_t)(w >> 32), c_hi, i_hi);
       code16 = (pack4(c_lo) << 8) | pack4(c_hi);
       uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4);
-      if (HASQ) {
-        const uint64_t q = load8((m2 ? P.qual2 + o2 : P.qual1 + o1) + b, rem);
-        inv8 |= gather4(qmask4((uint32_t)q, P.mq)) | (gather4(qmask4((uint32_t)(q >> 32), P.mq)) << 4);
-      }
+      if (HASQ) inv8 |= gather4(qmask4((uint32_t)q, P.mq)) | (gather4(qmask4((uint32_t)(q >> 32), P.mq)) << 4);
       if (rem < 8) inv8 |= 0xFFu << rem;
       valid8 = ~inv8 & 0xFFu;
     }
@@ -143,6 +227,17 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     reinterpret_cast<uint16_t *>(st.codes)[((gi >> 2) << 2) + (3u - (gi & 3u))] = (uint16_t)code16;
     reinterpret_cast<uint8_t *>(st.vbits)[gi] = (uint8_t)valid8;
     my_valid += __builtin_popcount(valid8);
+  };
+  uint32_t gi0 = (uint32_t)lane;
+  if (pre) {
+    // this lane's first group was fetched one read ahead: no load (and no wait) on this path
+    if (gi0 < n_groups) stage_group(gi0, pre_w, pre_q);
+    gi0 += 64;
+  }
+  for (uint32_t gi = gi0; gi < n_groups; gi += 64) {
+    uint64_t w = 0x4341544743414754ull, q = 0;   // (ablation 4: no base loads)
+    if (!(P.ablate & 4u)) fetch_group<HASQ>(P, meta, gi, w, q);
+    stage_group(gi, w, q);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -467,10 +562,10 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 // ---------------------------------------------------------------------------
 template <int MODE>
 struct FastGeom {
-  static constexpr int WAVES = MODE == PM_LDS_TAB ? 16 : CF_WAVES;   // 1024-thread workgroups share one LDS summary
+  static constexpr int WAVES = MODE == PM_LDS_TAB ? 8 : CF_WAVES;   // 512-thread workgroups share one LDS summary
   static constexpr int THREADS = WAVES * 64;
   // two 1024-thread workgroups per CU need 8 waves per SIMD, i.e. <= 64 VGPRs
-  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? 8 : 1;
+  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? 6 : 1;
   static constexpr uint32_t SUM_WORDS64 = MODE == PM_LDS_TAB ? LDS_SUM_BITS / 64 : 0;
 };
 
@@ -500,9 +595,34 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
   st.rec_start = nullptr;
   st.rec_end = nullptr;
   st.cur = nullptr;
+  // software pipeline over this wave's reads: the offsets are fetched two reads ahead and the
+  // bases one read ahead, so their HBM latency hides under the hashing of the current read
+  // (ablation: the in-place base loads cost 4.4 of 14 ms on the all-miss workload)
   const uint64_t stride = (uint64_t)gridDim.x * G::WAVES;
-  for (uint64_t read = (uint64_t)blockIdx.x * G::WAVES + wave; read < P.n; read += stride)
-    process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u, lsum);
+  uint64_t read = (uint64_t)blockIdx.x * G::WAVES + wave;
+  if (read >= P.n) return;
+  ReadMeta m_cur = fetch_meta(P, read);
+  uint64_t w_cur, q_cur;
+  fetch_group<HASQ>(P, m_cur, (uint32_t)lane, w_cur, q_cur);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w_cur), "+v"(q_cur));   // same reason as at the loop end
+  uint64_t nxt = read + stride;
+  ReadMeta m_nxt = fetch_meta(P, nxt < P.n ? nxt : read);
+  for (;;) {
+    uint64_t w_nxt = 0, q_nxt = 0;
+    const bool have_nxt = nxt < P.n;
+    if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
+    const uint64_t nn = nxt + stride;
+    const ReadMetaRaw r_nn = fetch_meta_async(P, nn < P.n ? nn : read);   // scalar loads, clamped index
+    process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u, lsum, m_cur, true, w_cur, q_cur);
+    if (!have_nxt) break;
+    // The prefetched bases landed long ago.  Retire them HERE and hand the compiler plain register
+    // values: otherwise it carries "a load may be pending" around the loop and, because the number of
+    // younger loads is branch dependent, protects the first use with s_waitcnt vmcnt(0) -- right
+    // behind the next prefetch, which would serialise the pipeline again.
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w_nxt), "+v"(q_nxt));
+    read = nxt; m_cur = m_nxt; w_cur = w_nxt; q_cur = q_nxt;
+    nxt = nn; m_nxt = meta_wait(r_nn);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -538,7 +658,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
     } else if (P.work) {
       read = P.work[w];
     }
-    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn);
+    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn, nullptr, fetch_meta(P, read), false, 0ull, 0ull);
   }
 }
 
@@ -653,8 +773,8 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   const int mode = probe_mode(ctx->idx);
   // persistent grid: enough workgroups to fill 256 CUs several times over
   // persistent workgroups; the LDS-summary mode runs 2 x 1024-thread workgroups per CU
-  const uint64_t wpb = mode == PM_LDS_TAB ? 16 : CF_WAVES;
-  const uint64_t cap = mode == PM_LDS_TAB ? 512 : 4096;
+  const uint64_t wpb = mode == PM_LDS_TAB ? 8 : CF_WAVES;
+  const uint64_t cap = mode == PM_LDS_TAB ? 768 : 4096;
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   const uint32_t u = fast_kernel_unroll(max_slots);

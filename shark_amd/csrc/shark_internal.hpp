@@ -40,7 +40,7 @@ namespace shk {
 //                [31:0]  gene (single-gene list) or rank r (multi: ent[r])
 //              The filter itself stays in HBM as the ground truth (it defines
 //              rank, is exported, and is what the tests compare bit for bit).
-constexpr uint32_t LDS_SUM_LOG2 = 19;                 // 2^19 bits = 64 KiB of LDS per workgroup
+constexpr uint32_t LDS_SUM_LOG2 = 18;                 // 2^18 bits = 32 KiB of LDS per workgroup
 constexpr uint32_t LDS_SUM_BITS = 1u << LDS_SUM_LOG2;
 
 struct ListEntry {
