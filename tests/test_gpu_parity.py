@@ -395,3 +395,62 @@ def test_cli_block_reader_handover_on_irregular_records(oracle, tmp_path):
             assert r.stdout == ossv.read_bytes(), (env_serial, batch)
             assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
             assert (tmp_path / "h2.fq").read_bytes() == (tmp_path / "o2.fq").read_bytes()
+
+
+def test_full_size_properties_config2():
+    """BASELINE configs[1] at full size (10 M pairs 2x150 bp, 1 gene, k=17, 2^33-bit filter) through
+    size-independent properties of the domain:
+      * mate swap and read reverse-complement leave every read's gene set unchanged (canonical k-mers; the
+        per-gene coverage is a union of k-mer intervals, which mirrors under reverse complement)
+      * results do not depend on how the batch is split or ordered
+      * the per-gene counters equal a histogram of the per-read results; two runs are identical
+      * every error-free on-target pair is assigned, no uniform-random pair is (filter density 2e-6)"""
+    from shark_amd import synth as dsynth
+    from shark_amd.capi import hip_memcpy_dtoh
+    n, L = 10_000_000, 150
+    dev = torch.device("cuda:0")
+    genes = dsynth.make_reference(1, 20000)
+    h = _hip(k=17, c=0.6, bf_bits=1 << 33)
+    h.build([g.tobytes() for g in genes])
+    b = dsynth.make_pairs_device(n, genes, dev, seed=99, sub_rate=0.0, n_rate=0.0)
+    torch.cuda.synchronize()
+
+    def run(seq1, off1, seq2, off2, m=n):
+        r = h.classify_device(m, seq1.data_ptr(), off1.data_ptr(), seq2.data_ptr(), off2.data_ptr(), max_read_len=L)
+        goff = np.empty(m + 1, np.uint32)
+        hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+        gids = np.empty(int(r.n_assoc), np.uint16)
+        if len(gids):
+            hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+        return goff, gids
+
+    h.gene_counts_reset()
+    goff, gids = run(b["seq1"], b["off1"], b["seq2"], b["off2"])
+    cnt = np.diff(goff.astype(np.int64))
+    assert int(h.gene_counts(4)[0]) == int((gids == 0).sum()) == int(cnt.sum())
+    assert cnt.max() == 1 and 0.49 * n < cnt.sum() < 0.51 * n      # half the pairs come from the gene, error free
+    # determinism
+    g2, i2 = run(b["seq1"], b["off1"], b["seq2"], b["off2"])
+    assert np.array_equal(goff, g2) and np.array_equal(gids, i2)
+    # mate swap
+    g3, _ = run(b["seq2"], b["off2"], b["seq1"], b["off1"])
+    assert np.array_equal(goff, g3)
+    # reverse complement of both mates (fixed length: reshape, flip, complement)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a_, c_ in zip(b"ACGTN", b"TGCAN"):
+        comp[a_] = c_
+    rc1 = comp[b["seq1"].view(n, L).flip(1).to(torch.int64)].contiguous().view(-1)
+    rc2 = comp[b["seq2"].view(n, L).flip(1).to(torch.int64)].contiguous().view(-1)
+    torch.cuda.synchronize()
+    g4, _ = run(rc1, b["off1"], rc2, b["off2"])
+    assert np.array_equal(goff, g4)
+    # order independence: reverse the order of the reads
+    r1 = b["seq1"].view(n, L).flip(0).contiguous().view(-1)
+    r2 = b["seq2"].view(n, L).flip(0).contiguous().view(-1)
+    torch.cuda.synchronize()
+    g5, _ = run(r1, b["off1"], r2, b["off2"])
+    assert np.array_equal(np.diff(g5.astype(np.int64)), cnt[::-1])
+    # split independence: first 3 333 333 pairs alone
+    m = 3_333_333
+    g6, _ = run(b["seq1"], b["off1"], b["seq2"], b["off2"], m=m)
+    assert np.array_equal(g6, goff[:m + 1])
