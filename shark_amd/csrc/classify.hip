@@ -70,20 +70,40 @@ struct WaveStore {
 // workload), so the bytes are fetched as up to three ALIGNED dwords and realigned with
 // v_alignbyte_b32.  An aligned dword that contains at least one byte of the read cannot leave the
 // caller's allocation, so nothing outside the buffers is ever touched.
-__device__ __forceinline__ uint64_t load8(const uint8_t *p, uint32_t rem)
+struct Raw8 {
+  uint32_t d0, d1, d2;   // up to three aligned dwords
+  uint32_t shn;          // byte shift (bits 1:0) | number of wanted bytes << 4 (0 = nothing fetched)
+};
+
+__device__ __forceinline__ Raw8 load8_issue(const uint8_t *p, uint32_t rem)
 {
   const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
   const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
   const uint32_t nbytes = rem < 8u ? rem : 8u;
   const uint32_t last = sh + nbytes - 1u;            // index of the last wanted byte relative to q
-  const uint32_t d0 = q[0];
-  const uint32_t d1 = last >= 4u ? q[1] : 0u;
-  const uint32_t d2 = last >= 8u ? q[2] : 0u;
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-  const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  Raw8 r;
+  r.d0 = q[0];
+  r.d1 = last >= 4u ? q[1] : 0u;
+  r.d2 = last >= 8u ? q[2] : 0u;
+  r.shn = sh | (nbytes << 4);
+  return r;
+}
+
+// realign (first use of the loaded dwords: this is where the wait lands)
+__device__ __forceinline__ uint64_t load8_finish(const Raw8 r)
+{
+  const uint32_t sh = r.shn & 3u, nbytes = r.shn >> 4;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(r.d1, r.d0, sh);
+  const uint32_t hi = __builtin_amdgcn_alignbyte(r.d2, r.d1, sh);
   uint64_t w = ((uint64_t)hi << 32) | lo;
   if (nbytes < 8u) w &= (1ull << (8u * nbytes)) - 1ull;
   return w;
+}
+
+// wait for outstanding vector loads and hand `r` back as plain register values
+__device__ __forceinline__ void retire_loads(Raw8 &r)
+{
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.d0), "+v"(r.d1), "+v"(r.d2));
 }
 
 // offsets / lengths of one read (pair)
@@ -152,22 +172,23 @@ __device__ __forceinline__ ReadMeta meta_wait(ReadMetaRaw r)
   return m;
 }
 
-// the 8 bases (and qualities) that lane `gi` stages for this read: group gi of the packed layout
+// issue the loads of the 8 bases (and qualities) that lane `gi` stages for this read (group gi of
+// the packed layout); nothing here consumes the loaded dwords, so no wait is placed here
 template <bool HASQ>
-__device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadMeta &m, uint32_t gi, uint64_t &w, uint64_t &q)
+__device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadMeta &m, uint32_t gi, Raw8 &w, Raw8 &q)
 {
   const uint32_t g2 = (((m.L1 + 31) >> 5) << 5) >> 3;
   const uint32_t n_groups = g2 + ((m.L2 + 7) >> 3);
-  w = 0;
-  q = 0;
-  if (P.ablate & 4u) { w = 0x4341544743414754ull ^ ((uint64_t)(gi * 0x9E3779B9u + m.o1) & 0x0606060606060606ull); return; }   // ablation 4: no base loads
+  w = Raw8{0u, 0u, 0u, 0u};
+  q = Raw8{0u, 0u, 0u, 0u};
+  if (P.ablate & 4u) { w.d0 = 0x43414754u; w.d1 = 0x43415447u; w.shn = 8u << 4; return; }   // ablation 4: no base loads
   if (gi < n_groups) {
     const bool m2 = gi >= g2;
     const uint32_t b = (m2 ? gi - g2 : gi) << 3;
     const uint32_t L = m2 ? m.L2 : m.L1;
     if (b < L) {
-      w = load8((m2 ? P.seq2 + m.o2 : P.seq1 + m.o1) + b, L - b);
-      if (HASQ) q = load8((m2 ? P.qual2 + m.o2 : P.qual1 + m.o1) + b, L - b);
+      w = load8_issue((m2 ? P.seq2 + m.o2 : P.seq1 + m.o1) + b, L - b);
+      if (HASQ) q = load8_issue((m2 ? P.qual2 + m.o2 : P.qual1 + m.o1) + b, L - b);
     }
   }
 }
@@ -175,7 +196,7 @@ __device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadM
 template <int U, int MODE, bool HASQ, bool FAST, bool EMIT>
 __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
                                              const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk,
-                                             const uint32_t *lsum, const ReadMeta meta, const bool pre, const uint64_t pre_w, const uint64_t pre_q)
+                                             const uint32_t *lsum, const ReadMeta meta, const bool pre, const Raw8 pre_w, const Raw8 pre_q)
 {
   constexpr bool POW2 = MODE != PM_BV_MOD;
   constexpr bool SUM = MODE == PM_BV_SUM || MODE == PM_TAB_SUM;
@@ -231,13 +252,13 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   uint32_t gi0 = (uint32_t)lane;
   if (pre) {
     // this lane's first group was fetched one read ahead: no load (and no wait) on this path
-    if (gi0 < n_groups) stage_group(gi0, pre_w, pre_q);
+    if (gi0 < n_groups) stage_group(gi0, load8_finish(pre_w), HASQ ? load8_finish(pre_q) : 0ull);
     gi0 += 64;
   }
   for (uint32_t gi = gi0; gi < n_groups; gi += 64) {
-    uint64_t w = 0x4341544743414754ull, q = 0;   // (ablation 4: no base loads)
-    if (!(P.ablate & 4u)) fetch_group<HASQ>(P, meta, gi, w, q);
-    stage_group(gi, w, q);
+    Raw8 w, q;
+    fetch_group<HASQ>(P, meta, gi, w, q);
+    stage_group(gi, load8_finish(w), HASQ ? load8_finish(q) : 0ull);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -602,13 +623,14 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
   uint64_t read = (uint64_t)blockIdx.x * G::WAVES + wave;
   if (read >= P.n) return;
   ReadMeta m_cur = fetch_meta(P, read);
-  uint64_t w_cur, q_cur;
+  Raw8 w_cur, q_cur;
   fetch_group<HASQ>(P, m_cur, (uint32_t)lane, w_cur, q_cur);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w_cur), "+v"(q_cur));   // same reason as at the loop end
+  retire_loads(w_cur);   // same reason as at the loop end
+  retire_loads(q_cur);
   uint64_t nxt = read + stride;
   ReadMeta m_nxt = fetch_meta(P, nxt < P.n ? nxt : read);
   for (;;) {
-    uint64_t w_nxt = 0, q_nxt = 0;
+    Raw8 w_nxt = Raw8{0u, 0u, 0u, 0u}, q_nxt = Raw8{0u, 0u, 0u, 0u};
     const bool have_nxt = nxt < P.n;
     if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
     const uint64_t nn = nxt + stride;
@@ -619,7 +641,8 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
     // values: otherwise it carries "a load may be pending" around the loop and, because the number of
     // younger loads is branch dependent, protects the first use with s_waitcnt vmcnt(0) -- right
     // behind the next prefetch, which would serialise the pipeline again.
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w_nxt), "+v"(q_nxt));
+    retire_loads(w_nxt);
+    retire_loads(q_nxt);
     read = nxt; m_cur = m_nxt; w_cur = w_nxt; q_cur = q_nxt;
     nxt = nn; m_nxt = meta_wait(r_nn);
   }
@@ -658,7 +681,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
     } else if (P.work) {
       read = P.work[w];
     }
-    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn, nullptr, fetch_meta(P, read), false, 0ull, 0ull);
+    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn, nullptr, fetch_meta(P, read), false, Raw8{0u, 0u, 0u, 0u}, Raw8{0u, 0u, 0u, 0u});
   }
 }
 
