@@ -42,6 +42,14 @@ constexpr int CF_WAVES = 4;              // wavefronts per workgroup
 constexpr int CF_THREADS = CF_WAVES * 64;
 constexpr uint32_t GENE_INF = 0xFFFFFFFFu;
 
+// timing-only ablation switches (env SHK_ABLATE) exist only in builds made with -DSHK_ABLATION;
+// the shipped kernels carry neither the branches nor the SGPRs
+#ifdef SHK_ABLATION
+#define SHK_ABL(P, bit) ((P).ablate & (bit))
+#else
+#define SHK_ABL(P, bit) false
+#endif
+
 // how a k-mer's filter position is looked up (chosen per index at finalize time)
 enum ProbeMode {
   PM_BV_MOD = 0,   // filter word, position = hash % size (non power-of-two sizes)
@@ -181,7 +189,7 @@ __device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadM
   const uint32_t n_groups = g2 + ((m.L2 + 7) >> 3);
   w = Raw8{0u, 0u, 0u, 0u};
   q = Raw8{0u, 0u, 0u, 0u};
-  if (P.ablate & 4u) { w.d0 = 0x43414754u; w.d1 = 0x43415447u; w.shn = 8u << 4; return; }   // ablation 4: no base loads
+  if (SHK_ABL(P, 4u)) { w.d0 = 0x43414754u; w.d1 = 0x43415447u; w.shn = 8u << 4; return; }   // ablation 4: no base loads
   if (gi < n_groups) {
     const bool m2 = gi >= g2;
     const uint32_t b = (m2 ? gi - g2 : gi) << 3;
@@ -293,7 +301,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       const uint64_t canon = canonical_from_top(top, k);
       pos[j] = bf_pos<POW2>(xxh64_u64(canon), P.bf_bits, P.bf_mask);
     }
-    if (P.work_counters) {
+    if (!FAST && P.work_counters) {
 #pragma unroll
       for (int j = 0; j < U; ++j) wk_kmers += ok[j];
     }
@@ -314,7 +322,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 #pragma unroll
       for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.lsum_shift) & 31u)) & 1u;
     }
-    if (FAST && (SUM || LSUM) && !P.work_counters) {
+    if (FAST && (SUM || LSUM)) {
       bool lane_ok = false;
 #pragma unroll
       for (int j = 0; j < U; ++j) lane_ok |= ok[j];
@@ -367,12 +375,12 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 #pragma unroll
       for (int j = 0; j < U; ++j) lane_any |= hit[j];
       const bool round_any = __ballot(lane_any) != 0ull;
-      if (P.work_counters) {
+      if (!FAST && P.work_counters) {
 #pragma unroll
         for (int j = 0; j < U; ++j) wk_hits += hit[j];
       }
       if (FAST && !round_any) break;
-      if (P.ablate & 1u) break;
+      if (SHK_ABL(P, 1u)) break;
       any_hit |= round_any;
       // multi-gene lists (rare): entry r gives start/len/first gene
       bool lane_multi = false;
@@ -396,7 +404,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 #pragma unroll
         for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
       }
-      if (P.work_counters) {
+      if (!FAST && P.work_counters) {
 #pragma unroll
         for (int j = 0; j < U; ++j) wk_ids += hit[j] ? (multi[j] ? re[j] - rs[j] : 1u) : 0u;
       }
@@ -414,12 +422,12 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
         lane_any |= hit[j];
       }
       const bool round_any = __ballot(lane_any) != 0ull;
-      if (P.work_counters) {
+      if (!FAST && P.work_counters) {
 #pragma unroll
         for (int j = 0; j < U; ++j) wk_hits += hit[j];
       }
       if (FAST && !round_any) break;  // single round: nothing hit, nothing to record
-      if (P.ablate & 1u) break;       // ablation: stop after the probes
+      if (SHK_ABL(P, 1u)) break;       // ablation: stop after the probes
       any_hit |= round_any;
       // ---- hits: rank -> list entry (bloomfilter.h:90-94).  Unconditional loads
       // from safe addresses (entry 0 for non-hits) so the U chains overlap. ----
@@ -441,7 +449,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
             rs[j] = le[j].start;
             re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : P.ent[rw[j] + 1].start;
             cur[j] = le[j].gene0;
-            if (P.work_counters) wk_ids += re[j] - rs[j];
+            if (!FAST && P.work_counters) wk_ids += re[j] - rs[j];
           } else {
             rs[j] = 0; re[j] = 0; cur[j] = GENE_INF;
           }
@@ -459,7 +467,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       }
     }
   }
-  if (P.work_counters) {
+  if (!FAST && P.work_counters) {
     const uint32_t a = wave_sum_u32((uint32_t)wk_kmers), b = wave_sum_u32((uint32_t)wk_hits), c = wave_sum_u32((uint32_t)wk_ids);
     if (lane == 0) {
       atomicAdd(&P.work_counters[0], (unsigned long long)a);
@@ -473,7 +481,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
   uint32_t n_emit = 0;
   uint32_t len = 0;
-  if (any_hit && !(P.ablate & 2u)) {   // ablation 2: skip the vote
+  if (any_hit && !SHK_ABL(P, 2u)) {   // ablation 2: skip the vote
     // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49);
     // only needed for the threshold, i.e. when something hit
     len = wave_sum_u32(my_valid);
