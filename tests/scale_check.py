@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""GENCODE-scale run (BASELINE configs[2] shape): ~60 k genes / ~1.8e8 reference k-mers, 2^36-bit filter,
+"""(test infrastructure; run by hand on a GPU box: `python tests/scale_check.py`)
+GENCODE-scale run (BASELINE configs[2] shape): ~60 k genes / ~1.8e8 reference k-mers, 2^36-bit filter,
 2x150 bp pairs.  Checks (a) the index build at scale, (b) that both probe structures give identical
 results, (c) bit-exact parity with the CPU oracle on a sample, and reports kernel time."""
 import argparse, os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np
 import torch
 from shark_amd import SharkHip, synth
