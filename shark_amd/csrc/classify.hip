@@ -114,6 +114,15 @@ __device__ __forceinline__ void retire_loads(Raw8 &r)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.d0), "+v"(r.d1), "+v"(r.d2));
 }
 
+// the result/queue pointers, re-read from device memory where they are needed (scalar loads from
+// the constant cache); the empty asm stops LICM from hoisting them into loop-long SGPRs
+__device__ __forceinline__ const ClassifyOut *out_ptrs(const ClassifyParams &P)
+{
+  const ClassifyOut *o = P.out;
+  asm volatile("" : "+s"(o));
+  return o;
+}
+
 // offsets / lengths of one read (pair)
 struct ReadMeta {
   uint64_t o1, o2;
@@ -221,11 +230,12 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   if (FAST) {
     if (ns > slot_cap) {  // does not fit the LDS specialisation: general kernel
       if (lane == 0) {
-        const uint32_t q = atomicAdd(&P.counters[CTR_LONG], 1u);
-        P.long_queue[q] = (uint32_t)read;
-        atomicMax(&P.counters[CTR_MAX_SLOTS], ns);
-        atomicMax(&P.counters[CTR_MAX_BASES], P2 + L2);
-        P.count[read] = 0;
+        const ClassifyOut *O = out_ptrs(P);
+        const uint32_t q = atomicAdd(&O->counters[CTR_LONG], 1u);
+        O->long_queue[q] = (uint32_t)read;
+        atomicMax(&O->counters[CTR_MAX_SLOTS], ns);
+        atomicMax(&O->counters[CTR_MAX_BASES], P2 + L2);
+        O->count[read] = 0;
       }
       return;
     }
@@ -570,17 +580,18 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   if (lane == 0) {
     // No same-address atomics here: the association total comes from the scan
     // of `count`, the per-gene counts from gather_inline_kernel (wave-aggregated).
-    P.count[read] = n_out;
+    const ClassifyOut *O = out_ptrs(P);
+    O->count[read] = n_out;
     if (n_out > 0) {
-      uint16_t *o = P.inl + read * SHK_INLINE_IDS;
+      uint16_t *o = O->inl + read * SHK_INLINE_IDS;
 #pragma unroll
       for (int i = 0; i < SHK_INLINE_IDS; ++i)
         if ((uint32_t)i < n_out) o[i] = (uint16_t)best_id[i];
       if (n_out > SHK_INLINE_IDS) {
-        const uint32_t q = atomicAdd(&P.counters[CTR_TIE], 1u);
-        P.tie_queue[3 * q + 0] = (uint32_t)read;
-        P.tie_queue[3 * q + 1] = best_cov;
-        P.tie_queue[3 * q + 2] = best_nk;
+        const uint32_t q = atomicAdd(&O->counters[CTR_TIE], 1u);
+        O->tie_queue[3 * q + 0] = (uint32_t)read;
+        O->tie_queue[3 * q + 1] = best_cov;
+        O->tie_queue[3 * q + 2] = best_nk;
       }
     }
   }

@@ -65,8 +65,11 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   p.seq1 = (const uint8_t *)b->seq1; p.off1 = b->off1;
   p.seq2 = (const uint8_t *)b->seq2; p.off2 = b->off2;
   p.qual1 = (const uint8_t *)b->qual1; p.qual2 = (const uint8_t *)b->qual2;
-  p.count = ctx->d_count; p.inl = ctx->d_inl;
-  p.counters = ctx->d_counters; p.long_queue = ctx->d_long_queue; p.tie_queue = ctx->d_tie_queue;
+  ClassifyOut ho;
+  ho.count = ctx->d_count; ho.inl = ctx->d_inl;
+  ho.counters = ctx->d_counters; ho.long_queue = ctx->d_long_queue; ho.tie_queue = ctx->d_tie_queue;
+  SHK_HIP(ctx, hipMemcpyAsync(ctx->d_out, &ho, sizeof(ho), hipMemcpyHostToDevice, st));   // (pageable source: staged before return)
+  p.out = ctx->d_out;
   p.gene_counts = wc ? nullptr : ctx->d_gene_counts;
   p.work_counters = nullptr;
   p.ablate = getenv("SHK_ABLATE") ? (uint32_t)atoi(getenv("SHK_ABLATE")) : 0u;
@@ -233,6 +236,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   CR_HIP(hipMalloc((void **)&ix.bf64, ix.bf_words64 * sizeof(uint64_t)));
   CR_HIP(hipMemsetAsync(ix.bf64, 0, ix.bf_words64 * sizeof(uint64_t), ctx->stream));
   CR_HIP(hipMalloc((void **)&ctx->d_counters, CTR_WORDS * sizeof(uint32_t)));
+  CR_HIP(hipMalloc((void **)&ctx->d_out, sizeof(ClassifyOut)));
   CR_HIP(hipMalloc((void **)&ctx->d_gene_counts, 65536 * sizeof(unsigned long long)));
   CR_HIP(hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
   CR_HIP(hipMalloc((void **)&ctx->d_work_counters, 4 * sizeof(unsigned long long)));
@@ -252,7 +256,7 @@ void shk_destroy(shk_ctx *ctx)
   hipFree(ctx->d_seq1); hipFree(ctx->d_seq2); hipFree(ctx->d_qual1); hipFree(ctx->d_qual2);
   hipFree(ctx->d_off1); hipFree(ctx->d_off2);
   hipFree(ctx->d_count); hipFree(ctx->d_inl); hipFree(ctx->d_gene_off); hipFree(ctx->d_gene_ids);
-  hipFree(ctx->d_long_queue); hipFree(ctx->d_tie_queue); hipFree(ctx->d_counters);
+  hipFree(ctx->d_long_queue); hipFree(ctx->d_tie_queue); hipFree(ctx->d_counters); hipFree(ctx->d_out);
   hipFree(ctx->d_scan_temp); hipFree(ctx->d_scratch); hipFree(ctx->d_gene_counts); hipFree(ctx->d_work_counters);
   if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
   for (auto e : ctx->ev_start) (void)hipEventDestroy(e);

@@ -69,6 +69,17 @@ struct DeviceIndex {
   uint64_t tot_idx = 0;
 };
 
+// result / queue pointers of a classify launch.  They live in device memory behind ONE pointer so
+// that the hot loop does not pin ~14 SGPRs for values it needs once per read (the fast kernel is at
+// the 106-SGPR limit and spills wave-uniform values into VGPRs otherwise).
+struct ClassifyOut {
+  uint32_t *count;           // n : number of genes kept (exact)
+  uint16_t *inl;             // n * SHK_INLINE_IDS : first genes
+  uint32_t *counters;        // see CTR_*
+  uint32_t *long_queue;      // read indices that did not fit the fast kernel
+  uint32_t *tie_queue;       // 3 words per entry: read index, best cov, best nk
+};
+
 // ---- classify kernel parameters (passed by value) --------------------------
 struct ClassifyParams {
   // index
@@ -97,14 +108,9 @@ struct ClassifyParams {
   const uint64_t *off2;
   const uint8_t *qual1;
   const uint8_t *qual2;
-  // per-read results
-  uint32_t *count;           // n : number of genes kept (exact)
-  uint16_t *inl;             // n * SHK_INLINE_IDS : first genes
-  // queues / counters (device)
-  uint32_t *counters;        // see CTR_*
-  uint32_t *long_queue;      // read indices that did not fit the fast kernel
-  uint32_t *tie_queue;       // 3 words per entry: read index, best cov, best nk
-  unsigned long long *gene_counts;  // 65536
+  // per-read results and queues (device copy of ClassifyOut)
+  const ClassifyOut *out;
+  unsigned long long *gene_counts;  // 65536 (general kernel, EMIT mode)
   // work list for the general kernel (nullptr => all reads 0..n)
   const uint32_t *work;
   uint64_t n_work;
@@ -175,6 +181,7 @@ struct Ctx {
   uint64_t *d_scratch = nullptr;   size_t cap_scratch = 0;
   unsigned long long *d_gene_counts = nullptr;
   unsigned long long *d_work_counters = nullptr;
+  ClassifyOut *d_out = nullptr;
   uint32_t *h_counters = nullptr;  // pinned, CTR_WORDS + 2 (the scan total lands behind the counters)
 
   // host result buffers
