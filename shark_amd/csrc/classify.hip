@@ -638,22 +638,24 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
   // software pipeline over this wave's reads: the offsets are fetched two reads ahead and the
   // bases one read ahead, so their HBM latency hides under the hashing of the current read
   // (ablation: the in-place base loads cost 4.4 of 14 ms on the all-miss workload)
-  const uint64_t stride = (uint64_t)gridDim.x * G::WAVES;
-  uint64_t read = (uint64_t)blockIdx.x * G::WAVES + wave;
-  if (read >= P.n) return;
+  // (read indices fit 32 bits: shk_classify* refuses batches of 2^32-1 reads or more)
+  const uint32_t stride = gridDim.x * G::WAVES, n32 = (uint32_t)P.n;
+  uint32_t read = blockIdx.x * G::WAVES + wave;
+  if (read >= n32) return;
   ReadMeta m_cur = fetch_meta(P, read);
   Raw8 w_cur, q_cur;
   fetch_group<HASQ>(P, m_cur, (uint32_t)lane, w_cur, q_cur);
   retire_loads(w_cur);   // same reason as at the loop end
   retire_loads(q_cur);
-  uint64_t nxt = read + stride;
-  ReadMeta m_nxt = fetch_meta(P, nxt < P.n ? nxt : read);
+  // nxt / nn saturate at n32 (no wrap-around near 2^32)
+  uint32_t nxt = n32 - read > stride ? read + stride : n32;
+  ReadMeta m_nxt = fetch_meta(P, nxt < n32 ? nxt : read);
   for (;;) {
     Raw8 w_nxt = Raw8{0u, 0u, 0u, 0u}, q_nxt = Raw8{0u, 0u, 0u, 0u};
-    const bool have_nxt = nxt < P.n;
+    const bool have_nxt = nxt < n32;
     if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
-    const uint64_t nn = nxt + stride;
-    const ReadMetaRaw r_nn = fetch_meta_async(P, nn < P.n ? nn : read);   // scalar loads, clamped index
+    const uint32_t nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
+    const ReadMetaRaw r_nn = fetch_meta_async(P, nn < n32 ? nn : read);   // scalar loads, clamped index
     process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u, lsum, m_cur, true, w_cur, q_cur);
     if (!have_nxt) break;
     // The prefetched bases landed long ago.  Retire them HERE and hand the compiler plain register
