@@ -5,7 +5,7 @@
 //            bloomfilter.h:57-59                    -> ref_kmer_kernel<MODE_SET>
 //   switch_mode(1)  bloomfilter.h:112-125 (rank)    -> bf_word_popcount + scan
 //   pass 2   main.cpp:154-189 + BF::add_to_kmer bloomfilter.h:61-75
-//                                                   -> ref_kmer_kernel<MODE_KEYS> + radix sort
+//                                                   -> ref_kmer_kernel<MODE_KEYS> + radix sort (device_sort.hip)
 //   switch_mode(2)  bloomfilter.h:126-184           -> unique + CSR + list-entry kernels
 // plus the summary level, which only restates the filter.
 //
@@ -14,8 +14,6 @@
 // STARTING at position s of a record exists iff s + k <= len and characters
 // s..s+k-1 are all valid, which is the same set (kmer_utils.hpp:57-71).
 #include <hip/hip_runtime.h>
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -23,6 +21,7 @@
 #include <vector>
 
 #include "device_scan.hpp"
+#include "device_sort.hpp"
 #include "kmer_device.hpp"
 #include "shark_internal.hpp"
 
@@ -303,11 +302,16 @@ int build_index(Ctx *ctx)
     // bits needed to order keys up to and including the sentinel
     unsigned end_bit = 17;
     while (end_bit < 64 && (sentinel >> end_bit) != 0) ++end_bit;
-    size_t tmp_bytes = 0;
-    BI_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_keys_alt, (size_t)total, 0u, end_bit, st));
-    BI_HIP(hipMalloc(&d_sort_tmp, tmp_bytes ? tmp_bytes : 16));
-    BI_HIP(rocprim::radix_sort_keys(d_sort_tmp, tmp_bytes, d_keys, d_keys_alt, (size_t)total, 0u, end_bit, st));
-    const uint64_t *sorted = d_keys_alt;
+    if (total >= (1ull << 32)) { cleanup(); ctx->last_error = "reference has >= 2^32 bases"; return SHK_ERR_INDEX_TOO_LARGE; }
+    uint32_t *d_hist = nullptr;
+    uint64_t *d_sort_scan = nullptr;
+    BI_HIP(hipMalloc((void **)&d_hist, radix_sort_hist_words(total) * sizeof(uint32_t)));
+    d_sort_tmp = d_hist;   // freed by cleanup()
+    BI_HIP(hipMalloc((void **)&d_sort_scan, scan_temp_words(radix_sort_hist_words(total)) * sizeof(uint64_t)));
+    const uint64_t *sorted = radix_sort_u64(d_keys, d_keys_alt, total, end_bit, d_hist, d_sort_scan, st);
+    BI_HIP(hipStreamSynchronize(st));
+    (void)hipFree(d_sort_scan);
+    if (!sorted) { cleanup(); ctx->last_error = "radix sort launch failed"; return SHK_ERR_HIP; }
 
     BI_HIP(hipMalloc((void **)&d_flags, total * sizeof(uint32_t)));
     hipLaunchKernelGGL(unique_flags_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, total, sentinel, d_flags);
