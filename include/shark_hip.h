@@ -141,6 +141,15 @@ int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_
 int shk_gene_counts(shk_ctx *ctx, uint64_t *counts, uint32_t n);
 int shk_gene_counts_reset(shk_ctx *ctx);
 
+/* The path's one exchange step when the read stream is sharded over several GPUs of one node
+ * (one context per GPU, index replicated, reads split by batch): all-reduce (sum) of the per-gene
+ * counters of `n_ctx` contexts over RCCL (xGMI), leaving the totals in every context's device
+ * counters and, if `totals` is not NULL, copying counts[0..n) of the result to the host.  RCCL is
+ * loaded on first use (librccl.so.1); with one context and without SHK_FORCE_RCCL=1 in the
+ * environment no collective is needed and none is issued.  New: the reference is single process
+ * and has no counterpart (its per-read lines are merged by the output mutex, ReadOutput.hpp:38). */
+int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint32_t n);
+
 /* ---- measurement --------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel (classify) on the context's own
  * stream.  enable=1 starts recording one event pair per launch. */

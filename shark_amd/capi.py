@@ -48,7 +48,7 @@ EXPORTS = [
     "shk_create", "shk_destroy", "shk_strerror", "shk_last_error", "shk_ref_add", "shk_ref_finalize",
     "shk_index_info_get", "shk_index_copy_bf", "shk_index_copy_lists", "shk_classify", "shk_classify_device",
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
-    "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode",
+    "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode", "shk_gene_counts_allreduce",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def load():
     L.shk_free_pinned.restype = None; L.shk_free_pinned.argtypes = [p]
     L.shk_version.restype = C.c_char_p; L.shk_version.argtypes = []
     L.shk_probe_mode.restype = C.c_char_p; L.shk_probe_mode.argtypes = [p]
+    L.shk_gene_counts_allreduce.restype = C.c_int; L.shk_gene_counts_allreduce.argtypes = [C.POINTER(p), C.c_int, p, C.c_uint32]
     _lib = L
     return L
 
@@ -202,6 +203,14 @@ class SharkHip:
     def gene_counts(self, n=65536):
         a = np.zeros(n, dtype=np.uint64)
         self._check(self.L.shk_gene_counts(self.h, _ptr(a), n), "shk_gene_counts")
+        return a
+
+    def gene_counts_allreduce(self, others=(), n=65536):
+        """sum the per-gene counters of this context and `others` (one per GPU) over RCCL"""
+        ctxs = [self] + list(others)
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        a = np.zeros(n, dtype=np.uint64)
+        self._check(self.L.shk_gene_counts_allreduce(arr, len(ctxs), _ptr(a), n), "shk_gene_counts_allreduce")
         return a
 
     def gene_counts_reset(self):

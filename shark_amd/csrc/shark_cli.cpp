@@ -60,6 +60,7 @@ const char *USAGE_MESSAGE =
     "MI355X build only:\n"
     "          --gpus N                      number of GPUs to shard the reads over (default:1)\n"
     "          --batch N                     reads per device batch (default:1048576)\n"
+    "          --gene-counts FILE            write <gene> <assigned reads> per gene (summed over the GPUs with RCCL)\n"
     "      -t N also sets the number of host threads that parse FASTQ / format output (default: up to 16)\n";
 
 struct Options {
@@ -73,6 +74,7 @@ struct Options {
   int nThreads = 1;
   int gpus = 1;
   uint64_t batch = 1u << 20;
+  std::string gene_counts_path;
 };
 
 Options parse_arguments(int argc, char **argv)
@@ -87,7 +89,8 @@ Options parse_arguments(int argc, char **argv)
       {"bf-size", required_argument, NULL, 'b'},   {"min-base-quality", required_argument, NULL, 'q'},
       {"single", no_argument, NULL, 's'},          {"verbose", no_argument, NULL, 'v'},
       {"help", no_argument, NULL, 'h'},            {"gpus", required_argument, NULL, 1000},
-      {"batch", required_argument, NULL, 1001},    {NULL, 0, NULL, 0}};
+      {"batch", required_argument, NULL, 1001},    {"gene-counts", required_argument, NULL, 1002},
+      {NULL, 0, NULL, 0}};
   for (int ch; (ch = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
     std::istringstream arg(optarg != NULL ? optarg : "");
     switch (ch) {
@@ -139,6 +142,7 @@ Options parse_arguments(int argc, char **argv)
     case 'h': std::cerr << USAGE_MESSAGE; exit(EXIT_SUCCESS);
     case 1000: arg >> opt.gpus; if (opt.gpus < 1) opt.gpus = 1; break;
     case 1001: arg >> opt.batch; if (opt.batch < 1) opt.batch = 1; break;
+    case 1002: arg >> opt.gene_counts_path; break;
     default:
       std::cerr << "shark : unknown argument" << std::endl;
       std::cerr << "\n" << USAGE_MESSAGE;
@@ -605,6 +609,30 @@ int main(int argc, char *argv[])
     }
   }
   pelapsed("Sample completed");
+
+  // per-gene assigned-read counts: the one exchange step of the sharded run (RCCL all-reduce over xGMI)
+  if (opt.gene_counts_path != "" || (opt.verbose && n_gpus > 1)) {
+    std::vector<uint64_t> totals(legend_ID.size() ? legend_ID.size() : 1, 0);
+    const uint32_t ng = (uint32_t)std::min<size_t>(legend_ID.size(), 65536);
+    const int rc = shk_gene_counts_allreduce(ctxs.data(), n_gpus, totals.data(), ng);
+    if (rc != SHK_OK) {
+      std::cerr << "shark: gene count reduction failed: " << shk_strerror(rc) << " " << shk_last_error(ctxs[0]) << std::endl;
+      return EXIT_FAILURE;
+    }
+    if (opt.gene_counts_path != "") {
+      FILE *gc = fopen(opt.gene_counts_path.c_str(), "w");
+      if (gc) {
+        for (uint32_t g = 0; g < ng; ++g)
+          if (totals[g]) fprintf(gc, "%s %llu\n", legend_ID[g].c_str(), (unsigned long long)totals[g]);
+        fclose(gc);
+      }
+    }
+    if (opt.verbose) {
+      uint64_t sum = 0;
+      for (uint32_t g = 0; g < ng; ++g) sum += totals[g];
+      std::cerr << "[shark/counts] " << sum << " associations over " << n_gpus << " GPU(s)" << std::endl;
+    }
+  }
 
   for (auto *ctx : ctxs) shk_destroy(ctx);
   pelapsed("Association done");

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <new>
 
@@ -440,6 +441,76 @@ int shk_gene_counts_reset(shk_ctx *ctx)
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
   SHK_HIP(ctx, hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
   SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SHK_OK;
+}
+
+// ---- RCCL, loaded on first use so that single-GPU users never pay for (or conflict over) it ----
+namespace {
+typedef void *rccl_comm_t;
+struct RcclApi {
+  void *lib = nullptr;
+  int (*CommInitAll)(rccl_comm_t *, int, const int *) = nullptr;
+  int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  bool ok = false;
+};
+RcclApi &rccl()
+{
+  static RcclApi api;
+  if (!api.lib) {
+    api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) {
+      api.CommInitAll = (int (*)(rccl_comm_t *, int, const int *))dlsym(api.lib, "ncclCommInitAll");
+      api.CommDestroy = (int (*)(rccl_comm_t))dlsym(api.lib, "ncclCommDestroy");
+      api.AllReduce = (int (*)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+      api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+      api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+    }
+  }
+  return api;
+}
+}  // namespace
+
+int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint32_t n)
+{
+  if (!ctxs || n_ctx < 1 || n > 65536) return SHK_ERR_ARG;
+  for (int i = 0; i < n_ctx; ++i)
+    if (!ctxs[i]) return SHK_ERR_ARG;
+  shk_ctx *c0 = ctxs[0];
+  for (int i = 0; i < n_ctx; ++i) {
+    SHK_HIP(ctxs[i], hipSetDevice(ctxs[i]->prm.device));
+    SHK_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+  }
+  const char *force = getenv("SHK_FORCE_RCCL");
+  if (n_ctx > 1 || (force && force[0] == '1')) {
+    RcclApi &api = rccl();
+    if (!api.ok) { c0->last_error = "librccl.so.1 could not be loaded"; return SHK_ERR_HIP; }
+    std::vector<int> devs((size_t)n_ctx);
+    for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->prm.device;
+    std::vector<rccl_comm_t> comms((size_t)n_ctx, nullptr);
+    if (api.CommInitAll(comms.data(), n_ctx, devs.data()) != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
+    int rc = api.GroupStart();
+    for (int i = 0; i < n_ctx && rc == 0; ++i) {
+      (void)hipSetDevice(devs[(size_t)i]);
+      // ncclUint64 = 5, ncclSum = 0; in place on every GPU's 65 536 x 8 B counter block
+      rc = api.AllReduce(ctxs[i]->d_gene_counts, ctxs[i]->d_gene_counts, 65536, 5, 0, comms[(size_t)i], ctxs[i]->stream);
+    }
+    if (rc == 0) rc = api.GroupEnd();
+    for (int i = 0; i < n_ctx; ++i) {
+      (void)hipSetDevice(devs[(size_t)i]);
+      (void)hipStreamSynchronize(ctxs[i]->stream);
+      (void)api.CommDestroy(comms[(size_t)i]);
+    }
+    if (rc != 0) { c0->last_error = "ncclAllReduce failed"; return SHK_ERR_HIP; }
+  }
+  if (totals) {
+    SHK_HIP(c0, hipSetDevice(c0->prm.device));
+    SHK_HIP(c0, hipMemcpy(totals, c0->d_gene_counts, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
   return SHK_OK;
 }
 

@@ -454,3 +454,33 @@ def test_full_size_properties_config2():
     m = 3_333_333
     g6, _ = run(b["seq1"], b["off1"], b["seq2"], b["off2"], m=m)
     assert np.array_equal(g6, goff[:m + 1])
+
+
+def test_gene_counts_allreduce_over_rccl(oracle, tmp_path, monkeypatch):
+    """the sharded run's one exchange step: RCCL all-reduce of the per-gene counters (forced on with one GPU),
+    through the ABI and through `shark --gene-counts`"""
+    rng = np.random.default_rng(3)
+    genes = synth.make_genes(rng, 9, 400, 1200)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 22)
+    b = synth.make_reads(rng, genes, 3000, read_len=100, paired=True, on_target=0.8)
+    goff, gids = _compare_classify(o, h, b)
+    want = np.bincount(gids, minlength=16)[:16].astype(np.uint64)
+    monkeypatch.setenv("SHK_FORCE_RCCL", "1")
+    assert np.array_equal(h.gene_counts_allreduce(n=16), want)
+    assert np.array_equal(h.gene_counts(16), want)          # in place on the device, one rank: unchanged
+    # CLI
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">g%d\n%s\n" % (i, bytes(g).decode()) for i, g in enumerate(genes)))
+    f1, f2 = tmp_path / "a.fq", tmp_path / "b.fq"
+    for f, seq, off, tag in ((f1, b["seq1"], b["off1"], 1), (f2, b["seq2"], b["off2"], 2)):
+        with open(f, "wb") as fh:
+            for i in range(len(off) - 1):
+                s = bytes(seq[int(off[i]):int(off[i + 1])])
+                fh.write(b"@r%d/%d\n%s\n+\n%s\n" % (i, tag, s, b"I" * len(s)))
+    gc = tmp_path / "counts.txt"
+    r = _run_shark(["-r", str(fa), "-1", str(f1), "-2", str(f2), "-o", str(tmp_path / "o1"), "-p", str(tmp_path / "o2"),
+                    "--gene-counts", str(gc), "-v"], str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    got = dict(line.split() for line in gc.read_text().splitlines())
+    assert {k: int(v) for k, v in got.items()} == {"g%d" % g: int(c) for g, c in enumerate(want) if c}
+    assert b"[shark/counts] %d associations" % int(want.sum()) in r.stderr
