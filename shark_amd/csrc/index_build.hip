@@ -333,32 +333,11 @@ int build_index(Ctx *ctx)
   BI_HIP(hipGetLastError());
   ix.tot_idx = tot_idx;
 
-  // ---- summary level (result preserving; DESIGN.md 2) -------------------------
-  // a clear summary bit proves 2^shift filter bits clear.  Use it when it can
-  // live in L2 (<= 2^24 bits) and passes <= 5 % of random probes, else when it
-  // fits the Infinity Cache (<= 2^30 bits) and passes <= 50 %; otherwise not.
-  ix.sum_shift = 0;
-  if (ix.pow2 && ix.bf_bits >= (1ull << 12) && n_set > 0 && !getenv("SHK_NO_SUMMARY")) {
-    auto pass_rate = [&](uint32_t sh) { return 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits); };
-    uint32_t lg = 0;
-    while ((1ull << lg) < ix.bf_bits) ++lg;
-    const uint32_t sh_l2 = std::max<uint32_t>(6, lg > 24 ? lg - 24 : 6);
-    const uint32_t sh_ic = std::max<uint32_t>(6, lg > 30 ? lg - 30 : 6);
-    if (sh_l2 < lg && pass_rate(sh_l2) <= 0.05) ix.sum_shift = sh_l2;
-    else if (sh_ic < lg && pass_rate(sh_ic) <= 0.5) ix.sum_shift = sh_ic;
-  }
-  if (ix.sum_shift) {
-    ix.sum_bits = ix.bf_bits >> ix.sum_shift;
-    const uint64_t sw = (ix.sum_bits + 31) / 32 + 2;
-    BI_HIP(hipMalloc((void **)&ix.sum32, sw * sizeof(uint32_t)));
-    BI_HIP(hipMemsetAsync(ix.sum32, 0, sw * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(bf_summary_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words, ix.sum_shift, ix.sum32);
-    BI_HIP(hipGetLastError());
-  }
   BI_HIP(hipStreamSynchronize(st));
 
   // ---- position table: exact sparse encoding of the set bits -----
   ix.tab_lg = 0;
+  uint64_t table_bytes = 0;
   const char *force = getenv("SHK_PROBE");   // "bitvector" disables the table (tests exercise both paths)
   if (ix.pow2 && n_set > 0 && !(force && force[0] == 'b')) {
     uint32_t lgB = 0;
@@ -397,14 +376,50 @@ int build_index(Ctx *ctx)
             ix.lsum_shift = sh;
           }
         }
-        // a table that stays in L2 needs no summary in front of it
-        ix.tab_with_summary = ix.sum_shift != 0 && slots * sizeof(uint64_t) > (4ull << 20);
+        table_bytes = slots * sizeof(uint64_t);
       } else {
         (void)hipFree(ix.tab);   // displacement overflow: keep the bit-vector path
         ix.tab = nullptr;
       }
     }
   }
+  // ---- summary level (result preserving; DESIGN.md 2) -------------------------
+  // A clear summary bit proves 2^shift filter bits clear.  A summary probe that misses L2 is itself
+  // a memory-side request, and the kernel is bound by the RATE of such requests on large indices
+  // (~54 G/s measured, whether the Infinity Cache or HBM serves them), so:
+  //  * in front of the position table only an L2-sized summary (<= 2^24 bits) that passes <= 30 %
+  //    of random probes is used, and only when neither the LDS summary nor a cache-resident table
+  //    makes it pointless (the Infinity-Cache-sized summary made the 60 000-gene index 23 % slower);
+  //  * in front of plain filter words (no table): L2-sized at <= 5 %, else Infinity-Cache-sized
+  //    (<= 2^30 bits) at <= 50 %.
+  ix.sum_shift = 0;
+  ix.tab_with_summary = false;
+  if (ix.pow2 && ix.bf_bits >= (1ull << 12) && n_set > 0 && !getenv("SHK_NO_SUMMARY")) {
+    auto pass_rate = [&](uint32_t sh) { return 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits); };
+    uint32_t lg = 0;
+    while ((1ull << lg) < ix.bf_bits) ++lg;
+    const uint32_t sh_l2 = std::max<uint32_t>(6, lg > 24 ? lg - 24 : 6);
+    const uint32_t sh_ic = std::max<uint32_t>(6, lg > 30 ? lg - 30 : 6);
+    if (ix.tab_lg) {
+      if (!ix.lsum_shift && table_bytes > (4ull << 20) && sh_l2 < lg && pass_rate(sh_l2) <= 0.30) {
+        ix.sum_shift = sh_l2;
+        ix.tab_with_summary = true;
+      }
+    } else {
+      if (sh_l2 < lg && pass_rate(sh_l2) <= 0.05) ix.sum_shift = sh_l2;
+      else if (sh_ic < lg && pass_rate(sh_ic) <= 0.5) ix.sum_shift = sh_ic;
+    }
+  }
+  if (ix.sum_shift) {
+    ix.sum_bits = ix.bf_bits >> ix.sum_shift;
+    const uint64_t sw = (ix.sum_bits + 31) / 32 + 2;
+    BI_HIP(hipMalloc((void **)&ix.sum32, sw * sizeof(uint32_t)));
+    BI_HIP(hipMemsetAsync(ix.sum32, 0, sw * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(bf_summary_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words, ix.sum_shift, ix.sum32);
+    BI_HIP(hipGetLastError());
+  }
+  BI_HIP(hipStreamSynchronize(st));
+
   cleanup();
 #undef BI_HIP
   return SHK_OK;

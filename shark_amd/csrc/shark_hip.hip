@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <cstring>
 #include <new>
 
@@ -492,7 +493,18 @@ int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint3
     std::vector<int> devs((size_t)n_ctx);
     for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->prm.device;
     std::vector<rccl_comm_t> comms((size_t)n_ctx, nullptr);
-    if (api.CommInitAll(comms.data(), n_ctx, devs.data()) != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
+    // RCCL may print a version banner on stdout when it initialises; stdout is the ssv stream of
+    // the CLI (ReadOutput.hpp:43), so anything RCCL prints during init is sent to stderr instead
+    fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) (void)dup2(2, 1);
+    const int init_rc = api.CommInitAll(comms.data(), n_ctx, devs.data());
+    if (saved_stdout >= 0) {
+      fflush(stdout);
+      (void)dup2(saved_stdout, 1);
+      close(saved_stdout);
+    }
+    if (init_rc != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
     int rc = api.GroupStart();
     for (int i = 0; i < n_ctx && rc == 0; ++i) {
       (void)hipSetDevice(devs[(size_t)i]);

@@ -484,3 +484,6 @@ def test_gene_counts_allreduce_over_rccl(oracle, tmp_path, monkeypatch):
     got = dict(line.split() for line in gc.read_text().splitlines())
     assert {k: int(v) for k, v in got.items()} == {"g%d" % g: int(c) for g, c in enumerate(want) if c}
     assert b"[shark/counts] %d associations" % int(want.sum()) in r.stderr
+    # stdout stays pure ssv even if RCCL prints a banner while it initialises
+    lines = r.stdout.splitlines()
+    assert len(lines) == int(want.sum()) and all(len(x.split()) == 2 and x.startswith(b"r") for x in lines)
