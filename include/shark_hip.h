@@ -14,6 +14,11 @@
  *
  * There is NO CPU fallback: without a HIP device every call that computes
  * fails with SHK_ERR_HIP / SHK_ERR_NO_DEVICE.
+ *
+ * Threading: a context serialises nothing by itself -- use one context per
+ * host thread (and per GPU); different contexts may be used concurrently.  The
+ * reference's ReadAnalyzer is const over a frozen index (ReadAnalyzer.hpp:39,
+ * main.cpp:193); here every context owns a replica of that index.
  */
 #ifndef SHARK_HIP_H
 #define SHARK_HIP_H

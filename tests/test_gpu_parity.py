@@ -487,3 +487,28 @@ def test_gene_counts_allreduce_over_rccl(oracle, tmp_path, monkeypatch):
     # stdout stays pure ssv even if RCCL prints a banner while it initialises
     lines = r.stdout.splitlines()
     assert len(lines) == int(want.sum()) and all(len(x.split()) == 2 and x.startswith(b"r") for x in lines)
+
+
+@pytest.mark.parametrize("read_len,paired,q", [(60, True, 0), (100, True, 20), (125, True, 0), (170, True, 0), (200, True, 30),
+                                               (250, True, 0), (300, False, 0), (520, False, 20), (64, False, 0)])
+def test_every_kernel_specialisation(oracle, read_len, paired, q):
+    """fixed-length batches that select each unroll U in {2,3,4,5,6,8} of the fast kernel (paired and single-end,
+    with and without the quality mask); lengths just above a specialisation's capacity go to the general kernel"""
+    rng = np.random.default_rng(1000 + read_len)
+    genes = synth.make_genes(rng, 12, 800, 3000, share_every=4)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 24, min_quality=q)
+    b = synth.make_reads(rng, genes, 2500, read_len=read_len, paired=paired, on_target=0.7, qual=q > 0, n_rate=0.005)
+    goff, _ = _compare_classify(o, h, b)
+    assert goff[-1] > 20      # (a strict quality mask leaves few reads above the confidence threshold)
+    # one read far beyond the specialisation rides along: it must take the general kernel, the rest the fast one
+    long_read = bytes(genes[0][:700])
+    m1 = [bytes(b["seq1"][int(b["off1"][i]):int(b["off1"][i + 1])]) for i in range(300)] + [long_read]
+    q1 = None if q == 0 else [bytes(b["qual1"][int(b["off1"][i]):int(b["off1"][i + 1])]) for i in range(300)] + [b"I" * 700]
+    if paired:
+        m2 = [bytes(b["seq2"][int(b["off2"][i]):int(b["off2"][i + 1])]) for i in range(300)] + [long_read[::-1]]
+        q2 = None if q == 0 else [bytes(b["qual2"][int(b["off2"][i]):int(b["off2"][i + 1])]) for i in range(300)] + [b"I" * 700]
+        bb = synth.batch_from_lists(m1, m2, q1, q2)
+    else:
+        bb = synth.batch_from_lists(m1, None, q1, None)
+    _compare_classify(o, h, bb)
+    assert h.timing()["last_n_long"] == 1
