@@ -253,20 +253,38 @@ class BatchSplitter {
     }
     if (!fast_ && !done_) {
       auto ts = std::chrono::steady_clock::now();
-      shk::FastxRecord a, c;
-      while (b->seq1.size() < maxnum_) {
-        if (r1_.read(a) < 0) break;
-        if (paired_ && r2_->read(c) < 0) break;
-        // the reference builds std::string from C strings (FastqSplitter.hpp:55,63): stop at NUL
-        b->id1.push(a.name.c_str(), strlen(a.name.c_str()));
-        b->seq1.push(a.seq.data(), strnlen(a.seq.data(), a.seq.size()));
-        b->qual1.push(a.qual.data(), strnlen(a.qual.data(), a.qual.size()));
-        if (paired_) {
-          b->id2.push(c.name.c_str(), strlen(c.name.c_str()));
-          b->seq2.push(c.seq.data(), strnlen(c.seq.data(), c.seq.size()));
-          b->qual2.push(c.qual.data(), strnlen(c.qual.data(), c.qual.size()));
+      // the two mate files are parsed (and, for .gz, inflated) by two threads at once; the pair
+      // stream ends with the shorter file, as in the reference's read loop (FastqSplitter.hpp:60)
+      const size_t have = b->seq1.size(), want = (size_t)maxnum_ - have;
+      auto fill_serial = [want](shk::FastxReader &r, Strings &id, Strings &seq, Strings &qual) {
+        shk::FastxRecord a;
+        size_t got = 0;
+        while (got < want && r.read(a) >= 0) {
+          // the reference builds std::string from C strings (FastqSplitter.hpp:55,63): stop at NUL
+          id.push(a.name.c_str(), strlen(a.name.c_str()));
+          seq.push(a.seq.data(), strnlen(a.seq.data(), a.seq.size()));
+          qual.push(a.qual.data(), strnlen(a.qual.data(), a.qual.size()));
+          ++got;
         }
+        return got;
+      };
+      size_t got1 = 0, got2 = 0;
+      if (paired_) {
+        std::thread t2([&] { got2 = fill_serial(*r2_, b->id2, b->seq2, b->qual2); });
+        got1 = fill_serial(r1_, b->id1, b->seq1, b->qual1);
+        t2.join();
+        const size_t keep = have + std::min(got1, got2);
+        if (got1 != got2) {   // one file ended: drop the unpaired surplus, nothing more will be read
+          for (Strings *x : {&b->id1, &b->seq1, &b->qual1, &b->id2, &b->seq2, &b->qual2}) {
+            x->off.resize(keep + 1);
+            x->bytes.resize(x->off[keep]);
+          }
+          done_ = true;
+        }
+      } else {
+        got1 = fill_serial(r1_, b->id1, b->seq1, b->qual1);
       }
+      if (got1 < want) done_ = true;
       t_serial += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
     }
     n_reads_ += b->seq1.size();
