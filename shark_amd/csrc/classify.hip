@@ -60,13 +60,22 @@ enum ProbeMode {
   PM_LDS_TAB = 5   // 2^19-bit summary held in LDS, then position table (small indices)
 };
 
-// per-wave storage sizes (in 64-bit words) for a slot capacity S
-__host__ __device__ constexpr uint32_t code_words_for(uint32_t S) { return (S + 91 + 31) / 32 + 1; }
-__host__ __device__ constexpr uint32_t vbit_words_for(uint32_t S) { return (S + 91 + 63) / 64 + 2; }
-
+// Per-wave staging area of a read (LDS in the fast kernel, a global scratch slice in the general
+// kernel).  The read's bases live at PACKED positions: mate 1 at [0, L1), mate 2 at [P2, P2+L2)
+// with P2 = L1 rounded up to 8.  A k-mer SLOT is a packed position pp: slot pp is the k-mer that
+// starts at packed position pp; it exists when pp < nk1 or 0 <= pp-P2 < nk2.  Two streams of 2-bit
+// codes are kept so that both orientations of a k-mer are plain right-shift extractions
+// (v_alignbit_b32) -- the per-k-mer bit reversal of the first versions is gone:
+//   fw : base at position p  -> bits [2(p&15), +2) of dword p>>4
+//   rv : base at position p  -> same rule applied to the mirrored position rcap-1-p
+// A window of k bases read from `rv` at rcap-k-pp is the k-mer MSB-first (kmer_utils.hpp:67-69);
+// the window read from `fw` at pp holds the bases in reverse order, so its complement is the
+// reverse complement (kmer_utils.hpp:47-55).
 struct WaveStore {
-  uint64_t *codes;      // 2-bit codes, 32 bases per word, first base in bits 63:62
-  uint64_t *vbits;      // validity, 64 bases per word, LSB first
+  uint32_t *fw;         // forward code stream
+  uint32_t *rv;         // mirrored code stream
+  uint32_t rcap;        // mirror length in bases (= stage_cap_bases(S))
+  uint64_t *vbits;      // validity, 64 packed positions per word, LSB first
   uint32_t *rec_start;  // per slot: cursor into csr_ids
   uint32_t *rec_end;    // per slot: end of its list
   uint32_t *cur;        // per slot: gene at the cursor, GENE_INF when exhausted / no hit
@@ -141,14 +150,16 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t x)
 __device__ __forceinline__ ReadMeta fetch_meta(const ClassifyParams &P, uint64_t read_in)
 {
   const uint64_t read = uniform64(read_in);
+  // (the loads may be vector loads; readfirstlane makes the VALUES scalar, so that the per-read
+  // geometry derived from them is computed on the scalar unit in the callers' loops)
   ReadMeta m;
-  m.o1 = P.off1[read];
-  m.L1 = (uint32_t)(P.off1[read + 1] - m.o1);
+  m.o1 = uniform64(P.off1[read]);
+  m.L1 = __builtin_amdgcn_readfirstlane((uint32_t)(P.off1[read + 1] - m.o1));
   m.o2 = 0;
   m.L2 = 0;
   if (P.seq2) {
-    m.o2 = P.off2[read];
-    m.L2 = (uint32_t)(P.off2[read + 1] - m.o2);
+    m.o2 = uniform64(P.off2[read]);
+    m.L2 = __builtin_amdgcn_readfirstlane((uint32_t)(P.off2[read + 1] - m.o2));
   }
   return m;
 }
@@ -194,7 +205,7 @@ __device__ __forceinline__ ReadMeta meta_wait(ReadMetaRaw r)
 template <bool HASQ>
 __device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadMeta &m, uint32_t gi, Raw8 &w, Raw8 &q)
 {
-  const uint32_t g2 = (((m.L1 + 31) >> 5) << 5) >> 3;
+  const uint32_t g2 = (m.L1 + 7) >> 3;
   const uint32_t n_groups = g2 + ((m.L2 + 7) >> 3);
   w = Raw8{0u, 0u, 0u, 0u};
   q = Raw8{0u, 0u, 0u, 0u};
@@ -219,13 +230,15 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   constexpr bool SUM = MODE == PM_BV_SUM || MODE == PM_TAB_SUM;
   constexpr bool LSUM = MODE == PM_LDS_TAB;
   constexpr bool TAB = MODE == PM_TAB || MODE == PM_TAB_SUM || MODE == PM_LDS_TAB;
+  // LAZY: with the summary in LDS a probe of a non-existent slot costs no memory traffic, so the
+  // slot's existence and validity are only evaluated for the (few) probes that match in the table
+  constexpr bool LAZY = FAST && LSUM;
   const uint32_t k = P.k;
-  const uint64_t o1 = meta.o1, o2 = meta.o2;
   const uint32_t L1 = meta.L1, L2 = meta.L2;
   const uint32_t nk1 = L1 >= k ? L1 - k + 1 : 0;
   const uint32_t nk2 = L2 >= k ? L2 - k + 1 : 0;
-  const uint32_t ns = nk1 + nk2;
-  const uint32_t P2 = ((L1 + 31) >> 5) << 5;  // packed position of mate 2's first base
+  const uint32_t P2 = (L1 + 7u) & ~7u;            // packed position of mate 2's first base
+  const uint32_t ns = nk2 ? P2 + nk2 : nk1;       // slots are the packed positions [0, ns)
 
   if (FAST) {
     if (ns > slot_cap) {  // does not fit the LDS specialisation: general kernel
@@ -234,36 +247,39 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
         const uint32_t q = atomicAdd(&O->counters[CTR_LONG], 1u);
         O->long_queue[q] = (uint32_t)read;
         atomicMax(&O->counters[CTR_MAX_SLOTS], ns);
-        atomicMax(&O->counters[CTR_MAX_BASES], P2 + L2);
         O->count[read] = 0;
       }
       return;
     }
   }
 
-  // ---- stage the read: 8 bases per lane -> packed codes + validity in LDS ----
+  // ---- stage the read: 8 bases per lane -> the two code streams + validity ----
   const uint32_t g2 = P2 >> 3;
   const uint32_t n_groups = g2 + ((L2 + 7) >> 3);
+  const uint32_t rv_last = (st.rcap >> 3) - 1u;   // 16-bit chunk of `rv` that mirrors chunk 0 of `fw`
   uint32_t my_valid = 0;
-  // classify + pack the 8 bases of group gi (already in registers) and write them to LDS
+  // classify + pack the 8 bases of group gi (already in registers) and write them out
   auto stage_group = [&](const uint32_t gi, const uint64_t w, const uint64_t q) {
     const bool m2 = gi >= g2;
     const uint32_t b = (m2 ? gi - g2 : gi) << 3;
     const uint32_t L = m2 ? L2 : L1;
-    uint32_t code16 = 0, valid8 = 0;
+    uint32_t msb16 = 0, valid8 = 0;
     if (b < L) {
       const uint32_t rem = L - b;
       uint32_t c_lo, c_hi, i_lo, i_hi;
       classify4((uint32_t)w, c_lo, i_lo);
       classify4((uint32_t)(w >> 32), c_hi, i_hi);
-      code16 = (pack4(c_lo) << 8) | pack4(c_hi);
+      msb16 = (pack4(c_lo) << 8) | pack4(c_hi);           // first base in bits 15:14
       uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4);
       if (HASQ) inv8 |= gather4(qmask4((uint32_t)q, P.mq)) | (gather4(qmask4((uint32_t)(q >> 32), P.mq)) << 4);
       if (rem < 8) inv8 |= 0xFFu << rem;
       valid8 = ~inv8 & 0xFFu;
     }
-    // 16-bit chunk q4 of word W, chunk 0 most significant (little-endian LDS)
-    reinterpret_cast<uint16_t *>(st.codes)[((gi >> 2) << 2) + (3u - (gi & 3u))] = (uint16_t)code16;
+    // the same 8 codes with the first base in the LOW bits: reverse the bits, swap each pair back
+    uint32_t lsb = __builtin_bitreverse32(msb16);         // lands in the high half
+    lsb = ((lsb >> 1) & 0x55555555u) | ((lsb & 0x55555555u) << 1);
+    reinterpret_cast<uint16_t *>(st.fw)[gi] = (uint16_t)(lsb >> 16);
+    reinterpret_cast<uint16_t *>(st.rv)[rv_last - gi] = (uint16_t)msb16;
     reinterpret_cast<uint8_t *>(st.vbits)[gi] = (uint8_t)valid8;
     my_valid += __builtin_popcount(valid8);
   };
@@ -283,7 +299,17 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // ---- probe every k-mer slot ----------------------------------------------
-  const uint64_t kmask = (1ull << k) - 1ull;
+  const uint64_t kmask = (1ull << k) - 1ull;          // k validity bits
+  const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
+  // slot pp exists and all its k characters are valid (equivalent to the reference's roll/restart
+  // walk, kmer_utils.hpp:57-71 + ReadAnalyzer.hpp:51-77)
+  auto slot_ok = [&](const uint32_t pp) -> bool {
+    const bool act = (pp < nk1) | ((pp - P2) < nk2);
+    const uint32_t V = pp >> 6, vs = pp & 63u;
+    const uint64_t v0 = st.vbits[V], v1 = st.vbits[V + 1];
+    const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+    return act & ((win & kmask) == kmask);
+  };
   bool any_hit = false;
   unsigned long long wk_kmers = 0, wk_hits = 0, wk_ids = 0;
   // slot records of the (single) round of the fast kernel live in registers
@@ -297,19 +323,23 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     bool ok[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const uint32_t t = base + lane + 64 * j;
-      const bool act = t < ns;
-      const bool m2 = t >= nk1;
-      const uint32_t pp = act ? (m2 ? t - nk1 + P2 : t) : 0u;
-      const uint32_t W = pp >> 5, sh = (pp & 31u) << 1;
-      const uint64_t w0 = st.codes[W], w1 = st.codes[W + 1];
-      const uint64_t top = (w0 << sh) | ((w1 >> 1) >> (63u - sh));
-      const uint32_t V = pp >> 6, vs = pp & 63u;
-      const uint64_t v0 = st.vbits[V], v1 = st.vbits[V + 1];
-      const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
-      ok[j] = act && ((win & kmask) == kmask);
-      const uint64_t canon = canonical_from_top(top, k);
-      pos[j] = bf_pos<POW2>(xxh64_u64(canon), P.bf_bits, P.bf_mask);
+      // fast kernel: one round, pp = lane + 64 j for every read, so the addresses and shift
+      // amounts below are loop invariant and the 64 j become instruction offsets
+      const uint32_t t = (FAST ? 0u : base) + (uint32_t)lane + 64u * j;
+      const uint32_t pp = FAST ? t : (t < ns ? t : 0u);
+      const uint32_t *f = st.fw + (pp >> 4);
+      const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+      const uint32_t q0 = st.rcap - k - pp;
+      const uint32_t *r = st.rv + (q0 >> 4);
+      const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+      const uint32_t sf = (pp & 15u) << 1, sr = (q0 & 15u) << 1;
+      const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
+      const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
+      const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+      const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
+      // (LDS-summary mode keeps the raw hash: every use below masks the bits it needs)
+      pos[j] = LAZY ? xxh64_u64(canon) : bf_pos<POW2>(xxh64_u64(canon), P.bf_bits, P.bf_mask);
+      ok[j] = LAZY ? true : ((FAST || t < ns) && slot_ok(pp));
     }
     if (!FAST && P.work_counters) {
 #pragma unroll
@@ -324,15 +354,25 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 #pragma unroll
       for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
     }
+    uint32_t okm[U];   // LDS-summary mode: all ones where the summary bit is set, else 0
     if (LSUM) {
-      // LDS-resident summary: same proof, no memory-system traffic for a miss
-      uint32_t sw[U];
+      // LDS-resident summary (2^LDS_SUM_LOG2 bits, bit i = OR of filter bits [i << lsum_shift, +2^lsum_shift)):
+      // same proof, no memory-system traffic for a miss.  lsum_shift < 32 (index_build.hip).
+      uint32_t si[U], sw[U];
 #pragma unroll
-      for (int j = 0; j < U; ++j) sw[j] = ok[j] ? lsum[(uint32_t)(pos[j] >> P.lsum_shift) >> 5] : 0u;
+      for (int j = 0; j < U; ++j) {
+        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low 18 bits = summary index
+        sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (LDS_SUM_BITS / 8 - 4)));
+      }
+      uint32_t any = 0;
 #pragma unroll
-      for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.lsum_shift) & 31u)) & 1u;
-    }
-    if (FAST && (SUM || LSUM)) {
+      for (int j = 0; j < U; ++j) {
+        okm[j] = (uint32_t)__builtin_amdgcn_sbfe((int)sw[j], si[j], 1u);   // v_bfe_i32: bit (si & 31), sign extended
+        ok[j] = okm[j] != 0u;
+        any |= okm[j];
+      }
+      if (!__ballot(any != 0u)) break;   // every probe of this read is proven clear
+    } else if (FAST && SUM) {
       bool lane_ok = false;
 #pragma unroll
       for (int j = 0; j < U; ++j) lane_ok |= ok[j];
@@ -342,39 +382,50 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     bool lane_any = false;
     if (TAB) {
       // ---- position table: one 16-byte bucket answers membership AND the list ----
+      // slot = tag(24) | valid | displacement(6) in the high word, multi(1) | payload(31) in the low
+      // word, so membership is ONE compare per slot and nothing else is decoded unless it matched
       const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
-      const uint64_t bmask = (1ull << P.tab_lg) - 1ull;
+      const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;   // tab_lg <= 31; bucket = pos & bmask
+      const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
+      const uint32_t spare = 1u << P.tab_lg;                                    // one bucket past the table, always empty
+      auto want_of = [&](const int j) -> uint32_t {                              // tag, valid, displacement 0
+        const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
+        return (tag << 8) | 0x80u;
+      };
       uint4 bk[U];
 #pragma unroll
-      for (int j = 0; j < U; ++j) bk[j] = tab16[ok[j] ? (pos[j] & bmask) : 0ull];
-      uint32_t payload[U];
-      bool multi[U], more[U];
+      for (int j = 0; j < U; ++j) {
+        // probes that are already proven clear read the spare bucket behind the table: it is empty,
+        // so they neither match nor continue, and nothing below has to look at ok[j] again
+        const uint32_t b = (uint32_t)pos[j] & bmask;
+        bk[j] = tab16[LSUM ? ((b & okm[j]) | (spare & ~okm[j])) : (ok[j] ? b : spare)];
+      }
+      bool more[U];
       bool lane_more = false;
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t want = ((uint32_t)(pos[j] >> P.tab_lg) << 8) | 0x80u;   // tag, valid, displacement 0
-        const bool m0 = (bk[j].y & ~0x40u) == want, m1 = (bk[j].w & ~0x40u) == want;
-        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);                   // valid bit lives in the high word
-        hit[j] = ok[j] & (m0 | m1);
-        payload[j] = m0 ? bk[j].x : bk[j].z;
-        multi[j] = ((m0 ? bk[j].y : bk[j].w) >> 6) & 1u;
-        more[j] = ok[j] & !(m0 | m1) & !empty;
+        const uint32_t want = want_of(j);
+        const bool match = (bk[j].y == want) | (bk[j].w == want);
+        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);                   // a free slot ends the probe path
+        lane_any |= match;
+        more[j] = !match & !empty;
         lane_more |= more[j];
       }
-      // rare: the home bucket was full of other keys -> walk the probe path
+      // rare: the home bucket was full of other keys -> walk the probe path; a slot found there is
+      // moved into (x, y) of bk[j] in home form, so that the decode below needs no second case
       if (__ballot(lane_more)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
           uint32_t d = 0;
           while (more[j]) {
             ++d;
-            const uint4 b2 = tab16[(pos[j] + d) & bmask];
-            const uint32_t want = ((uint32_t)(pos[j] >> P.tab_lg) << 8) | 0x80u | d;
-            const bool m0 = (b2.y & ~0x40u) == want, m1 = (b2.w & ~0x40u) == want;
-            if (m0 | m1) {
-              hit[j] = true;
-              payload[j] = m0 ? b2.x : b2.z;
-              multi[j] = ((m0 ? b2.y : b2.w) >> 6) & 1u;
+            const uint4 b2 = tab16[((uint32_t)pos[j] + d) & bmask];
+            const uint32_t want = want_of(j) | d;
+            const bool n0 = b2.y == want, n1 = b2.w == want;
+            if (n0 | n1) {
+              bk[j].x = n0 ? b2.x : b2.z;
+              bk[j].y = want_of(j);
+              lane_any = true;
               more[j] = false;
             } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
               more[j] = false;
@@ -382,14 +433,32 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
           }
         }
       }
+      bool round_any = __ballot(lane_any) != 0ull;
+      if (FAST && !round_any) break;
+      // something matched: decode.  In LDS-summary mode the slots now have to exist and be valid
+      // k-mers as well (their probes were issued unconditionally).
+      uint32_t payload[U];
+      bool multi[U];
+      lane_any = false;
 #pragma unroll
-      for (int j = 0; j < U; ++j) lane_any |= hit[j];
-      const bool round_any = __ballot(lane_any) != 0ull;
+      for (int j = 0; j < U; ++j) {
+        const uint32_t want = want_of(j);
+        const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+        hit[j] = m0 | m1;
+        if (LAZY) hit[j] = hit[j] && slot_ok((uint32_t)lane + 64u * j);
+        lane_any |= hit[j];
+        const uint32_t lo = m0 ? bk[j].x : bk[j].z;
+        payload[j] = lo & 0x7FFFFFFFu;
+        multi[j] = (lo >> 31) != 0u;
+      }
       if (!FAST && P.work_counters) {
 #pragma unroll
         for (int j = 0; j < U; ++j) wk_hits += hit[j];
       }
-      if (FAST && !round_any) break;
+      if (LAZY) {
+        round_any = __ballot(lane_any) != 0ull;
+        if (!round_any) break;
+      }
       if (SHK_ABL(P, 1u)) break;
       any_hit |= round_any;
       // multi-gene lists (rare): entry r gives start/len/first gene
@@ -517,8 +586,11 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       if (g == GENE_INF) break;
       uint32_t contrib = 0, nk = 0;
       uint64_t hprev = 0;
-      // one 64-slot chunk: hit mask by ballot, distance to the previous hit by clz
-      auto chunk = [&](const bool h, const uint32_t t, uint32_t &c_rs, const uint32_t c_re, uint32_t &c_cur) {
+      // one 64-slot chunk: hit mask by ballot, distance to the previous hit by clz.  Slots are
+      // packed positions, and mate 2 starts at P2 >= L1, so a hit in mate 2 is at least k away
+      // from any hit in mate 1 (last slot L1-k): the min() clamps to k exactly as it does in the
+      // reference's joined coordinates.
+      auto chunk = [&](const bool h, uint32_t &c_rs, const uint32_t c_re, uint32_t &c_cur) {
         const uint64_t H = __ballot(h);
         nk += (uint32_t)__builtin_popcountll(H);
         if (h) {
@@ -526,7 +598,6 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
           uint32_t d = k;
           if (below) d = lane - (63u - (uint32_t)__builtin_clzll(below));
           else if (hprev) d = lane + 1u + (uint32_t)__builtin_clzll(hprev);
-          if (t >= nk1 && t - d < nk1) d = k;  // previous hit is in the other mate
           contrib += d < k ? d : k;            // min(k, pos - last)  ReadAnalyzer.hpp:81
           c_rs += 1u;                          // advance this slot's cursor past g
           c_cur = c_rs < c_re ? (uint32_t)P.ids[c_rs] : GENE_INF;
@@ -535,7 +606,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       };
       if (FAST) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) chunk(cur[j] == g, (uint32_t)lane + 64u * j, rs[j], re[j], cur[j]);
+        for (int j = 0; j < U; ++j) chunk(cur[j] == g, rs[j], re[j], cur[j]);
       } else {
         for (uint32_t tb = 0; tb < ns; tb += 64) {
           const uint32_t t = tb + lane;
@@ -543,7 +614,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
           uint32_t c_rs = in ? st.rec_start[t] : 0u, c_cur = in ? st.cur[t] : GENE_INF;
           const uint32_t c_re = in ? st.rec_end[t] : 0u;
           const bool h = c_cur == g;
-          chunk(h, t, c_rs, c_re, c_cur);
+          chunk(h, c_rs, c_re, c_cur);
           if (h) { st.rec_start[t] = c_rs; st.cur[t] = c_cur; }
         }
       }
@@ -614,14 +685,13 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
 {
   using G = FastGeom<MODE>;
   constexpr uint32_t S = 64 * U;
-  constexpr uint32_t CW = code_words_for(S), VW = vbit_words_for(S);
-  constexpr uint32_t WORDS = CW + VW;   // slot records stay in registers
+  constexpr uint32_t WORDS = stage_words_for(S);   // slot records stay in registers
   __shared__ uint64_t lds[G::SUM_WORDS64 + G::WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t *lsum = nullptr;
   if (MODE == PM_LDS_TAB) {
-    // stage the summary: 64 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
+    // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < LDS_SUM_BITS / 128; i += G::THREADS) dst[i] = src[i];
@@ -630,8 +700,10 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
   }
   uint64_t *base = lds + G::SUM_WORDS64 + wave * WORDS;
   WaveStore st;
-  st.codes = base;
-  st.vbits = base + CW;
+  st.fw = reinterpret_cast<uint32_t *>(base);
+  st.rv = st.fw + code_dwords_for(S);
+  st.rcap = stage_cap_bases(S);
+  st.vbits = base + code_dwords_for(S);
   st.rec_start = nullptr;
   st.rec_end = nullptr;
   st.cur = nullptr;
@@ -683,12 +755,13 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t gw = (uint64_t)blockIdx.x * CF_WAVES + wave;
   uint64_t *base = P.scratch + gw * P.scratch_stride_words;
-  const uint32_t S = P.scratch_slots;
-  const uint32_t CW = P.scratch_code_words, VW = P.scratch_code_words / 2 + 2;
+  const uint32_t S = P.scratch_slots;   // multiple of 64
   WaveStore st;
-  st.codes = base;
-  st.vbits = base + CW;
-  st.rec_start = reinterpret_cast<uint32_t *>(base + CW + VW);
+  st.fw = reinterpret_cast<uint32_t *>(base);
+  st.rv = st.fw + code_dwords_for(S);
+  st.rcap = stage_cap_bases(S);
+  st.vbits = base + code_dwords_for(S);
+  st.rec_start = reinterpret_cast<uint32_t *>(base + stage_words_for(S));
   st.rec_end = st.rec_start + S;
   st.cur = st.rec_end + S;
   const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void table_build_kernel(const uint64_t *__rest
     const uint64_t pos = (w << 6) | b;
     const ListEntry le = ent[r];
     const bool multi = le.len != 1;
-    const uint64_t base = ((pos >> tab_lg) << 40) | (1ull << 39) | ((uint64_t)multi << 38) | (uint64_t)(multi ? r : (uint32_t)le.gene0);
+    // slot: tag(24) | valid (bit 39) | displacement (6) in the high word -- the word the kernel compares --
+    // and multi (bit 31) | rank or gene in the low word
+    const uint64_t base = ((pos >> tab_lg) << 40) | (1ull << 39) | ((uint64_t)multi << 31) | (uint64_t)(multi ? r : (uint32_t)le.gene0);
     uint64_t bkt = pos & bmask;
     bool done = false;
     for (uint32_t d = 0; d < 64 && !done; ++d) {
@@ -345,11 +347,12 @@ int build_index(Ctx *ctx)
     uint32_t lg = 9;                                        // >= 512 buckets
     while ((2ull << lg) < 4ull * n_set) ++lg;               // load factor <= 1/4
     if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
-    if (lg < lgB) {
+    if (lg < lgB && lg <= 31) {                             // (bucket indices are 32-bit in the kernel)
       const uint64_t slots = 2ull << lg;
       uint32_t *d_fail = nullptr;
-      BI_HIP(hipMalloc((void **)&ix.tab, slots * sizeof(uint64_t)));
-      BI_HIP(hipMemsetAsync(ix.tab, 0, slots * sizeof(uint64_t), st));
+      // (+1 bucket that stays empty: where the kernel sends probes that need no answer)
+      BI_HIP(hipMalloc((void **)&ix.tab, (slots + 2) * sizeof(uint64_t)));
+      BI_HIP(hipMemsetAsync(ix.tab, 0, (slots + 2) * sizeof(uint64_t), st));
       BI_HIP(hipMalloc((void **)&d_fail, sizeof(uint32_t)));
       BI_HIP(hipMemsetAsync(d_fail, 0, sizeof(uint32_t), st));
       hipLaunchKernelGGL(table_build_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words,
@@ -367,7 +370,7 @@ int build_index(Ctx *ctx)
         if (lgB > LDS_SUM_LOG2 && !getenv("SHK_NO_LDS_SUMMARY")) {
           const uint32_t sh = lgB - LDS_SUM_LOG2;
           const double pass = 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits);
-          if (sh >= 6 && pass <= 0.30) {
+          if (sh >= 6 && sh < 32 && pass <= 0.30) {
             BI_HIP(hipMalloc((void **)&ix.lsum32, (LDS_SUM_BITS / 32 + 2) * sizeof(uint32_t)));
             BI_HIP(hipMemsetAsync(ix.lsum32, 0, (LDS_SUM_BITS / 32 + 2) * sizeof(uint32_t), st));
             hipLaunchKernelGGL(bf_summary_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words, sh, ix.lsum32);

@@ -31,10 +31,12 @@ static void free_index(DeviceIndex &ix)
   ix = DeviceIndex{};
 }
 
+// slot positions of a read (pair) whose mates are `len` long: classify.hip packs mate 2 at the next
+// multiple of 8 after mate 1 and uses packed positions as k-mer slots
 static uint32_t slots_for_len(uint32_t len, uint32_t k, bool paired)
 {
   const uint32_t per = len >= k ? len - k + 1 : 0;
-  return paired ? 2 * per : per;
+  return (paired && per) ? ((len + 7u) & ~7u) + per : per;
 }
 
 // everything after the inputs are resident in HBM; batch pointers are device pointers
@@ -101,13 +103,11 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   SHK_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   SHK_HIP(ctx, hipStreamSynchronize(st));
   const uint32_t n_long = ctx->h_counters[CTR_LONG];
-  uint32_t gen_slots = fast_cap, gen_bases = fast_cap + 91;
+  uint32_t gen_slots = fast_cap;
 
   auto size_scratch = [&](uint64_t n_items, unsigned *n_waves) -> int {
     const uint32_t S = ((gen_slots + 63) / 64) * 64;
-    const uint32_t CW = (gen_bases + 31) / 32 + 2;
-    const uint32_t VW = CW / 2 + 2;
-    const uint64_t stride = (uint64_t)CW + VW + (3ull * S) / 2 + 2;
+    const uint64_t stride = (uint64_t)stage_words_for(S) + (3ull * S) / 2 + 2;   // staging area + 3 u32 slot records
     uint64_t waves = std::min<uint64_t>(n_items, 4096);
     const uint64_t budget_words = (1ull << 31) / 8;  // at most 2 GiB of scratch
     if (waves * stride > budget_words) waves = std::max<uint64_t>(1, budget_words / stride);
@@ -117,14 +117,12 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
     p.scratch = ctx->d_scratch;
     p.scratch_stride_words = stride;
     p.scratch_slots = S;
-    p.scratch_code_words = CW;
     *n_waves = (unsigned)waves;
     return SHK_OK;
   };
 
   if (n_long) {
     gen_slots = std::max(gen_slots, ctx->h_counters[CTR_MAX_SLOTS]);
-    gen_bases = std::max(gen_bases, ctx->h_counters[CTR_MAX_BASES]);
     unsigned n_waves = 0;
     if ((rc = size_scratch(n_long, &n_waves))) return rc;
     p.work = ctx->d_long_queue;

@@ -69,6 +69,12 @@ struct DeviceIndex {
   uint64_t tot_idx = 0;
 };
 
+// per-wave staging area of a read for a slot capacity S (layout: classify.hip)
+__host__ __device__ constexpr uint32_t stage_cap_bases(uint32_t S) { return S + 96; }                  // S = slot capacity, multiple of 64
+__host__ __device__ constexpr uint32_t code_dwords_for(uint32_t S) { return stage_cap_bases(S) / 16 + 2; }   // one stream (even)
+__host__ __device__ constexpr uint32_t vbit_words_for(uint32_t S) { return stage_cap_bases(S) / 64 + 2; }
+__host__ __device__ constexpr uint32_t stage_words_for(uint32_t S) { return code_dwords_for(S) + vbit_words_for(S); }   // 64-bit words: fw + rv + validity
+
 // result / queue pointers of a classify launch.  They live in device memory behind ONE pointer so
 // that the hot loop does not pin ~14 SGPRs for values it needs once per read (the fast kernel is at
 // the 106-SGPR limit and spills wave-uniform values into VGPRs otherwise).
@@ -118,7 +124,6 @@ struct ClassifyParams {
   uint64_t *scratch;
   uint64_t scratch_stride_words;   // per wave
   uint32_t scratch_slots;          // slot capacity per wave
-  uint32_t scratch_code_words;     // code words capacity
   // emit mode (general kernel): write every gene whose (cov,nk) equals the
   // recorded best to gene_ids[gene_off[read] + i]
   const uint32_t *gene_off;
@@ -135,7 +140,7 @@ enum {
   CTR_UNUSED2 = 2,
   CTR_UNUSED3 = 3,
   CTR_MAX_SLOTS = 4, // max k-mer slots over queued long reads
-  CTR_MAX_BASES = 5, // max packed length over queued long reads
+  CTR_UNUSED5 = 5,
   CTR_WORDS = 8
 };
 
