@@ -164,39 +164,45 @@ __device__ __forceinline__ ReadMeta fetch_meta(const ClassifyParams &P, uint64_t
   return m;
 }
 
-// Offsets of a read fetched with explicit SCALAR loads.  hipcc turns these uniform loads into
-// vector loads once the kernel has stored anything (it cannot prove the offsets invariant), and a
-// vector load behind the prefetched bases forces `s_waitcnt vmcnt(0)` -- the prefetch would be
-// waited for immediately.  s_load uses the lgkm counter instead.  The compiler does not track
-// asm loads, so meta_wait() must run before the values are used (cdna_hip_programming.md 5.7).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Offsets of a read fetched one iteration ahead.  The loads are ordinary (vector) loads of a
+// wave-uniform address, so the compiler tracks them: any use, spill or move waits for them first.
+// (An earlier version issued s_load_dwordx4 in inline asm to keep these loads off the vmcnt
+// counter; the compiler cannot know that such a result is still in flight, and under SGPR pressure
+// it spilled the destination registers right behind the load -- saving stale values.)  The caller
+// retires them together with the prefetched bases at the end of its loop, where they have long
+// landed, and turns them into scalars there.
 struct ReadMetaRaw {
-  u32x4 a, b;   // off1[read], off1[read+1] ; off2[read], off2[read+1]
+  uint64_t a0, a1, b0, b1;   // off1[read], off1[read+1] ; off2[read], off2[read+1]
 };
 
-__device__ __forceinline__ ReadMetaRaw fetch_meta_async(const ClassifyParams &P, uint64_t read_in)
+__device__ __forceinline__ ReadMetaRaw fetch_meta_issue(const ClassifyParams &P, uint64_t read_in)
 {
   const uint64_t read = uniform64(read_in);
   ReadMetaRaw r;
-  const uint64_t *p1 = P.off1 + read;
-  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r.a) : "s"(p1));
+  r.a0 = P.off1[read];
+  r.a1 = P.off1[read + 1];
+  r.b0 = 0;
+  r.b1 = 0;
   if (P.seq2) {
-    const uint64_t *p2 = P.off2 + read;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r.b) : "s"(p2));
-  } else {
-    r.b = u32x4{0, 0, 0, 0};
+    r.b0 = P.off2[read];
+    r.b1 = P.off2[read + 1];
   }
   return r;
 }
 
-__device__ __forceinline__ ReadMeta meta_wait(ReadMetaRaw r)
+// wait for the outstanding vector loads and hand the offsets back as plain register values
+__device__ __forceinline__ void retire_meta(ReadMetaRaw &r)
 {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b));
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.b0), "+v"(r.b1));
+}
+
+__device__ __forceinline__ ReadMeta meta_finish(const ReadMetaRaw &r)
+{
   ReadMeta m;
-  m.o1 = ((uint64_t)r.a.y << 32) | r.a.x;
-  m.L1 = (uint32_t)((((uint64_t)r.a.w << 32) | r.a.z) - m.o1);
-  m.o2 = ((uint64_t)r.b.y << 32) | r.b.x;
-  m.L2 = (uint32_t)((((uint64_t)r.b.w << 32) | r.b.z) - m.o2);
+  m.o1 = uniform64(r.a0);
+  m.L1 = __builtin_amdgcn_readfirstlane((uint32_t)(r.a1 - r.a0));
+  m.o2 = uniform64(r.b0);
+  m.L2 = __builtin_amdgcn_readfirstlane((uint32_t)(r.b1 - r.b0));
   return m;
 }
 
@@ -584,41 +590,63 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       }
       const uint32_t g = wave_min_u32(mymin);
       if (g == GENE_INF) break;
-      uint32_t contrib = 0, nk = 0;
-      uint64_t hprev = 0;
-      // one 64-slot chunk: hit mask by ballot, distance to the previous hit by clz.  Slots are
-      // packed positions, and mate 2 starts at P2 >= L1, so a hit in mate 2 is at least k away
-      // from any hit in mate 1 (last slot L1-k): the min() clamps to k exactly as it does in the
+      // Gene g's hits as bit masks over the packed positions (one ballot per 64 slots).  Its
+      // coverage k + sum min(k, p_j - p_(j-1))  (ReadAnalyzer.hpp:56-62,:79-86) is the size of the union
+      // of the intervals [p_j, p_j + k): position x is covered iff a hit lies in (x-k, x].  Lane l of
+      // chunk c looks at the 64 positions ending at x = 64c + l -- the chunk's mask shifted up, the
+      // previous chunk's mask shifted down -- and tests the top k bits; the covered positions are
+      // counted by popcounts of ballots on the scalar unit.  Mate 2 starts at P2 >= L1 and mate 1's
+      // last slot is L1-k, so an interval never reaches into the other mate: same clamp as the
       // reference's joined coordinates.
-      auto chunk = [&](const bool h, uint32_t &c_rs, const uint32_t c_re, uint32_t &c_cur) {
-        const uint64_t H = __ballot(h);
-        nk += (uint32_t)__builtin_popcountll(H);
-        if (h) {
-          const uint64_t below = H & ((1ull << lane) - 1ull);
-          uint32_t d = k;
-          if (below) d = lane - (63u - (uint32_t)__builtin_clzll(below));
-          else if (hprev) d = lane + 1u + (uint32_t)__builtin_clzll(hprev);
-          contrib += d < k ? d : k;            // min(k, pos - last)  ReadAnalyzer.hpp:81
-          c_rs += 1u;                          // advance this slot's cursor past g
-          c_cur = c_rs < c_re ? (uint32_t)P.ids[c_rs] : GENE_INF;
-        }
-        hprev = H;
+      uint32_t nk = 0, cov = 0;
+      const uint64_t kthr = 1ull << (64u - k);
+      auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
+        const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
+        return (uint32_t)__builtin_popcountll(__ballot(t >= kthr));
       };
       if (FAST) {
+        uint64_t H[U];
+        bool more_ids = false;
 #pragma unroll
-        for (int j = 0; j < U; ++j) chunk(cur[j] == g, rs[j], re[j], cur[j]);
+        for (int j = 0; j < U; ++j) {
+          const bool h = cur[j] == g;
+          H[j] = __ballot(h);
+          rs[j] += h ? 1u : 0u;                // advance this slot's cursor past g
+          more_ids |= h & (rs[j] < re[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          nk += (uint32_t)__builtin_popcountll(H[j]);
+          cov += cover(H[j], j ? H[j - 1] : 0ull);
+        }
+        cov += cover(0ull, H[U - 1]);
+        if (__ballot(more_ids)) {              // multi-gene lists only
+#pragma unroll
+          for (int j = 0; j < U; ++j)
+            if ((H[j] >> lane) & 1ull) cur[j] = rs[j] < re[j] ? (uint32_t)P.ids[rs[j]] : GENE_INF;
+        } else {
+#pragma unroll
+          for (int j = 0; j < U; ++j) cur[j] = ((H[j] >> lane) & 1ull) ? GENE_INF : cur[j];
+        }
       } else {
+        uint64_t Hprev = 0;
         for (uint32_t tb = 0; tb < ns; tb += 64) {
           const uint32_t t = tb + lane;
           const bool in = t < ns;
-          uint32_t c_rs = in ? st.rec_start[t] : 0u, c_cur = in ? st.cur[t] : GENE_INF;
-          const uint32_t c_re = in ? st.rec_end[t] : 0u;
+          const uint32_t c_cur = in ? st.cur[t] : GENE_INF;
           const bool h = c_cur == g;
-          chunk(h, c_rs, c_re, c_cur);
-          if (h) { st.rec_start[t] = c_rs; st.cur[t] = c_cur; }
+          const uint64_t Hc = __ballot(h);
+          nk += (uint32_t)__builtin_popcountll(Hc);
+          cov += cover(Hc, Hprev);
+          if (h) {
+            const uint32_t c_rs = st.rec_start[t] + 1u;
+            st.rec_start[t] = c_rs;
+            st.cur[t] = c_rs < st.rec_end[t] ? (uint32_t)P.ids[c_rs] : GENE_INF;
+          }
+          Hprev = Hc;
         }
+        cov += cover(0ull, Hprev);
       }
-      const uint32_t cov = wave_sum_u32(contrib);
       if (EMIT) {
         if (cov == tie_cov && nk == tie_nk) {
           if (lane == 0) {
@@ -708,7 +736,8 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
   st.rec_end = nullptr;
   st.cur = nullptr;
   // software pipeline over this wave's reads: the offsets are fetched two reads ahead and the
-  // bases one read ahead, so their HBM latency hides under the hashing of the current read
+  // bases one read ahead (all ordinary loads), so their HBM latency hides under the hashing of the
+  // current read
   // (ablation: the in-place base loads cost 4.4 of 14 ms on the all-miss workload)
   // (read indices fit 32 bits: shk_classify* refuses batches of 2^32-1 reads or more)
   const uint32_t stride = gridDim.x * G::WAVES, n32 = (uint32_t)P.n;
@@ -727,7 +756,7 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
     const bool have_nxt = nxt < n32;
     if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
     const uint32_t nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
-    const ReadMetaRaw r_nn = fetch_meta_async(P, nn < n32 ? nn : read);   // scalar loads, clamped index
+    ReadMetaRaw r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
     process_read<U, MODE, HASQ, true, false>(P, read, lane, st, S, 0u, 0u, lsum, m_cur, true, w_cur, q_cur);
     if (!have_nxt) break;
     // The prefetched bases landed long ago.  Retire them HERE and hand the compiler plain register
@@ -736,8 +765,9 @@ __global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_
     // behind the next prefetch, which would serialise the pipeline again.
     retire_loads(w_nxt);
     retire_loads(q_nxt);
+    retire_meta(r_nn);
     read = nxt; m_cur = m_nxt; w_cur = w_nxt; q_cur = q_nxt;
-    nxt = nn; m_nxt = meta_wait(r_nn);
+    nxt = nn; m_nxt = meta_finish(r_nn);
   }
 }
 
