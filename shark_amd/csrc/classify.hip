@@ -333,12 +333,15 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       // amounts below are loop invariant and the 64 j become instruction offsets
       const uint32_t t = (FAST ? 0u : base) + (uint32_t)lane + 64u * j;
       const uint32_t pp = FAST ? t : (t < ns ? t : 0u);
-      const uint32_t *f = st.fw + (pp >> 4);
+      // (fast kernel: everything is derived from slot U-1 / slot 0 of the lane plus constants, so
+      // only two addresses and two shift amounts stay live across reads)
+      const uint32_t qU = st.rcap - k - ((uint32_t)lane + 64u * (U - 1));
+      const uint32_t q0 = FAST ? qU + 64u * (U - 1 - j) : st.rcap - k - pp;
+      const uint32_t *f = FAST ? st.fw + ((uint32_t)lane >> 4) + 4 * j : st.fw + (pp >> 4);
+      const uint32_t *r = FAST ? st.rv + (qU >> 4) + 4 * (U - 1 - j) : st.rv + (q0 >> 4);
       const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
-      const uint32_t q0 = st.rcap - k - pp;
-      const uint32_t *r = st.rv + (q0 >> 4);
       const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
-      const uint32_t sf = (pp & 15u) << 1, sr = (q0 & 15u) << 1;
+      const uint32_t sf = ((FAST ? (uint32_t)lane : pp) & 15u) << 1, sr = ((FAST ? qU : q0) & 15u) << 1;
       const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
       const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
       const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
@@ -699,19 +702,20 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 // ---------------------------------------------------------------------------
 // fast kernel: everything per wave lives in LDS; slot capacity 64*U
 // ---------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int U>
 struct FastGeom {
   static constexpr int WAVES = MODE == PM_LDS_TAB ? 8 : CF_WAVES;   // 512-thread workgroups share one LDS summary
   static constexpr int THREADS = WAVES * 64;
-  // two 1024-thread workgroups per CU need 8 waves per SIMD, i.e. <= 64 VGPRs
-  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? 6 : 1;
+  // LDS-summary mode: four 512-thread workgroups per CU (4 x 34 KiB of LDS) = 8 waves per SIMD, which
+  // needs <= 64 VGPRs; the specialisations for more than 320 slots do not fit that and run 6 waves
+  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? (U <= 5 ? 8 : 6) : 1;
   static constexpr uint32_t SUM_WORDS64 = MODE == PM_LDS_TAB ? LDS_SUM_BITS / 64 : 0;
 };
 
 template <int U, int MODE, bool HASQ>
-__global__ __launch_bounds__(FastGeom<MODE>::THREADS, FastGeom<MODE>::MIN_WAVES_PER_SIMD) void classify_fast_kernel(const ClassifyParams P)
+__global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::MIN_WAVES_PER_SIMD)) void classify_fast_kernel(const ClassifyParams P)
 {
-  using G = FastGeom<MODE>;
+  using G = FastGeom<MODE, U>;
   constexpr uint32_t S = 64 * U;
   constexpr uint32_t WORDS = stage_words_for(S);   // slot records stay in registers
   __shared__ uint64_t lds[G::SUM_WORDS64 + G::WAVES * WORDS];
@@ -901,7 +905,7 @@ const char *probe_mode_name(const Ctx *ctx)
 template <int U>
 static void launch_fast_u(const ClassifyParams &p, int mode, bool hasq, unsigned grid, hipStream_t s)
 {
-#define LF(M_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, M_, HQ_>), dim3(grid), dim3(FastGeom<M_>::THREADS), 0, s, p)
+#define LF(M_, HQ_) hipLaunchKernelGGL((classify_fast_kernel<U, M_, HQ_>), dim3(grid), dim3(FastGeom<M_, U>::THREADS), 0, s, p)
   switch (mode) {
   case PM_BV_MOD: if (hasq) LF(PM_BV_MOD, true); else LF(PM_BV_MOD, false); break;
   case PM_BV: if (hasq) LF(PM_BV, true); else LF(PM_BV, false); break;
@@ -921,10 +925,10 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   // persistent grid: enough workgroups to fill 256 CUs several times over
   // persistent workgroups; the LDS-summary mode runs 2 x 1024-thread workgroups per CU
   const uint64_t wpb = mode == PM_LDS_TAB ? 8 : CF_WAVES;
-  const uint64_t cap = mode == PM_LDS_TAB ? 768 : 4096;
+  const uint32_t u = fast_kernel_unroll(max_slots);
+  const uint64_t cap = mode == PM_LDS_TAB ? (u <= 5 ? 1024 : 768) : 4096;   // LDS mode: exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  const uint32_t u = fast_kernel_unroll(max_slots);
   if (u == 2) launch_fast_u<2>(p, mode, hasq, grid, stream);
   else if (u == 3) launch_fast_u<3>(p, mode, hasq, grid, stream);
   else if (u == 4) launch_fast_u<4>(p, mode, hasq, grid, stream);
