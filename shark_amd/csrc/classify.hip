@@ -708,7 +708,7 @@ struct FastGeom {
   static constexpr int THREADS = WAVES * 64;
   // LDS-summary mode: four 512-thread workgroups per CU (4 x 34 KiB of LDS) = 8 waves per SIMD, which
   // needs <= 64 VGPRs; the specialisations for more than 320 slots do not fit that and run 6 waves
-  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? (U <= 5 ? 8 : 6) : 1;
+  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? (U <= 5 ? 8 : 6) : ((MODE == PM_TAB || MODE == PM_TAB_SUM) && U <= 5 ? 8 : 1);
   static constexpr uint32_t SUM_WORDS64 = MODE == PM_LDS_TAB ? LDS_SUM_BITS / 64 : 0;
 };
 

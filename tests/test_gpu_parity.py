@@ -512,3 +512,36 @@ def test_every_kernel_specialisation(oracle, read_len, paired, q):
         bb = synth.batch_from_lists(m1, None, q1, None)
     _compare_classify(o, h, bb)
     assert h.timing()["last_n_long"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [17, 31, 4])
+def test_packed_position_edges(oracle, k):
+    """the fast kernel addresses k-mers by packed position (mate 2 starts at L1 rounded up to 8): every
+    alignment of L1, mates shorter than k, an empty mate, and pairs that fill a specialisation's capacity
+    exactly / exceed it by one (general kernel), all in ONE batch so that waves see stale staging data
+    of longer reads behind shorter ones"""
+    rng = np.random.default_rng(77 + k)
+    genes = synth.make_genes(rng, 6, 1200, 2500, share_every=3)
+    o, h, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 24)
+    shapes = [(L1, L2) for L1 in range(140, 153) for L2 in (150, 151)]                       # every L1 mod 8
+    shapes += [(150, L2) for L2 in (0, 1, k - 1, k, k + 1)] + [(L1, 150) for L1 in (0, 1, k - 1, k, k + 1)]
+    shapes += [(k - 1, k - 1), (0, 0), (k, 0), (0, k)]
+    for U in (2, 3, 4, 5, 6, 8):                                                              # ns = round8(L1) + L2-k+1 around 64 U
+        L1 = 8 * (4 * U - 1)                                                                  # multiple of 8, about half the capacity
+        for d in (-1, 0, 1):
+            shapes.append((L1, 64 * U - L1 + k - 1 + d))
+    m1, m2 = [], []
+    for i, (L1, L2) in enumerate(shapes * 3):
+        g = genes[i % len(genes)]
+        st = int(rng.integers(0, len(g) - 600))
+        a = g[st:st + L1].copy()
+        b = synth.revcomp(g[st:st + 600])[:L2].copy()
+        if i % 5 == 0 and L2 > 3:
+            b[int(rng.integers(0, L2))] = ord("N")
+        m1.append(a.tobytes())
+        m2.append(b.tobytes())
+    order = rng.permutation(len(m1))
+    batch = synth.batch_from_lists([m1[i] for i in order], [m2[i] for i in order])
+    goff, _ = _compare_classify(o, h, batch)
+    assert goff[-1] > len(m1) // 3
