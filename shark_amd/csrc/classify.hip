@@ -132,6 +132,8 @@ __device__ __forceinline__ const ClassifyOut *out_ptrs(const ClassifyParams &P)
   return o;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // offsets / lengths of one read (pair)
 struct ReadMeta {
   uint64_t o1, o2;
@@ -407,7 +409,15 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
         // probes that are already proven clear read the spare bucket behind the table: it is empty,
         // so they neither match nor continue, and nothing below has to look at ok[j] again
         const uint32_t b = (uint32_t)pos[j] & bmask;
-        bk[j] = tab16[LSUM ? ((b & okm[j]) | (spare & ~okm[j])) : (ok[j] ? b : spare)];
+        const uint32_t bi = LSUM ? ((b & okm[j]) | (spare & ~okm[j])) : (ok[j] ? b : spare);
+        if (!LSUM && P.tab_nt) {
+          // a table far beyond the caches: streaming loads (measured +4 % on the 8 GiB table of the
+          // 60 000-gene index, but 1.5x slower on an L2-resident table)
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
+          bk[j] = make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+          bk[j] = tab16[bi];
+        }
       }
       bool more[U];
       bool lane_more = false;

@@ -61,6 +61,7 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   p.bf64 = ix.bf64; p.rank_w = ix.rank_w; p.ent = ix.ent; p.ids = ix.ids;
   p.sum32 = ix.sum_shift ? ix.sum32 : nullptr; p.sum_shift = ix.sum_shift;
   p.tab = ix.tab_lg ? ix.tab : nullptr; p.tab_lg = ix.tab_lg;
+  p.tab_nt = ix.tab_lg && (16ull << ix.tab_lg) > (256ull << 20);   // beyond L2 + Infinity Cache
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
   p.bf_bits = ix.bf_bits; p.bf_mask = ix.bf_bits - 1;
   p.k = ctx->prm.k; p.c = ctx->prm.c; p.single = ctx->prm.single;

@@ -97,6 +97,7 @@ struct ClassifyParams {
   uint32_t sum_shift;
   const uint64_t *tab;
   uint32_t tab_lg;
+  uint32_t tab_nt;           // 1 = table far larger than the caches: probe it with non-temporal loads
   const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
   uint32_t lsum_shift;
   uint64_t bf_bits;
