@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""(test infrastructure; run by hand on a GPU box: `python tests/fuzz_parity.py [iterations] [seed]`)
+Randomised differential test of the HIP path against the CPU oracle: random k, filter size (power of
+two or not, sparse to almost full), gene sets with shared halves, read lengths from empty to beyond the
+LDS specialisations, N / lower case / quality masks, -s, confidence, single-end or paired, both probe
+structures.  Prints one line per case; stops at the first mismatch and prints the seed to replay."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime for both)
+from tests import synth
+from oracle import pyoracle
+from shark_amd import SharkHip
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20261003
+t_start = time.time()
+modes = {}
+for it in range(iters):
+    seed = seed0 + it
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([1, 2, 5, 11, 16, 17, 18, 21, 25, 31, int(rng.integers(1, 32))]))
+    if rng.random() < 0.7:
+        bf_bits = 1 << int(rng.integers(8, 30))
+    else:
+        bf_bits = int(rng.integers(300, 1 << 22))
+    n_genes = int(rng.choice([1, 2, 7, 40, 300]))
+    gl = int(rng.choice([60, 400, 2500]))
+    genes = synth.make_genes(rng, n_genes, max(20, gl // 3), gl, share_every=int(rng.choice([0, 2, 5])))
+    q = int(rng.choice([0, 0, 2, 20, 35]))
+    single = bool(rng.random() < 0.3)
+    c = float(rng.choice([0.0, 0.3, 0.6, 0.9, 1.0]))
+    paired = bool(rng.random() < 0.75)
+    read_len = int(rng.choice([20, 50, 76, 100, 150, 151, 250, 300, 700]))
+    if rng.random() < 0.5:
+        os.environ["SHK_PROBE"] = "bitvector"
+    else:
+        os.environ.pop("SHK_PROBE", None)
+    kw = dict(k=k, c=c, bf_bits=bf_bits, min_quality=q, single=single)
+    o = pyoracle.Shark(**kw)
+    nidx = o.build([bytes(g) for g in genes])
+    h = SharkHip(**kw)
+    info = h.build([bytes(g) for g in genes])
+    ok = info["nidx"] == nidx and info["n_set_bits"] == o.num_kmer() and np.array_equal(o.bf_words(), h.copy_bf())
+    n_reads = int(rng.choice([1, 63, 64, 65, 1000, 4000]))
+    b = synth.make_reads(rng, genes, n_reads, read_len=read_len, paired=paired, on_target=float(rng.choice([0.0, 0.5, 1.0])),
+                         n_rate=float(rng.choice([0.0, 0.002, 0.05])), lower_rate=float(rng.choice([0.0, 0.1])),
+                         var_len=bool(rng.random() < 0.6), qual=q > 0)
+    og, oi = o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"], nthreads=4)
+    hg, hi = h.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"])
+    ok = ok and np.array_equal(og, hg) and np.array_equal(oi, hi)
+    mode = h.probe_mode()
+    modes[mode] = modes.get(mode, 0) + 1
+    print("%4d seed=%d k=%d bf=%d genes=%d len=%d%s q=%d s=%d c=%.1f reads=%d mode=%s set=%d assoc=%d %s" % (
+        it, seed, k, bf_bits, n_genes, read_len, "x2" if paired else "", q, single, c, n_reads, mode, info["n_set_bits"], int(og[-1]),
+        "ok" if ok else "MISMATCH"), flush=True)
+    h.close()
+    if not ok:
+        print("replay: python tests/fuzz_parity.py 1 %d" % seed)
+        sys.exit(1)
+print("FUZZ OK: %d cases in %.0f s, probe modes %s" % (iters, time.time() - t_start, modes))

@@ -34,13 +34,16 @@ t0 = time.time()
 write_fastq(os.path.join(td, "r1.fq"), 1)
 write_fastq(os.path.join(td, "r2.fq"), 2)
 gen_s = time.time() - t0
-t0 = time.time()
-with open(os.path.join(td, "out.ssv"), "wb") as so:
-    r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"),
-                        "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq")] + extra,
-                       stdout=so, stderr=subprocess.PIPE)
-dt = time.time() - t0
-print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
-                  "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "extra": extra,
-                  "stderr_tail": r.stderr.decode()[-300:]}))
+# CLI_T=16,64 runs the same files once per thread count
+for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
+    args = extra + (["-t", t] if t else [])
+    t0 = time.time()
+    with open(os.path.join(td, "out.ssv"), "wb") as so:
+        r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"),
+                            "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq")] + args,
+                           stdout=so, stderr=subprocess.PIPE)
+    dt = time.time() - t0
+    print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
+                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args,
+                      "stderr_tail": r.stderr.decode()[-400:]}), flush=True)
 subprocess.run(["rm", "-rf", td])
