@@ -19,31 +19,123 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
 
 namespace shk {
 
+// Persistent worker pool behind parallel_for: the reader calls it several times per batch, and
+// spawning 16-128 std::threads per call cost more than some of the stages themselves.  One job at a
+// time (callers on different threads queue up on run_m_); jobs must not call parallel_for again.
+class WorkerPool {
+ public:
+  static WorkerPool &instance()
+  {
+    static WorkerPool p;
+    return p;
+  }
+  // run task(i) for i in [0, n_tasks) on up to `width` threads (the caller is one of them)
+  template <typename Task>
+  void run(unsigned width, unsigned n_tasks, Task &&task)
+  {
+    if (n_tasks == 0) return;
+    if (width <= 1 || n_tasks == 1) {
+      for (unsigned i = 0; i < n_tasks; ++i) task(i);
+      return;
+    }
+    std::lock_guard<std::mutex> serial(run_m_);
+    grow(width - 1);
+    std::function<void(unsigned)> fn = std::ref(task);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &fn;
+      n_tasks_ = n_tasks;
+      next_.store(0, std::memory_order_relaxed);
+      helpers_ = std::min<unsigned>(width - 1, (unsigned)th_.size());
+      active_ = helpers_;
+      ++gen_;
+    }
+    cv_.notify_all();
+    work(fn, n_tasks);
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [&] { return active_ == 0; });
+    job_ = nullptr;
+  }
+  ~WorkerPool()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+
+ private:
+  WorkerPool() = default;
+  void grow(unsigned want)
+  {
+    while (th_.size() < want) {
+      const unsigned id = (unsigned)th_.size();
+      th_.emplace_back([this, id] { loop(id); });
+    }
+  }
+  void work(std::function<void(unsigned)> &fn, unsigned n_tasks)
+  {
+    for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n_tasks;) fn(i);
+  }
+  void loop(unsigned id)
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(unsigned)> *fn;
+      unsigned n;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || (gen_ != seen && id < helpers_); });
+        if (stop_) return;
+        seen = gen_;
+        fn = job_;
+        n = n_tasks_;
+      }
+      work(*fn, n);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--active_ == 0) done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_, run_m_;
+  std::condition_variable cv_, done_cv_;
+  std::function<void(unsigned)> *job_ = nullptr;
+  std::atomic<unsigned> next_{0};
+  unsigned n_tasks_ = 0, helpers_ = 0, active_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+// f(begin, end, part) over `n_threads` contiguous parts of [0, n)
 template <typename F>
 inline void parallel_for(unsigned n_threads, size_t n, F f)
 {
   if (n == 0) return;
   n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>(n_threads, n));
   if (n_threads == 1) { f(0, n, 0u); return; }
-  std::vector<std::thread> th;
   const size_t per = (n + n_threads - 1) / n_threads;
-  for (unsigned t = 0; t < n_threads; ++t) {
+  WorkerPool::instance().run(n_threads, n_threads, [&](unsigned t) {
     const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
-    if (b < e) th.emplace_back([=] { f(b, e, t); });
-  }
-  for (auto &x : th) x.join();
+    if (b < e) f(b, e, t);
+  });
 }
 
 // allocator that leaves chars uninitialised on resize (every byte is overwritten)
@@ -57,8 +149,8 @@ struct NoInitAlloc : std::allocator<T> {
 // a view of the next `n` strict records of one file
 struct RecordBlock {
   const char *base = nullptr;          // mmap base
-  std::vector<uint64_t> nl;            // offsets of the 4*n newlines (record r: lines 4r..4r+3)
-  std::vector<uint32_t> id_len, seq_len;  // per record: name length (up to the first whitespace), sequence length
+  std::vector<uint64_t, NoInitAlloc<uint64_t>> nl;            // offsets of the 4*n newlines (record r: lines 4r..4r+3)
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> id_len, seq_len;  // per record: name length (up to the first whitespace), sequence length
   uint64_t first = 0;                  // offset of the first record's '@'
   size_t n = 0;
   // line i spans [begin(i), nl[i])
@@ -134,7 +226,9 @@ class FastqMmap {   // (historic name: the window is now filled with parallel pr
       t_read += std::chrono::duration<double>(c1 - c0).count();
       if (scan == cur_ && base_[cur_] != '@') { irregular = true; blk.base = base_; return 0; }   // kseq would skip to the next '@' / '>'
       const unsigned T = threads_;
-      std::vector<std::vector<uint64_t>> parts(T);
+      std::vector<std::vector<uint64_t>> &parts = parts_;   // (kept across calls: no fresh pages per batch)
+      parts.resize(T);
+      for (auto &v : parts) v.clear();
       parallel_for(T, (size_t)(end - scan), [&](size_t b, size_t e, unsigned t) {
         std::vector<uint64_t> &v = parts[t];
         v.reserve((size_t)((e - b) / std::max(1.0, bytes_per_line)) + 16);
@@ -213,6 +307,7 @@ class FastqMmap {   // (historic name: the window is now filled with parallel pr
   int fd_ = -1;
   const char *base_ = nullptr;   // window buffer biased by the window's file offset
   std::vector<char, NoInitAlloc<char>> buf_;
+  std::vector<std::vector<uint64_t>> parts_;
   uint64_t size_ = 0, cur_ = 0, win_start_ = 0;
   bool ok_ = false;
   unsigned threads_;

@@ -194,6 +194,36 @@ struct ReadBatch {
   std::vector<uint32_t> gene_off;
   std::vector<uint16_t> gene_ids;
   int rc = 0;
+  void reset()
+  {
+    for (Strings *x : {&id1, &seq1, &qual1, &id2, &seq2, &qual2}) { x->bytes.clear(); x->off.assign(1, 0); }
+    gene_off.clear(); gene_ids.clear();
+    rc = 0;
+  }
+};
+
+// Batches are recycled: a drained batch goes back to the splitter with its buffers' capacity, so
+// the ~0.6 GB a batch holds is faulted in once per pipeline slot instead of once per batch.
+class BatchPool {
+ public:
+  std::unique_ptr<ReadBatch> acquire()
+  {
+    std::lock_guard<std::mutex> l(m_);
+    if (free_.empty()) return std::unique_ptr<ReadBatch>(new ReadBatch());
+    std::unique_ptr<ReadBatch> b = std::move(free_.back());
+    free_.pop_back();
+    return b;
+  }
+  void release(std::unique_ptr<ReadBatch> b)
+  {
+    b->reset();
+    std::lock_guard<std::mutex> l(m_);
+    if (free_.size() < 8) free_.push_back(std::move(b));
+  }
+
+ private:
+  std::mutex m_;
+  std::vector<std::unique_ptr<ReadBatch>> free_;
 };
 
 // FastqSplitter role (FastqSplitter.hpp:47-93): batches of reads in input order.
@@ -201,7 +231,7 @@ struct ReadBatch {
 // (gzip, multi-line records, CR/LF, ...) through the serial kseq-rule reader.
 class BatchSplitter {
  public:
-  BatchSplitter(const Options &o, unsigned threads) : r1_(o.sample1_path), paired_(o.paired_flag), maxnum_(o.batch), threads_(threads)
+  BatchSplitter(const Options &o, unsigned threads, BatchPool &pool) : r1_(o.sample1_path), pool_(pool), paired_(o.paired_flag), maxnum_(o.batch), threads_(threads)
   {
     if (paired_) r2_.reset(new shk::FastxReader(o.sample2_path));
     m1_.reset(new shk::FastqMmap(o.sample1_path, threads));
@@ -220,7 +250,7 @@ class BatchSplitter {
   double t_index = 0, t_fill = 0, t_serial = 0;   // seconds spent (verbose report)
   std::unique_ptr<ReadBatch> operator()()
   {
-    std::unique_ptr<ReadBatch> b(new ReadBatch());
+    std::unique_ptr<ReadBatch> b = pool_.acquire();
     b->index = next_index_++;
     b->first_read = n_reads_;
     if (fast_) {
@@ -288,7 +318,7 @@ class BatchSplitter {
       t_serial += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
     }
     n_reads_ += b->seq1.size();
-    if (b->seq1.size() == 0) return nullptr;
+    if (b->seq1.size() == 0) { pool_.release(std::move(b)); return nullptr; }
     return b;
   }
 
@@ -296,7 +326,7 @@ class BatchSplitter {
   // copy n strict records into the structure-of-arrays strings, in parallel
   void fill(const shk::RecordBlock &k, size_t n, Strings &id, Strings &seq, Strings &qual)
   {
-    const std::vector<uint32_t> &idl = k.id_len, &sql = k.seq_len;   // measured while the block was validated
+    const auto &idl = k.id_len, &sql = k.seq_len;   // measured while the block was validated
     id.off.resize(n + 1);
     seq.off.resize(n + 1);
     qual.off.resize(n + 1);
@@ -319,6 +349,7 @@ class BatchSplitter {
   }
 
   shk::FastxReader r1_;
+  BatchPool &pool_;
   std::unique_ptr<shk::FastxReader> r2_;
   std::unique_ptr<shk::FastqMmap> m1_, m2_;
   shk::RecordBlock blk1_, blk2_;
@@ -540,7 +571,8 @@ int main(int argc, char *argv[])
   // ---- 3. sample ---------------------------------------------------------------
   {
     unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    BatchSplitter fs(opt, io_threads);
+    BatchPool pool;
+    BatchSplitter fs(opt, io_threads, pool);
     if (!fs.ok()) {
       std::cerr << "shark: cannot open the sample" << std::endl;
       return EXIT_FAILURE;
@@ -610,6 +642,7 @@ int main(int argc, char *argv[])
         ro(*b);
         t_out += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
+      pool.release(std::move(b));
       ++next;
     }
     splitter.join();
