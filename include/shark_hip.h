@@ -86,7 +86,9 @@ typedef struct shk_index_info {
 } shk_index_info;
 int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
 /* How the classify kernels look a k-mer's filter position up on this index:
- * "bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table"
+ * "bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table",
+ * "lds-summary+table", and for filter sizes that are not a power of two
+ * "table-mod", "lds-summary+table-mod"
  * (every mode returns exactly the filter's bit).  Environment
  * SHK_PROBE=bitvector at finalize time disables the table (tests use it). */
 const char *shk_probe_mode(const shk_ctx *ctx);

@@ -57,8 +57,19 @@ enum ProbeMode {
   PM_BV_SUM = 2,   // summary level, then filter word
   PM_TAB = 3,      // position table (exact sparse encoding of the set bits)
   PM_TAB_SUM = 4,  // summary level, then position table
-  PM_LDS_TAB = 5   // 2^19-bit summary held in LDS, then position table (small indices)
+  PM_LDS_TAB = 5,  // 2^18-bit summary held in LDS, then position table (small indices)
+  PM_TAB_MOD = 6,      // PM_TAB for a filter size that is not a power of two (position = hash % size)
+  PM_LDS_TAB_MOD = 7   // PM_LDS_TAB, likewise
 };
+__host__ __device__ constexpr bool pm_pow2(int m) { return m != PM_BV_MOD && m != PM_TAB_MOD && m != PM_LDS_TAB_MOD; }
+__host__ __device__ constexpr bool pm_lds(int m) { return m == PM_LDS_TAB || m == PM_LDS_TAB_MOD; }
+__host__ __device__ constexpr bool pm_tab(int m) { return m == PM_TAB || m == PM_TAB_SUM || m == PM_TAB_MOD || pm_lds(m); }
+
+// position of a hash in a filter whose size is not a power of two: hash % _size (bloomfilter.h:58,:66,:88)
+__device__ __forceinline__ uint64_t bf_pos_np(uint64_t h, const ClassifyParams &P)
+{
+  return P.mod_fast ? bf_pos_fastmod(h, P.mod_shift, P.mod_m, P.mod_c) : h % P.bf_bits;
+}
 
 // Per-wave staging area of a read (LDS in the fast kernel, a global scratch slice in the general
 // kernel).  The read's bases live at PACKED positions: mate 1 at [0, L1), mate 2 at [P2, P2+L2)
@@ -234,10 +245,10 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
                                              const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk,
                                              const uint32_t *lsum, const ReadMeta meta, const bool pre, const Raw8 pre_w, const Raw8 pre_q)
 {
-  constexpr bool POW2 = MODE != PM_BV_MOD;
+  constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool SUM = MODE == PM_BV_SUM || MODE == PM_TAB_SUM;
-  constexpr bool LSUM = MODE == PM_LDS_TAB;
-  constexpr bool TAB = MODE == PM_TAB || MODE == PM_TAB_SUM || MODE == PM_LDS_TAB;
+  constexpr bool LSUM = pm_lds(MODE);
+  constexpr bool TAB = pm_tab(MODE);
   // LAZY: with the summary in LDS a probe of a non-existent slot costs no memory traffic, so the
   // slot's existence and validity are only evaluated for the (few) probes that match in the table
   constexpr bool LAZY = FAST && LSUM;
@@ -348,8 +359,9 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
       const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
       const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
-      // (LDS-summary mode keeps the raw hash: every use below masks the bits it needs)
-      pos[j] = LAZY ? xxh64_u64(canon) : bf_pos<POW2>(xxh64_u64(canon), P.bf_bits, P.bf_mask);
+      // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+      const uint64_t hsh = xxh64_u64(canon);
+      pos[j] = POW2 ? (LAZY ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
       ok[j] = LAZY ? true : ((FAST || t < ns) && slot_ok(pp));
     }
     if (!FAST && P.work_counters) {
@@ -714,12 +726,12 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
 // ---------------------------------------------------------------------------
 template <int MODE, int U>
 struct FastGeom {
-  static constexpr int WAVES = MODE == PM_LDS_TAB ? 8 : CF_WAVES;   // 512-thread workgroups share one LDS summary
+  static constexpr int WAVES = pm_lds(MODE) ? 8 : CF_WAVES;   // 512-thread workgroups share one LDS summary
   static constexpr int THREADS = WAVES * 64;
   // LDS-summary mode: four 512-thread workgroups per CU (4 x 34 KiB of LDS) = 8 waves per SIMD, which
   // needs <= 64 VGPRs; the specialisations for more than 320 slots do not fit that and run 6 waves
-  static constexpr int MIN_WAVES_PER_SIMD = MODE == PM_LDS_TAB ? (U <= 5 ? 8 : 6) : ((MODE == PM_TAB || MODE == PM_TAB_SUM) && U <= 5 ? 8 : 1);
-  static constexpr uint32_t SUM_WORDS64 = MODE == PM_LDS_TAB ? LDS_SUM_BITS / 64 : 0;
+  static constexpr int MIN_WAVES_PER_SIMD = pm_lds(MODE) ? (U <= 5 ? 8 : 6) : ((MODE == PM_TAB || MODE == PM_TAB_SUM || MODE == PM_TAB_MOD) && U <= 5 ? 8 : 1);
+  static constexpr uint32_t SUM_WORDS64 = pm_lds(MODE) ? LDS_SUM_BITS / 64 : 0;
 };
 
 template <int U, int MODE, bool HASQ>
@@ -732,7 +744,7 @@ __global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::M
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t *lsum = nullptr;
-  if (MODE == PM_LDS_TAB) {
+  if (pm_lds(MODE)) {
     // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -900,15 +912,16 @@ uint32_t fast_kernel_unroll(uint32_t max_slots)
 
 static int probe_mode(const DeviceIndex &ix)
 {
+  if (ix.tab_lg && ix.lsum_shift) return ix.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
+  if (ix.tab_lg) return ix.pow2 ? (ix.tab_with_summary ? PM_TAB_SUM : PM_TAB) : PM_TAB_MOD;
   if (!ix.pow2) return PM_BV_MOD;
-  if (ix.tab_lg && ix.lsum_shift) return PM_LDS_TAB;
-  if (ix.tab_lg) return ix.tab_with_summary ? PM_TAB_SUM : PM_TAB;
   return ix.sum_shift ? PM_BV_SUM : PM_BV;
 }
 
 const char *probe_mode_name(const Ctx *ctx)
 {
-  static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table"};
+  static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table",
+                                "table-mod", "lds-summary+table-mod"};
   return names[probe_mode(ctx->idx)];
 }
 
@@ -922,6 +935,8 @@ static void launch_fast_u(const ClassifyParams &p, int mode, bool hasq, unsigned
   case PM_BV_SUM: if (hasq) LF(PM_BV_SUM, true); else LF(PM_BV_SUM, false); break;
   case PM_TAB: if (hasq) LF(PM_TAB, true); else LF(PM_TAB, false); break;
   case PM_LDS_TAB: if (hasq) LF(PM_LDS_TAB, true); else LF(PM_LDS_TAB, false); break;
+  case PM_TAB_MOD: if (hasq) LF(PM_TAB_MOD, true); else LF(PM_TAB_MOD, false); break;
+  case PM_LDS_TAB_MOD: if (hasq) LF(PM_LDS_TAB_MOD, true); else LF(PM_LDS_TAB_MOD, false); break;
   default: if (hasq) LF(PM_TAB_SUM, true); else LF(PM_TAB_SUM, false); break;
   }
 #undef LF
@@ -934,9 +949,9 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   const int mode = probe_mode(ctx->idx);
   // persistent grid: enough workgroups to fill 256 CUs several times over
   // persistent workgroups; the LDS-summary mode runs 2 x 1024-thread workgroups per CU
-  const uint64_t wpb = mode == PM_LDS_TAB ? 8 : CF_WAVES;
+  const uint64_t wpb = pm_lds(mode) ? 8 : CF_WAVES;
   const uint32_t u = fast_kernel_unroll(max_slots);
-  const uint64_t cap = mode == PM_LDS_TAB ? (u <= 5 ? 1024 : 768) : 4096;   // LDS mode: exactly the resident workgroups
+  const uint64_t cap = pm_lds(mode) ? (u <= 5 ? 1024 : 768) : 4096;   // LDS mode: exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   if (u == 2) launch_fast_u<2>(p, mode, hasq, grid, stream);

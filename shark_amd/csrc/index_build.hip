@@ -341,7 +341,7 @@ int build_index(Ctx *ctx)
   ix.tab_lg = 0;
   uint64_t table_bytes = 0;
   const char *force = getenv("SHK_PROBE");   // "bitvector" disables the table (tests exercise both paths)
-  if (ix.pow2 && n_set > 0 && !(force && force[0] == 'b')) {
+  if (n_set > 0 && !(force && force[0] == 'b')) {   // (any filter size: buckets and tags are cut from the position, not from the hash)
     uint32_t lgB = 0;
     while ((1ull << lgB) < ix.bf_bits) ++lgB;
     uint32_t lg = 9;                                        // >= 512 buckets

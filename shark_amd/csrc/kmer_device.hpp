@@ -129,6 +129,21 @@ __device__ __forceinline__ uint64_t bf_pos(uint64_t h, uint64_t bits, uint64_t m
   else return h % bits;
 }
 
+// hash % bits for bits = m * 2^s with s >= 32 and m < 2^32 -- every `-b` size of the CLI is a multiple of
+// 2^33 bits (argument_parser.hpp:150).  h % (m 2^s) = ((h >> s) % m) << s | (h mod 2^s), and the quotient
+// q = h >> s fits 32 bits, so the inner remainder is Lemire's direct computation (Faster Remainder by
+// Direct Computation, 2019): c = floor((2^64-1)/m) + 1, r = ((c*q mod 2^64) * m) >> 64 -- exact for all
+// 32-bit q and m; four multiply instructions instead of a 64-bit division loop.
+__device__ __forceinline__ uint64_t bf_pos_fastmod(uint64_t h, uint32_t s, uint32_t m, uint64_t c)
+{
+  const uint32_t q = (uint32_t)(h >> s);
+  const uint64_t lowbits = c * (uint64_t)q;
+  const uint64_t p0 = (uint64_t)(uint32_t)lowbits * m;
+  const uint64_t p1 = (uint64_t)(uint32_t)(lowbits >> 32) * m + (p0 >> 32);
+  const uint32_t r = (uint32_t)(p1 >> 32);
+  return ((uint64_t)r << s) | (h & ((1ull << s) - 1ull));
+}
+
 // rank of a set bit = number of ones in [0,pos) (bloomfilter.h:70 _brank(bf_idx);
 // :90 uses rank(pos+1), 1-based -- the same list).  One directory word per
 // 64-bit filter word, so the word that was probed is all that is needed.

@@ -63,7 +63,16 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   p.tab = ix.tab_lg ? ix.tab : nullptr; p.tab_lg = ix.tab_lg;
   p.tab_nt = ix.tab_lg && (16ull << ix.tab_lg) > (256ull << 20);   // beyond L2 + Infinity Cache
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
-  p.bf_bits = ix.bf_bits; p.bf_mask = ix.bf_bits - 1;
+  p.bf_bits = ix.bf_bits;
+  p.bf_mask = ix.pow2 ? ix.bf_bits - 1 : ~0ull;   // (non power-of-two: positions are reduced explicitly, the masks become no-ops)
+  if (!ix.pow2) {
+    const uint32_t s = (uint32_t)__builtin_ctzll(ix.bf_bits);
+    const uint64_t m = ix.bf_bits >> s;
+    p.mod_shift = s;
+    p.mod_fast = s >= 32 && m < (1ull << 32);
+    p.mod_m = p.mod_fast ? (uint32_t)m : 0;
+    p.mod_c = p.mod_fast ? 0xFFFFFFFFFFFFFFFFull / m + 1 : 0;
+  }
   p.k = ctx->prm.k; p.c = ctx->prm.c; p.single = ctx->prm.single;
   p.mq = ctx->prm.min_quality ? ctx->prm.min_quality + 33 : 0;  // FastqSplitter.hpp:70
   p.n = n;

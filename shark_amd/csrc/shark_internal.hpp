@@ -98,6 +98,9 @@ struct ClassifyParams {
   const uint64_t *tab;
   uint32_t tab_lg;
   uint32_t tab_nt;           // 1 = table far larger than the caches: probe it with non-temporal loads
+  // non power-of-two filter sizes: bits = mod_m << mod_shift; mod_fast = the 32-bit direct remainder applies
+  uint32_t mod_fast, mod_shift, mod_m;
+  uint64_t mod_c;
   const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
   uint32_t lsum_shift;
   uint64_t bf_bits;

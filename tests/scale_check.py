@@ -13,6 +13,7 @@ from shark_amd.capi import hip_memcpy_dtoh
 ap = argparse.ArgumentParser()
 ap.add_argument("--genes", type=int, default=60000)
 ap.add_argument("--bf-log2", type=int, default=36)
+ap.add_argument("--bf-bits", type=int, default=0, help="exact filter size in bits (overrides --bf-log2; e.g. 3<<33 for `-b 3`)")
 ap.add_argument("--pairs", type=int, default=10_000_000)
 ap.add_argument("--k", type=int, default=17)
 ap.add_argument("--q", type=int, default=0)
@@ -21,6 +22,7 @@ ap.add_argument("--oracle-pairs", type=int, default=200000)
 ap.add_argument("--skip-bitvector", action="store_true")
 a = ap.parse_args()
 
+BF_BITS = a.bf_bits if a.bf_bits else 1 << a.bf_log2
 rng = np.random.default_rng(synth.SEED)
 lens = np.clip(np.exp(rng.normal(np.log(2000), 0.9, size=a.genes)), 200, 20000).astype(np.int64)
 genes = synth.make_reference(a.genes, lens)
@@ -39,7 +41,7 @@ for mode in (["auto"] if a.skip_bitvector else ["auto", "bitvector"]):
     else:
         os.environ.pop("SHK_PROBE", None)
     t0 = time.time()
-    h = SharkHip(k=a.k, c=0.6, bf_bits=1 << a.bf_log2, min_quality=a.q, single=a.single)
+    h = SharkHip(k=a.k, c=0.6, bf_bits=BF_BITS, min_quality=a.q, single=a.single)
     info = h.build([g.tobytes() for g in genes])
     tb = time.time() - t0
     h.timing_enable(True)
@@ -60,7 +62,7 @@ if len(res) == 2:
 if a.oracle_pairs:
     from oracle import pyoracle
     t0 = time.time()
-    o = pyoracle.Shark(k=a.k, c=0.6, bf_bits=1 << a.bf_log2, min_quality=a.q, single=a.single)
+    o = pyoracle.Shark(k=a.k, c=0.6, bf_bits=BF_BITS, min_quality=a.q, single=a.single)
     o.build([g.tobytes() for g in genes])
     print("oracle index built in %.1f s (%d set bits)" % (time.time() - t0, o.num_kmer()), flush=True)
     hb = synth.to_host_sample(batch, a.oracle_pairs)

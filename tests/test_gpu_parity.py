@@ -116,10 +116,11 @@ def test_synthetic_parity(oracle, probe, k, bf_bits, paired, read_len):
     rng = np.random.default_rng(1234 + k)
     genes = synth.make_genes(rng, 40, 100, 1500, share_every=4)
     o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits)
-    if probe == "bitvector" or bf_bits & (bf_bits - 1):
+    if probe == "bitvector":
         assert "table" not in h.probe_mode()
     else:
         assert "table" in h.probe_mode()
+        assert h.probe_mode().endswith("-mod") == bool(bf_bits & (bf_bits - 1))
     _compare_index(o, h, info)
     batch = synth.make_reads(rng, genes, 3000, read_len=read_len, paired=paired, on_target=0.6,
                              n_rate=0.01, lower_rate=0.05, var_len=True)
@@ -545,3 +546,17 @@ def test_packed_position_edges(oracle, k):
     batch = synth.batch_from_lists([m1[i] for i in order], [m2[i] for i in order])
     goff, _ = _compare_classify(o, h, batch)
     assert goff[-1] > len(m1) // 3
+
+
+@pytest.mark.gpu
+def test_cli_filter_size_not_a_power_of_two(oracle):
+    """`-b 3` = 3 * 2^33 bits: position = hash % size through the direct 32-bit remainder
+    (h = q 2^s + r, pos = (q % m) 2^s + r); here 3 * 2^32 bits keeps the oracle's filter at 1.5 GiB"""
+    rng = np.random.default_rng(4242)
+    genes = synth.make_genes(rng, 30, 300, 2000, share_every=3)
+    o, h, info = _build_both(oracle, genes, k=17, bf_bits=3 << 32)
+    assert h.probe_mode() in ("table-mod", "lds-summary+table-mod")
+    _compare_index(o, h, info)
+    batch = synth.make_reads(rng, genes, 4000, read_len=150, paired=True, on_target=0.5, n_rate=0.005)
+    goff, _ = _compare_classify(o, h, batch)
+    assert goff[-1] > 1000
