@@ -121,14 +121,6 @@ __device__ __forceinline__ uint64_t canonical_from_top(uint64_t top, uint32_t k)
   return fw < rc ? fw : rc;
 }
 
-// position of a hash in the filter: hash % _size (bloomfilter.h:58,:66,:88)
-template <bool POW2>
-__device__ __forceinline__ uint64_t bf_pos(uint64_t h, uint64_t bits, uint64_t mask)
-{
-  if constexpr (POW2) return h & mask;
-  else return h % bits;
-}
-
 // hash % bits for bits = m * 2^s with s >= 32 and m < 2^32 -- every `-b` size of the CLI is a multiple of
 // 2^33 bits (argument_parser.hpp:150).  h % (m 2^s) = ((h >> s) % m) << s | (h mod 2^s), and the quotient
 // q = h >> s fits 32 bits, so the inner remainder is Lemire's direct computation (Faster Remainder by
