@@ -158,9 +158,15 @@ def main():
         from shark_amd.capi import hip_memcpy_dtoh
         hip_memcpy_dtoh(goff, res.gene_off, (ns + 1) * 4)
         parity = bool(np.array_equal(goff, ogoff))
+        # one thread on one reference chunk (SURVEY 8d asks for -t 1 next to all cores)
+        n1 = min(ns, 50000)
+        t0 = time.perf_counter()
+        o.classify(hb["seq1"][:int(hb["off1"][n1])], hb["off1"][:n1 + 1], hb["seq2"][:int(hb["off2"][n1])], hb["off2"][:n1 + 1], nthreads=1)
+        t1 = time.perf_counter() - t0
         cpu = {"value": round(2 * ns / tc, 1), "unit": "reads/s", "cores": cores, "kind": "port",
                "sample": "first %d pairs of the same batch, %d threads x 50 000-read chunks (main.cpp:215), %.1f s" % (ns, cores, tc),
-               "parity_with_gpu": parity}
+               "parity_with_gpu": parity,
+               "one_thread": {"value": round(2 * n1 / t1, 1), "unit": "reads/s", "sample": "first %d pairs, %.1f s" % (n1, t1)}}
         o.close()
 
     out = {
