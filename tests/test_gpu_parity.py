@@ -549,12 +549,13 @@ def test_packed_position_edges(oracle, k):
 
 
 @pytest.mark.gpu
-def test_cli_filter_size_not_a_power_of_two(oracle):
+@pytest.mark.parametrize("bf_bits", [3 << 32, 5 << 32, 7 << 33])
+def test_cli_filter_size_not_a_power_of_two(oracle, bf_bits):
     """`-b 3` = 3 * 2^33 bits: position = hash % size through the direct 32-bit remainder
-    (h = q 2^s + r, pos = (q % m) 2^s + r); here 3 * 2^32 bits keeps the oracle's filter at 1.5 GiB"""
+    (h = q 2^s + r, pos = (q % m) 2^s + r); sizes from 1.5 GiB (oracle memory) to `-b 7`"""
     rng = np.random.default_rng(4242)
     genes = synth.make_genes(rng, 30, 300, 2000, share_every=3)
-    o, h, info = _build_both(oracle, genes, k=17, bf_bits=3 << 32)
+    o, h, info = _build_both(oracle, genes, k=17, bf_bits=bf_bits)
     assert h.probe_mode() in ("table-mod", "lds-summary+table-mod")
     _compare_index(o, h, info)
     batch = synth.make_reads(rng, genes, 4000, read_len=150, paired=True, on_target=0.5, n_rate=0.005)
