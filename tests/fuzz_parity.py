@@ -20,10 +20,13 @@ for it in range(iters):
     seed = seed0 + it
     rng = np.random.default_rng(seed)
     k = int(rng.choice([1, 2, 5, 11, 16, 17, 18, 21, 25, 31, int(rng.integers(1, 32))]))
-    if rng.random() < 0.7:
+    u = rng.random()
+    if u < 0.69:
         bf_bits = 1 << int(rng.integers(8, 30))
-    else:
+    elif u < 0.99:
         bf_bits = int(rng.integers(300, 1 << 22))
+    else:
+        bf_bits = int(rng.choice([3, 5, 6, 7])) << 32      # direct-remainder positions (1.5 - 3.5 GiB filters)
     n_genes = int(rng.choice([1, 2, 7, 40, 300]))
     gl = int(rng.choice([60, 400, 2500]))
     genes = synth.make_genes(rng, n_genes, max(20, gl // 3), gl, share_every=int(rng.choice([0, 2, 5])))
