@@ -8,15 +8,18 @@
 // How the reference's serial loop is re-expressed:
 //  * k-mer slots.  The rolling walk with restart-on-invalid (ReadAnalyzer.hpp
 //    :51-77, kmer_utils.hpp:57-71) visits exactly the k-mers whose k
-//    characters are all valid.  Slot t < nk1 is the k-mer starting at base t of
-//    mate 1, slot t >= nk1 the one starting at base t-nk1 of mate 2 (nk_m =
-//    max(0, L_m-k+1)).  The joiner 'N' (FastqSplitter.hpp:63) is invalid, so no
-//    k-mer spans the mates and the two mates are just two slot ranges.
+//    characters are all valid.  The mates are laid out at packed positions
+//    (mate 1 at 0, mate 2 at P2 = L1 rounded up to 8); slot pp is the k-mer
+//    starting at packed position pp and exists for pp < nk1 or 0 <= pp-P2 < nk2
+//    (nk_m = max(0, L_m-k+1)).  The joiner 'N' (FastqSplitter.hpp:63) is
+//    invalid, so no k-mer spans the mates and the two mates are two slot ranges.
 //  * per-gene coverage.  For a gene g with hit end positions p0<p1<..., the
 //    reference accumulates cov = k + sum min(k, p_j - p_{j-1}), nk = #hits
 //    (ReadAnalyzer.hpp:56-62,:79-86; a fresh map entry is ((0,0),0) and its
 //    first increment is min(k, pos-0) = k).  Hits in different mates are more
-//    than k apart in joined coordinates, so the min clamps to k there.
+//    than k apart in joined coordinates, so the min clamps to k there -- and at
+//    least k apart in packed positions.  cov is the size of the union of the
+//    intervals [p_j, p_j + k), which is how the kernel counts it.
 //  * gene order.  Every set bit's list is ascending and duplicate free
 //    (bloomfilter.h:68-74), so a k-way merge over the lists of all hit slots
 //    visits genes in ascending id order -- the std::map iteration order used by
@@ -24,13 +27,13 @@
 //  * threshold.  `max >= c*len` is evaluated in double exactly as written
 //    (ReadAnalyzer.hpp:104); gfx950 has IEEE fp64 multiply/compare.
 //
-// Data path per read: 8 bases per lane are loaded with one (unaligned) 8-byte
-// global load, classified with SWAR, and written to LDS as a 2-bit packed
-// big-endian code stream plus a 1-bit validity stream.  Every lane then cuts
-// its k-mers out of LDS with two 64-bit reads and a funnel shift, hashes them
-// (XXH64, 5 64-bit multiplies) and issues all its filter probes before the
-// first wait.  `__ballot` of the hit flags ends the read immediately when no
-// probe hit -- the common case for off-target reads.
+// Data path per read: 8 bases per lane are loaded as aligned dwords (prefetched one read ahead),
+// classified with SWAR, and written to LDS as two streams of 2-bit codes (forward and mirrored)
+// plus a 1-bit validity stream.  Every lane then cuts both orientations of its k-mers out of LDS
+// with v_alignbit_b32, hashes the canonical one (XXH64, 15 integer multiplies) and issues all its
+// probes before the first wait.  `__ballot` of the pass / hit flags ends the read immediately when
+// nothing hit -- the common case for off-target reads.  DESIGN.md 3 has the full description and
+// what bounds the kernel.
 #include <hip/hip_runtime.h>
 
 #include "kmer_device.hpp"
