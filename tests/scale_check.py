@@ -16,6 +16,7 @@ ap.add_argument("--bf-log2", type=int, default=36)
 ap.add_argument("--bf-bits", type=int, default=0, help="exact filter size in bits (overrides --bf-log2; e.g. 3<<33 for `-b 3`)")
 ap.add_argument("--pairs", type=int, default=10_000_000)
 ap.add_argument("--k", type=int, default=17)
+ap.add_argument("--read-len", type=int, default=150)
 ap.add_argument("--q", type=int, default=0)
 ap.add_argument("--single", action="store_true")
 ap.add_argument("--oracle-pairs", type=int, default=200000)
@@ -31,7 +32,7 @@ for g in range(9, a.genes, 10):          # every 10th gene shares its first half
     genes[g][:h] = genes[g - 1][:h]
 print("reference: %d genes, %.3e bases" % (a.genes, float(lens.sum())), flush=True)
 dev = torch.device("cuda:0")
-batch = synth.make_pairs_device(a.pairs, genes, dev, seed=synth.SEED + 7, with_qual=a.q > 0)
+batch = synth.make_pairs_device(a.pairs, genes, dev, seed=synth.SEED + 7, read_len=a.read_len, with_qual=a.q > 0)
 torch.cuda.synchronize()
 ptr = {k: (v.data_ptr() if v is not None else 0) for k, v in batch.items()}
 res = {}
@@ -46,7 +47,7 @@ for mode in (["auto"] if a.skip_bitvector else ["auto", "bitvector"]):
     tb = time.time() - t0
     h.timing_enable(True)
     for _ in range(3):
-        r = h.classify_device(a.pairs, ptr["seq1"], ptr["off1"], ptr["seq2"], ptr["off2"], ptr["qual1"], ptr["qual2"], max_read_len=150)
+        r = h.classify_device(a.pairs, ptr["seq1"], ptr["off1"], ptr["seq2"], ptr["off2"], ptr["qual1"], ptr["qual2"], max_read_len=a.read_len)
     tm = h.timing()
     goff = np.empty(a.pairs + 1, np.uint32); hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
     gids = np.empty(int(r.n_assoc), np.uint16); hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
@@ -65,7 +66,7 @@ if a.oracle_pairs:
     o = pyoracle.Shark(k=a.k, c=0.6, bf_bits=BF_BITS, min_quality=a.q, single=a.single)
     o.build([g.tobytes() for g in genes])
     print("oracle index built in %.1f s (%d set bits)" % (time.time() - t0, o.num_kmer()), flush=True)
-    hb = synth.to_host_sample(batch, a.oracle_pairs)
+    hb = synth.to_host_sample(batch, a.oracle_pairs, a.read_len)
     t0 = time.time()
     og, oi = o.classify(hb["seq1"], hb["off1"], hb["seq2"], hb["off2"], hb["qual1"], hb["qual2"], nthreads=os.cpu_count())
     goff, gids = res["auto"]
