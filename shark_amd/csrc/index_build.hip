@@ -364,7 +364,7 @@ int build_index(Ctx *ctx)
       (void)hipFree(d_fail);
       if (h_fail == 0) {
         ix.tab_lg = lg;
-        // small indices: a 2^19-bit summary that the table kernel keeps in LDS answers
+        // small indices: a 2^18-bit summary that the table kernel keeps in LDS answers
         // almost every miss without touching the memory system (same proof as sum32)
         ix.lsum_shift = 0;
         if (lgB > LDS_SUM_LOG2 && !getenv("SHK_NO_LDS_SUMMARY")) {

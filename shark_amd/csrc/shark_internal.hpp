@@ -60,7 +60,7 @@ struct DeviceIndex {
   uint32_t *sum32 = nullptr;
   uint32_t sum_shift = 0;    // 0 = no summary level
   uint64_t sum_bits = 0;
-  uint32_t *lsum32 = nullptr; // 2^19-bit summary staged into LDS by the table kernel (small indices only)
+  uint32_t *lsum32 = nullptr; // 2^18-bit summary staged into LDS by the table kernel (small indices only)
   uint32_t lsum_shift = 0;    // 0 = not used
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
