@@ -48,7 +48,8 @@ typedef struct shk_params {
   uint32_t k;            /* -k, default 17, range [1,31]      (:56, :112-121) */
   double   c;            /* -c, default 0.6, range [0,1]      (:57, :122-129) */
   uint64_t bf_bits;      /* filter size in BITS; -b N => N<<33 (:58, :130-134) */
-  int32_t  min_quality;  /* -q, 0 = no masking, max 94        (:59, :135-145) */
+  int32_t  min_quality;  /* -q, 0 = no masking; any value >= 0: stored as the reference's `char`
+                            (:59, :135-145), so -q > 94 wraps exactly as it does there          */
   int32_t  single;       /* -s                                 (:60, :146-148) */
   int32_t  device;       /* HIP device ordinal */
 } shk_params;
@@ -130,8 +131,23 @@ typedef struct shk_result {
 } shk_result;
 
 /* ReadAnalyzer::operator()(const vector<elem_t>&, vector<assoc_t>&) const
- * ReadAnalyzer.hpp:39-110 over host buffers (H2D, kernels, D2H). */
+ * ReadAnalyzer.hpp:39-110 over host buffers (H2D, kernels, D2H): submit + wait of one batch. */
 int shk_classify(shk_ctx *ctx, const shk_batch *batch, shk_result *result);
+
+/* The same as a pipeline, for callers that stream batches -- the reference overlaps split / analyze /
+ * output across its worker threads (main.cpp:66-77, :219-223); here up to SHK_PIPE_DEPTH batches are in
+ * flight per context: while the caller waits for batch i, the H2D copies of batches i+1.. overlap the
+ * kernels of batch i on separate HIP streams, and no step in between waits for the host.
+ *   submit: reads `batch` (host buffers; pinned memory from shk_alloc_pinned makes the copies truly
+ *           asynchronous), enqueues everything and returns a ticket.  The host buffers must stay
+ *           untouched until the ticket has been waited for.  SHK_ERR_STATE when SHK_PIPE_DEPTH
+ *           tickets are outstanding.
+ *   wait  : blocks until that batch is classified and returns its associations in pinned host
+ *           buffers owned by the context; they stay valid until SHK_PIPE_DEPTH further submits.
+ * Tickets must be waited for in the order they were submitted. */
+#define SHK_PIPE_DEPTH 3
+int shk_classify_submit(shk_ctx *ctx, const shk_batch *batch, uint64_t *ticket);
+int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result);
 
 /* Same, for inputs ALREADY RESIDENT IN HBM: every pointer in `batch` is a
  * device pointer; the result pointers returned in `result` are DEVICE
@@ -139,23 +155,32 @@ int shk_classify(shk_ctx *ctx, const shk_batch *batch, shk_result *result);
  * longest mate (0 = unknown); it only selects the kernel specialisation --
  * reads that do not fit are routed to the general kernel, never dropped.
  * Work is enqueued on the context's stream and the call returns after the
- * stream has drained. */
+ * stream has drained (one host synchronisation per call when max_read_len is given). */
 int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_len, shk_result *result);
 
-/* Per-gene number of assigned reads accumulated over all classify calls since
- * the last reset (counts[g] for g in [0, 65536)); the quantity all-reduced
+/* Per-gene number of assigned reads accumulated over all classify calls (all
+ * waited tickets) since the last reset (counts[g] for g in [0, 65536)); the quantity all-reduced
  * across GPUs.  n must be <= 65536. */
 int shk_gene_counts(shk_ctx *ctx, uint64_t *counts, uint32_t n);
 int shk_gene_counts_reset(shk_ctx *ctx);
 
-/* The path's one exchange step when the read stream is sharded over several GPUs of one node
- * (one context per GPU, index replicated, reads split by batch): all-reduce (sum) of the per-gene
- * counters of `n_ctx` contexts over RCCL (xGMI), leaving the totals in every context's device
- * counters and, if `totals` is not NULL, copying counts[0..n) of the result to the host.  RCCL is
- * loaded on first use (librccl.so.1); with one context and without SHK_FORCE_RCCL=1 in the
- * environment no collective is needed and none is issued.  New: the reference is single process
- * and has no counterpart (its per-read lines are merged by the output mutex, ReadOutput.hpp:38). */
+/* The path's one exchange step when the read stream is sharded over several GPUs of one node (index
+ * replicated, reads split): all-reduce (sum) of the per-gene counters over RCCL (xGMI).  New: the reference is
+ * single process and has no counterpart (its per-read lines are merged by the output mutex, ReadOutput.hpp:38).
+ * The totals land in a separate device buffer of every context; the per-GPU counters are left as they are, so
+ * the call can be repeated.  RCCL is loaded on first use (librccl.so.1) and the communicators are created once.
+ *
+ * (a) one process, one context per GPU (`shark --gpus N`): `n_ctx` contexts; with one context and without
+ *     SHK_FORCE_RCCL=1 in the environment no collective is needed and none is issued. */
 int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint32_t n);
+/* (b) one process per GPU (torch.distributed.run, mpirun): rank 0 calls shk_dist_unique_id, the launcher's own
+ *     channel carries the SHK_DIST_ID_BYTES bytes to every rank, every rank calls shk_dist_init with its context;
+ *     shk_dist_gene_counts_allreduce is then collective over the ranks (stream-ordered behind the classify calls
+ *     made so far) and returns counts[0..n) of the totals.  Without shk_dist_init it returns the local counters. */
+#define SHK_DIST_ID_BYTES 128
+int shk_dist_unique_id(uint8_t *id);
+int shk_dist_init(shk_ctx *ctx, const uint8_t *id, int rank, int world);
+int shk_dist_gene_counts_allreduce(shk_ctx *ctx, uint64_t *totals, uint32_t n);
 
 /* ---- measurement --------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel (classify) on the context's own

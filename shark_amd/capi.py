@@ -49,7 +49,10 @@ EXPORTS = [
     "shk_index_info_get", "shk_index_copy_bf", "shk_index_copy_lists", "shk_classify", "shk_classify_device",
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
     "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode", "shk_gene_counts_allreduce",
+    "shk_classify_submit", "shk_classify_wait", "shk_dist_unique_id", "shk_dist_init", "shk_dist_gene_counts_allreduce",
 ]
+SHK_PIPE_DEPTH = 3
+SHK_DIST_ID_BYTES = 128
 
 _lib = None
 
@@ -90,6 +93,11 @@ def load():
     L.shk_version.restype = C.c_char_p; L.shk_version.argtypes = []
     L.shk_probe_mode.restype = C.c_char_p; L.shk_probe_mode.argtypes = [p]
     L.shk_gene_counts_allreduce.restype = C.c_int; L.shk_gene_counts_allreduce.argtypes = [C.POINTER(p), C.c_int, p, C.c_uint32]
+    L.shk_classify_submit.restype = C.c_int; L.shk_classify_submit.argtypes = [p, C.POINTER(ShkBatch), C.POINTER(C.c_uint64)]
+    L.shk_classify_wait.restype = C.c_int; L.shk_classify_wait.argtypes = [p, C.c_uint64, C.POINTER(ShkResult)]
+    L.shk_dist_unique_id.restype = C.c_int; L.shk_dist_unique_id.argtypes = [p]
+    L.shk_dist_init.restype = C.c_int; L.shk_dist_init.argtypes = [p, p, C.c_int, C.c_int]
+    L.shk_dist_gene_counts_allreduce.restype = C.c_int; L.shk_dist_gene_counts_allreduce.argtypes = [p, p, C.c_uint32]
     _lib = L
     return L
 
@@ -170,22 +178,39 @@ class SharkHip:
         return off, ids[:info["tot_idx"]]
 
     # ---- classification --------------------------------------------------------
-    def classify(self, seq1, off1, seq2=None, off2=None, qual1=None, qual2=None):
-        """host SoA batch -> (gene_off[n+1] u32, gene_ids u16)"""
+    def _host_batch(self, seq1, off1, seq2, off2, qual1, qual2):
         seq1, seq2, qual1, qual2 = _u8(seq1), _u8(seq2), _u8(qual1), _u8(qual2)
         off1 = np.ascontiguousarray(off1, dtype=np.uint64)
         off2 = np.ascontiguousarray(off2, dtype=np.uint64) if off2 is not None else None
         n = len(off1) - 1
-        b = ShkBatch(n, _ptr(seq1), _ptr(off1), _ptr(seq2), _ptr(off2), _ptr(qual1), _ptr(qual2))
+        keep = (seq1, off1, seq2, off2, qual1, qual2)      # the library reads them until the ticket is waited for
+        return ShkBatch(n, _ptr(seq1), _ptr(off1), _ptr(seq2), _ptr(off2), _ptr(qual1), _ptr(qual2)), keep
+
+    @staticmethod
+    def _host_result(r, copy=True):
+        n, tot = int(r.n), int(r.n_assoc)
+        gene_off = np.ctypeslib.as_array(C.cast(r.gene_off, C.POINTER(C.c_uint32)), shape=(n + 1,))
+        ids = np.ctypeslib.as_array(C.cast(r.gene_ids, C.POINTER(C.c_uint16)), shape=(tot,)) if tot else np.zeros(0, np.uint16)
+        return (gene_off.copy(), ids.copy()) if copy else (gene_off, ids)
+
+    def classify(self, seq1, off1, seq2=None, off2=None, qual1=None, qual2=None):
+        """host SoA batch -> (gene_off[n+1] u32, gene_ids u16)"""
+        b, keep = self._host_batch(seq1, off1, seq2, off2, qual1, qual2)
         r = ShkResult()
         self._check(self.L.shk_classify(self.h, C.byref(b), C.byref(r)), "shk_classify")
-        gene_off = np.ctypeslib.as_array(C.cast(r.gene_off, C.POINTER(C.c_uint32)), shape=(n + 1,)).copy()
-        tot = int(r.n_assoc)
-        if tot:
-            ids = np.ctypeslib.as_array(C.cast(r.gene_ids, C.POINTER(C.c_uint16)), shape=(tot,)).copy()
-        else:
-            ids = np.zeros(0, np.uint16)
-        return gene_off, ids
+        return self._host_result(r)
+
+    def submit(self, seq1, off1, seq2=None, off2=None, qual1=None, qual2=None):
+        """pipelined form: returns a ticket (an object that also keeps the host arrays alive)"""
+        b, keep = self._host_batch(seq1, off1, seq2, off2, qual1, qual2)
+        t = C.c_uint64()
+        self._check(self.L.shk_classify_submit(self.h, C.byref(b), C.byref(t)), "shk_classify_submit")
+        return (t.value, keep)
+
+    def wait(self, ticket, copy=True):
+        r = ShkResult()
+        self._check(self.L.shk_classify_wait(self.h, ticket[0], C.byref(r)), "shk_classify_wait")
+        return self._host_result(r, copy)
 
     def classify_device(self, n, seq1, off1, seq2=0, off2=0, qual1=0, qual2=0, max_read_len=0):
         """device pointers (ints) -> ShkResult with DEVICE pointers"""
@@ -215,6 +240,41 @@ class SharkHip:
 
     def gene_counts_reset(self):
         self._check(self.L.shk_gene_counts_reset(self.h), "shk_gene_counts_reset")
+
+    # ---- one process per GPU ------------------------------------------------------
+    def dist_init(self, sdist):
+        """join the RCCL communicator of a torch.distributed job (shark_amd.dist): rank 0's unique id is
+        broadcast over the job's own channel.  A gloo job (CPU tests, single-GPU dry runs) has no RCCL
+        communicator; dist_gene_counts_allreduce then reduces the local counters over gloo."""
+        import torch
+        import torch.distributed as td
+        self._td = None
+        if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+            return
+        if td.get_backend() != "nccl":
+            self._td = td
+            return
+        rank, world = td.get_rank(), td.get_world_size()
+        buf = (C.c_uint8 * SHK_DIST_ID_BYTES)()
+        if rank == 0:
+            rc = self.L.shk_dist_unique_id(buf)
+            if rc != 0:
+                raise SharkHipError("shk_dist_unique_id: %s" % self.L.shk_strerror(rc).decode())
+        t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
+        td.broadcast(t, 0)
+        ident = (C.c_uint8 * SHK_DIST_ID_BYTES)(*t.cpu().tolist())
+        self._check(self.L.shk_dist_init(self.h, ident, rank, world), "shk_dist_init")
+
+    def dist_gene_counts_allreduce(self, n=65536):
+        a = np.zeros(n, dtype=np.uint64)
+        self._check(self.L.shk_dist_gene_counts_allreduce(self.h, _ptr(a), n), "shk_dist_gene_counts_allreduce")
+        td = getattr(self, "_td", None)
+        if td is not None:
+            import torch
+            t = torch.from_numpy(a.astype(np.int64))
+            td.all_reduce(t)
+            a = t.numpy().astype(np.uint64)
+        return a
 
     def timing_enable(self, on=True):
         self._check(self.L.shk_timing_enable(self.h, int(on)), "shk_timing_enable")

@@ -677,10 +677,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       }
       if (EMIT) {
         if (cov == tie_cov && nk == tie_nk) {
-          if (lane == 0) {
-            P.gene_ids[out_base + n_emit] = (uint16_t)g;
-            if (P.gene_counts) atomicAdd(&P.gene_counts[g & 0xFFFFu], 1ull);
-          }
+          if (lane == 0) P.gene_ids[out_base + n_emit] = (uint16_t)g;
           ++n_emit;
         }
       } else {
@@ -824,7 +821,10 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
   st.rec_end = st.rec_start + S;
   st.cur = st.rec_end + S;
   const uint64_t stride = (uint64_t)gridDim.x * CF_WAVES;
-  for (uint64_t w = gw; w < P.n_work; w += stride) {
+  // the number of queued items may only be known on the device (tie queue: no host round trip)
+  const uint64_t n_work = P.work_count ? (uint64_t)__builtin_amdgcn_readfirstlane(*P.work_count) : P.n_work;
+  if (EMIT && P.flags && P.flags[CTR_OVERFLOW]) return;   // gene_ids too small: the host grows it and relaunches
+  for (uint64_t w = gw; w < n_work; w += stride) {
     uint64_t read = w;
     uint32_t tc = 0, tn = 0;
     if (EMIT) {
@@ -838,17 +838,48 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
   }
 }
 
-// copy the inline ids of reads with 1..SHK_INLINE_IDS genes into the CSR result
-// and count assigned reads per gene.  Gene counters are hot (one gene can own
-// most reads) and same-address global atomics serialise at ~12 ns each, so the
-// counts are combined twice before they reach HBM: equal genes inside a wave
-// by ballot, then per workgroup in an LDS hash table that is flushed once.
+// copy the inline ids of reads with 1..SHK_INLINE_IDS genes into the CSR result (reads with more
+// genes are written by the general kernel in EMIT mode)
 constexpr int GI_THREADS = 256;
-constexpr uint32_t GI_TABLE = 2048;   // LDS histogram slots per workgroup
 __global__ __launch_bounds__(GI_THREADS) void gather_inline_kernel(const uint32_t *__restrict__ count, const uint16_t *__restrict__ inl,
                                                                    const uint32_t *__restrict__ gene_off, uint16_t *__restrict__ gene_ids, uint64_t n,
-                                                                   unsigned long long *__restrict__ gene_counts)
+                                                                   const uint32_t *__restrict__ flags)
 {
+  if (flags[CTR_OVERFLOW]) return;   // gene_ids too small for this batch: the host grows it and relaunches
+  for (uint64_t i = (uint64_t)blockIdx.x * GI_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * GI_THREADS) {
+    const uint32_t c = count[i];
+    if (c == 0 || c > SHK_INLINE_IDS) continue;
+    const uint32_t o = gene_off[i];
+    const uint2 v = *reinterpret_cast<const uint2 *>(inl + i * SHK_INLINE_IDS);
+    gene_ids[o] = (uint16_t)v.x;
+    if (c > 1) gene_ids[o + 1] = (uint16_t)(v.x >> 16);
+    if (c > 2) gene_ids[o + 2] = (uint16_t)v.y;
+    if (c > 3) gene_ids[o + 3] = (uint16_t)(v.y >> 16);
+  }
+}
+
+// the scan's 64-bit total -> counters (read by the host through pinned memory) + capacity check
+__global__ void finalize_total_kernel(const uint64_t *__restrict__ total, uint32_t *__restrict__ counters, uint64_t gene_ids_cap)
+{
+  const uint64_t t = *total;
+  counters[CTR_ASSOC_LO] = (uint32_t)t;
+  counters[CTR_ASSOC_HI] = (uint32_t)(t >> 32);
+  counters[CTR_OVERFLOW] = t > gene_ids_cap ? 1u : 0u;
+}
+
+// Per-gene number of assigned reads (the quantity all-reduced across GPUs): histogram of the batch's
+// final gene_ids.  Gene counters are hot (one gene can own most reads) and same-address global
+// atomics serialise at ~12 ns each, so the counts are combined twice before they reach HBM: equal
+// genes inside a wave by ballot, then per workgroup in an LDS hash table that is flushed once.
+// Runs once per batch, after every kernel that writes gene_ids; skipped when the batch has to be
+// finished by the host's slow path (overflow, or queued long reads the launch did not expect), which
+// then runs it itself -- so a batch is never counted twice.
+constexpr uint32_t GI_TABLE = 2048;   // LDS histogram slots per workgroup
+__global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *__restrict__ gene_ids, const uint32_t *__restrict__ counters,
+                                                               uint32_t skip_if_long, unsigned long long *__restrict__ gene_counts)
+{
+  if (counters[CTR_OVERFLOW] || (skip_if_long && counters[CTR_LONG])) return;
+  const uint64_t n = ((uint64_t)counters[CTR_ASSOC_HI] << 32) | counters[CTR_ASSOC_LO];
   __shared__ uint32_t h_key[GI_TABLE];
   __shared__ uint32_t h_cnt[GI_TABLE];
   for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS) { h_key[i] = 0xFFFFFFFFu; h_cnt[i] = 0; }
@@ -856,48 +887,39 @@ __global__ __launch_bounds__(GI_THREADS) void gather_inline_kernel(const uint32_
   const int lane = threadIdx.x & 63;
   const uint64_t n_round = (n + GI_THREADS - 1) / GI_THREADS * GI_THREADS;   // keep whole waves in the loop (ballots)
   for (uint64_t i = (uint64_t)blockIdx.x * GI_THREADS + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * GI_THREADS) {
-    uint32_t c = 0, o = 0;
-    if (i < n) {
-      c = count[i];
-      if (c > SHK_INLINE_IDS) c = 0;  // written (and counted) by the general kernel in EMIT mode
-      o = gene_off[i];
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < SHK_INLINE_IDS; ++j) {
-      const bool pending = j < c;
-      uint32_t g = 0;
-      if (pending) {
-        g = inl[i * SHK_INLINE_IDS + j];
-        gene_ids[o + j] = (uint16_t)g;
-      }
-      if (!gene_counts) continue;
-      unsigned long long todo = __ballot(pending);
-      while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const uint32_t lg = __shfl(g, leader, 64);
-        const unsigned long long same = __ballot(pending && g == lg);
-        if (lane == leader) {
-          const uint32_t add = (uint32_t)__builtin_popcountll(same);
-          uint32_t slot = (lg * 2654435761u) >> 21;   // 11 bits
-          bool done = false;
-          for (uint32_t probe = 0; probe < 16 && !done; ++probe) {
-            const uint32_t old = atomicCAS(&h_key[slot], 0xFFFFFFFFu, lg);
-            if (old == 0xFFFFFFFFu || old == lg) {
-              atomicAdd(&h_cnt[slot], add);
-              done = true;
-            }
-            slot = (slot + 1) & (GI_TABLE - 1);
+    const bool pending = i < n;
+    const uint32_t g = pending ? gene_ids[i] : 0u;
+    unsigned long long todo = __ballot(pending);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t lg = __shfl(g, leader, 64);
+      const unsigned long long same = __ballot(pending && g == lg);
+      if (lane == leader) {
+        const uint32_t add = (uint32_t)__builtin_popcountll(same);
+        uint32_t slot = (lg * 2654435761u) >> 21;   // 11 bits
+        bool done = false;
+        for (uint32_t probe = 0; probe < 16 && !done; ++probe) {
+          const uint32_t old = atomicCAS(&h_key[slot], 0xFFFFFFFFu, lg);
+          if (old == 0xFFFFFFFFu || old == lg) {
+            atomicAdd(&h_cnt[slot], add);
+            done = true;
           }
-          if (!done) atomicAdd(&gene_counts[lg], (unsigned long long)add);   // table crowded: straight to HBM
+          slot = (slot + 1) & (GI_TABLE - 1);
         }
-        todo &= ~same;
+        if (!done) atomicAdd(&gene_counts[lg], (unsigned long long)add);   // table crowded: straight to HBM
       }
+      todo &= ~same;
     }
   }
-  if (!gene_counts) return;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS)
     if (h_cnt[i]) atomicAdd(&gene_counts[h_key[i]], (unsigned long long)h_cnt[i]);
+}
+
+// off[i] = i * stride: batches whose reads all have one length need no offsets over PCIe
+__global__ void fill_offsets_kernel(uint64_t *__restrict__ off, uint64_t n_plus_1, uint64_t stride)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_plus_1; i += (uint64_t)gridDim.x * blockDim.x) off[i] = i * stride;
 }
 
 // ---------------------------------------------------------------------------
@@ -948,7 +970,7 @@ static void launch_fast_u(const ClassifyParams &p, int mode, bool hasq, unsigned
 int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
 {
   if (p.n == 0) return SHK_OK;
-  const bool hasq = p.mq != 0;
+  const bool hasq = p.hasq != 0;
   const int mode = probe_mode(ctx->idx);
   // persistent grid: enough workgroups to fill 256 CUs several times over
   // persistent workgroups; the LDS-summary mode runs 2 x 1024-thread workgroups per CU
@@ -969,8 +991,8 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
 
 int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream)
 {
-  if (p.n_work == 0) return SHK_OK;
-  const bool pow2 = ctx->idx.pow2, hasq = p.mq != 0;
+  if (p.n_work == 0 && !p.work_count) return SHK_OK;
+  const bool pow2 = ctx->idx.pow2, hasq = p.hasq != 0;
   const unsigned grid = (n_waves + CF_WAVES - 1) / CF_WAVES;
 #define LG(P2_, HQ_, EM_) hipLaunchKernelGGL((classify_general_kernel<P2_, HQ_, EM_>), dim3(grid), dim3(CF_THREADS), 0, stream, p)
   if (emit) {
@@ -986,11 +1008,33 @@ int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsign
 }
 
 int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n,
-                         unsigned long long *gene_counts, hipStream_t stream)
+                         const uint32_t *counters, hipStream_t stream)
 {
   if (n == 0) return SHK_OK;
   const uint64_t want = (n + GI_THREADS - 1) / GI_THREADS;
-  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(GI_THREADS), 0, stream, count, inl, gene_off, gene_ids, n, gene_counts);
+  hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(GI_THREADS), 0, stream, count, inl, gene_off, gene_ids, n, counters);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
+int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t gene_ids_cap, hipStream_t stream)
+{
+  hipLaunchKernelGGL(finalize_total_kernel, dim3(1), dim3(1), 0, stream, total, counters, gene_ids_cap);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
+int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, hipStream_t stream)
+{
+  // the number of associations is only known on the device; it is of the order of the number of reads
+  const uint64_t want = (n_reads + GI_THREADS - 1) / GI_THREADS;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024));
+  hipLaunchKernelGGL(gene_hist_kernel, dim3(grid), dim3(GI_THREADS), 0, stream, gene_ids, counters, skip_if_long ? 1u : 0u, gene_counts);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
+int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream)
+{
+  const uint64_t want = (n_plus_1 + 255) / 256;
+  hipLaunchKernelGGL(fill_offsets_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, off, n_plus_1, stride);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

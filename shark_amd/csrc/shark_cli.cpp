@@ -13,6 +13,7 @@
 // batches in input order (ReadOutput role).  Extra flags: --gpus N, --batch N.
 #include <getopt.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -69,7 +70,7 @@ struct Options {
   unsigned k = 17;
   double c = 0.6;
   uint64_t bf_size = (uint64_t)1 << 33;
-  char min_quality = 0;
+  int min_quality = 0;     // as typed; the library narrows it to the reference's `char` (argument_parser.hpp:144)
   bool single = false, verbose = false;
   int nThreads = 1;
   int gpus = 1;
@@ -77,95 +78,117 @@ struct Options {
   std::string gene_counts_path;
 };
 
+// The command line is described by one table: option names, whether a value follows, and a handler that
+// stores the value and applies that option's own check at once -- options are checked in the order they
+// appear, as the reference does (argument_parser.hpp:84-174), so the first bad option decides the message.
+// Flags, messages and exit codes are the contract (tests/test_cabi_cpu.py::test_cli_argument_contract).
+[[noreturn]] void reject(const char *before, const char *message)
+{
+  std::cerr << before << message << std::endl << "aborting..." << std::endl;
+  exit(EXIT_FAILURE);
+}
+
+// values are extracted the way operator>> does it (leading blanks skipped, trailing text ignored, 0 on failure)
+template <typename T>
+T value_of(const char *text)
+{
+  T v{};
+  std::istringstream in(text ? text : "");
+  in >> v;
+  return v;
+}
+
+struct OptionRow {
+  int key;                 // short option character, or >= 1000 for long-only options
+  const char *name;
+  bool takes_value;
+  void (*apply)(Options &, const char *);
+};
+
+const OptionRow OPTION_TABLE[] = {
+    {'r', "reference", true, [](Options &o, const char *v) { o.fasta_path = value_of<std::string>(v); }},
+    {'t', "threads", true,
+     [](Options &o, const char *v) {
+       o.nThreads = value_of<int>(v);
+       // (the reference prints the literal word here, argument_parser.hpp:95)
+       if (o.nThreads <= 0) reject("USAGE_MESSAGE", "shark: at least 1 thread is required.");
+     }},
+    {'1', "sample1", true, [](Options &o, const char *v) { o.sample1_path = value_of<std::string>(v); }},
+    {'2', "sample2", true, [](Options &o, const char *v) { o.sample2_path = value_of<std::string>(v); o.paired_flag = true; }},
+    {'o', "out1", true, [](Options &o, const char *v) { o.out1_path = value_of<std::string>(v); }},
+    {'p', "out2", true, [](Options &o, const char *v) { o.out2_path = value_of<std::string>(v); }},
+    {'k', "kmer-size", true,
+     [](Options &o, const char *v) {
+       o.k = value_of<unsigned>(v);
+       if (o.k < 1 || o.k > 31) reject(USAGE_MESSAGE, "shark: k must be in the range [1, 31].");
+     }},
+    {'c', "confidence", true,
+     [](Options &o, const char *v) {
+       o.c = value_of<double>(v);
+       if (o.c < 0 || o.c > 1) reject("", "shark: c must be in the range [0, 1].");
+     }},
+    {'b', "bf-size", true, [](Options &o, const char *v) { o.bf_size = value_of<uint64_t>(v) << 33; /* GB -> bits */ }},
+    {'q', "min-base-quality", true,
+     [](Options &o, const char *v) {
+       o.min_quality = value_of<int>(v);
+       if (o.min_quality < 0) reject(USAGE_MESSAGE, "shark: q must be a positive value.");
+     }},
+    {'s', "single", false, [](Options &o, const char *) { o.single = true; }},
+    {'v', "verbose", false, [](Options &o, const char *) { o.verbose = true; }},
+    {'h', "help", false, [](Options &, const char *) { std::cerr << USAGE_MESSAGE; exit(EXIT_SUCCESS); }},
+    {1000, "gpus", true, [](Options &o, const char *v) { o.gpus = std::max(1, value_of<int>(v)); }},
+    {1001, "batch", true, [](Options &o, const char *v) { o.batch = std::max<uint64_t>(1, value_of<uint64_t>(v)); }},
+    {1002, "gene-counts", true, [](Options &o, const char *v) { o.gene_counts_path = value_of<std::string>(v); }},
+};
+
 Options parse_arguments(int argc, char **argv)
 {
-  Options opt;
-  static const char *shortopts = "t:r:1:2:o:p:k:c:b:q:svh";
-  static const struct option longopts[] = {
-      {"reference", required_argument, NULL, 'r'}, {"threads", required_argument, NULL, 't'},
-      {"sample1", required_argument, NULL, '1'},   {"sample2", required_argument, NULL, '2'},
-      {"out1", required_argument, NULL, 'o'},      {"out2", required_argument, NULL, 'p'},
-      {"kmer-size", required_argument, NULL, 'k'}, {"confidence", required_argument, NULL, 'c'},
-      {"bf-size", required_argument, NULL, 'b'},   {"min-base-quality", required_argument, NULL, 'q'},
-      {"single", no_argument, NULL, 's'},          {"verbose", no_argument, NULL, 'v'},
-      {"help", no_argument, NULL, 'h'},            {"gpus", required_argument, NULL, 1000},
-      {"batch", required_argument, NULL, 1001},    {"gene-counts", required_argument, NULL, 1002},
-      {NULL, 0, NULL, 0}};
-  for (int ch; (ch = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
-    std::istringstream arg(optarg != NULL ? optarg : "");
-    switch (ch) {
-    case 'r': arg >> opt.fasta_path; break;
-    case 't':
-      arg >> opt.nThreads;
-      if (opt.nThreads <= 0) {  // argument_parser.hpp:93-98 (prints the literal text)
-        std::cerr << "USAGE_MESSAGE";
-        std::cerr << "shark: at least 1 thread is required." << std::endl << "aborting..." << std::endl;
-        exit(EXIT_FAILURE);
-      }
-      break;
-    case '1': arg >> opt.sample1_path; break;
-    case '2': arg >> opt.sample2_path; opt.paired_flag = true; break;
-    case 'o': arg >> opt.out1_path; break;
-    case 'p': arg >> opt.out2_path; break;
-    case 'k':
-      arg >> opt.k;
-      if (opt.k == 0 || opt.k > 31) {
-        std::cerr << USAGE_MESSAGE;
-        std::cerr << "shark: k must be in the range [1, 31]." << std::endl << "aborting..." << std::endl;
-        exit(EXIT_FAILURE);
-      }
-      break;
-    case 'c':
-      arg >> opt.c;
-      if (opt.c < 0 || opt.c > 1) {
-        std::cerr << "shark: c must be in the range [0, 1]." << std::endl << "aborting..." << std::endl;
-        exit(EXIT_FAILURE);
-      }
-      break;
-    case 'b':
-      arg >> opt.bf_size;
-      opt.bf_size = opt.bf_size * ((uint64_t)1 << 33);  // GB -> bits
-      break;
-    case 'q': {
-      int mq = 0;
-      arg >> mq;
-      if (mq < 0) {
-        std::cerr << USAGE_MESSAGE;
-        std::cerr << "shark: q must be a positive value." << std::endl << "aborting..." << std::endl;
-        exit(EXIT_FAILURE);
-      }
-      opt.min_quality = static_cast<char>(mq);
-      break;
+  // getopt_long's two descriptions are generated from the table
+  std::string shorts;
+  std::vector<struct option> longs;
+  for (const OptionRow &row : OPTION_TABLE) {
+    if (row.key < 256) {
+      shorts.push_back((char)row.key);
+      if (row.takes_value) shorts.push_back(':');
     }
-    case 's': opt.single = true; break;
-    case 'v': opt.verbose = true; break;
-    case 'h': std::cerr << USAGE_MESSAGE; exit(EXIT_SUCCESS);
-    case 1000: arg >> opt.gpus; if (opt.gpus < 1) opt.gpus = 1; break;
-    case 1001: arg >> opt.batch; if (opt.batch < 1) opt.batch = 1; break;
-    case 1002: arg >> opt.gene_counts_path; break;
-    default:
-      std::cerr << "shark : unknown argument" << std::endl;
-      std::cerr << "\n" << USAGE_MESSAGE;
+    longs.push_back({row.name, row.takes_value ? required_argument : no_argument, nullptr, row.key});
+  }
+  longs.push_back({nullptr, 0, nullptr, 0});
+
+  Options opt;
+  int key;
+  while ((key = getopt_long(argc, argv, shorts.c_str(), longs.data(), nullptr)) != -1) {
+    const OptionRow *hit = nullptr;
+    for (const OptionRow &row : OPTION_TABLE)
+      if (row.key == key) hit = &row;
+    if (!hit) {
+      std::cerr << "shark : unknown argument" << std::endl << "\n" << USAGE_MESSAGE;
       exit(EXIT_FAILURE);
     }
+    hit->apply(opt, optarg);
   }
-  if (opt.fasta_path == "" || opt.sample1_path == "") {
-    std::cerr << "shark : missing required files" << std::endl;
-    std::cerr << "\n" << USAGE_MESSAGE;
+  if (opt.fasta_path.empty() || opt.sample1_path.empty()) {
+    std::cerr << "shark : missing required files" << std::endl << "\n" << USAGE_MESSAGE;
     exit(EXIT_FAILURE);
   }
-  if (opt.out1_path == "") opt.out1_path = "sharked_sample.1";
-  if (opt.out2_path == "" && opt.sample2_path != "") opt.out2_path = "sharked_sample.2";
+  if (opt.out1_path.empty()) opt.out1_path = "sharked_sample.1";
+  if (opt.out2_path.empty() && !opt.sample2_path.empty()) opt.out2_path = "sharked_sample.2";
   return opt;
 }
 
-auto start_t = std::chrono::high_resolution_clock::now();
-void pelapsed(const std::string &s)  // main.cpp:47-54
-{
-  auto now_t = std::chrono::high_resolution_clock::now();
-  std::cerr << "[shark/" << s << "] Time elapsed "
-            << std::chrono::duration_cast<std::chrono::milliseconds>(now_t - start_t).count() / 1000 << std::endl;
-}
+// progress lines on stderr in the reference's format (main.cpp:49-54; whole seconds since start)
+class Progress {
+ public:
+  void operator()(const std::string &stage) const
+  {
+    const auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0_).count();
+    std::cerr << "[shark/" << stage << "] Time elapsed " << secs << std::endl;
+  }
+
+ private:
+  std::chrono::steady_clock::time_point t0_ = std::chrono::steady_clock::now();
+};
+const Progress pelapsed;
 
 // ---- one batch of reads, structure of arrays ---------------------------------
 // allocator that leaves chars uninitialised on resize (the parallel filler overwrites every byte)
@@ -505,15 +528,11 @@ int main(int argc, char *argv[])
 {
   const Options opt = parse_arguments(argc, argv);
 
-  if (opt.verbose) {  // main.cpp:113-123
-    std::cerr << "Reference texts: " << opt.fasta_path << std::endl;
-    std::cerr << "Sample 1: " << opt.sample1_path << std::endl;
-    if (opt.paired_flag) std::cerr << "Sample 2: " << opt.sample2_path << std::endl;
-    std::cerr << "K-mer length: " << opt.k << std::endl;
-    std::cerr << "Threshold value: " << opt.c << std::endl;
-    std::cerr << "Only single associations: " << (opt.single ? "Yes" : "No") << std::endl;
-    std::cerr << "Minimum base quality: " << static_cast<int>(opt.min_quality) << std::endl;
-    std::cerr << std::endl;
+  if (opt.verbose) {
+    std::cerr << "shark (MI355X): reference " << opt.fasta_path << ", sample " << opt.sample1_path;
+    if (opt.paired_flag) std::cerr << " + " << opt.sample2_path;
+    std::cerr << "; k=" << opt.k << " c=" << opt.c << " q=" << opt.min_quality << (opt.single ? " single" : "") << " bf=" << (opt.bf_size >> 33)
+              << "GB gpus=" << opt.gpus << "\n" << std::endl;
   }
 
   // ---- contexts: one per GPU, index replicated by deterministic rebuild -------
@@ -610,7 +629,7 @@ int main(int argc, char *argv[])
     std::vector<std::thread> analyzers;
     for (int g = 0; g < n_gpus; ++g) {
       analyzers.emplace_back([&, g] {
-        ReadAnalyzer ra(ctxs[(size_t)g], opt.min_quality != 0);
+        ReadAnalyzer ra(ctxs[(size_t)g], static_cast<char>(opt.min_quality) != 0);
         std::unique_ptr<ReadBatch> b;
         while (todo.pop(b)) {
           auto t0 = std::chrono::steady_clock::now();

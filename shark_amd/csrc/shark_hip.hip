@@ -39,23 +39,75 @@ static uint32_t slots_for_len(uint32_t len, uint32_t k, bool paired)
   return (paired && per) ? ((len + 7u) & ~7u) + per : per;
 }
 
-// everything after the inputs are resident in HBM; batch pointers are device pointers
-static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, shk_result *res, shk_work_counters *wc = nullptr)
+// exact slot count of one read (pair): the `ns` of classify.hip's process_read
+static uint32_t slots_of_read(uint64_t L1, uint64_t L2, uint32_t k)
 {
-  hipStream_t st = ctx->stream;
-  const uint64_t n = b->n;
-  if (n >= 0xFFFFFFFFull) { ctx->last_error = "batch too large (n must be < 2^32-1)"; return SHK_ERR_ARG; }
+  const uint64_t nk1 = L1 >= k ? L1 - k + 1 : 0, nk2 = L2 >= k ? L2 - k + 1 : 0;
+  const uint64_t ns = nk2 ? ((L1 + 7u) & ~7ull) + nk2 : nk1;
+  return ns > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ns;
+}
+
+template <typename T>
+static int ensure_pinned(Ctx *ctx, T **ptr, size_t *cap, size_t need)
+{
+  if (need <= *cap && *ptr) return SHK_OK;
+  if (*ptr) { (void)hipHostFree(*ptr); *ptr = nullptr; *cap = 0; }
+  const size_t want = need + need / 4 + 64;
+  hipError_t e = hipHostMalloc((void **)ptr, want * sizeof(T), hipHostMallocDefault);
+  if (e != hipSuccess) return set_hip_error(ctx, e, "hipHostMalloc");
+  *cap = want;
+  return SHK_OK;
+}
+
+static int slot_init(Ctx *ctx, Slot &s)
+{
+  SHK_HIP(ctx, hipMalloc((void **)&s.d_counters, CTR_WORDS * sizeof(uint32_t)));
+  SHK_HIP(ctx, hipMalloc((void **)&s.d_out, sizeof(ClassifyOut)));
+  SHK_HIP(ctx, hipHostMalloc((void **)&s.h_counters, CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
+  SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+  SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_d2h, hipEventDisableTiming));
+  return SHK_OK;
+}
+
+static void slot_free(Slot &s)
+{
+  hipFree(s.d_seq1); hipFree(s.d_seq2); hipFree(s.d_qual1); hipFree(s.d_qual2); hipFree(s.d_off1); hipFree(s.d_off2);
+  hipFree(s.d_count); hipFree(s.d_inl); hipFree(s.d_gene_off); hipFree(s.d_gene_ids);
+  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out);
+  if (s.h_counters) (void)hipHostFree(s.h_counters);
+  if (s.h_gene_off) (void)hipHostFree(s.h_gene_off);
+  if (s.h_gene_ids) (void)hipHostFree(s.h_gene_ids);
+  if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
+  if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+  if (s.ev_d2h) (void)hipEventDestroy(s.ev_d2h);
+  s = Slot{};
+}
+
+// result buffers of a batch of n reads; *d_out is rewritten only when one of them moved (a blocking
+// copy: never on the steady-state path of the pipeline)
+static int slot_reserve(Ctx *ctx, Slot &s, uint64_t n)
+{
   int rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_count, &ctx->cap_count, n + 1))) return rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_inl, &ctx->cap_inl, n * SHK_INLINE_IDS + 8))) return rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_gene_off, &ctx->cap_gene_off, n + 1))) return rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_long_queue, &ctx->cap_long_queue, n + 1))) return rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_tie_queue, &ctx->cap_tie_queue, 3 * n + 3))) return rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_scan_temp, &ctx->cap_scan_temp, scan_temp_words(n + 1)))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_count, &s.cap_count, n + 1))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_inl, &s.cap_inl, n * SHK_INLINE_IDS + 8))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_gene_off, &s.cap_gene_off, n + 1))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_long_queue, &s.cap_long_queue, n + 1))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_tie_queue, &s.cap_tie_queue, 3 * n + 3))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_scan_temp, &s.cap_scan_temp, scan_temp_words(n + 1)))) return rc;
+  // associations: two per read to start with; a batch that needs more is finished by the overflow path
+  if ((rc = ensure_capacity(ctx, &s.d_gene_ids, &s.cap_gene_ids, 2 * n + 4096))) return rc;
+  ClassifyOut ho;
+  ho.count = s.d_count; ho.inl = s.d_inl; ho.counters = s.d_counters; ho.long_queue = s.d_long_queue; ho.tie_queue = s.d_tie_queue;
+  if (memcmp(&ho, &s.out_shadow, sizeof(ho)) != 0) {
+    SHK_HIP(ctx, hipMemcpy(s.d_out, &ho, sizeof(ho), hipMemcpyHostToDevice));
+    s.out_shadow = ho;
+  }
+  return SHK_OK;
+}
 
-  SHK_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
-  SHK_HIP(ctx, hipMemsetAsync(ctx->d_count + n, 0, sizeof(uint32_t), st));
-
+static void fill_params(Ctx *ctx, Slot &s, const shk_batch *b)
+{
   ClassifyParams p{};
   const DeviceIndex &ix = ctx->idx;
   p.bf64 = ix.bf64; p.rank_w = ix.rank_w; p.ent = ix.ent; p.ids = ix.ids;
@@ -66,32 +118,113 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   p.bf_bits = ix.bf_bits;
   p.bf_mask = ix.pow2 ? ix.bf_bits - 1 : ~0ull;   // (non power-of-two: positions are reduced explicitly, the masks become no-ops)
   if (!ix.pow2) {
-    const uint32_t s = (uint32_t)__builtin_ctzll(ix.bf_bits);
-    const uint64_t m = ix.bf_bits >> s;
-    p.mod_shift = s;
-    p.mod_fast = s >= 32 && m < (1ull << 32);
+    const uint32_t sh = (uint32_t)__builtin_ctzll(ix.bf_bits);
+    const uint64_t m = ix.bf_bits >> sh;
+    p.mod_shift = sh;
+    p.mod_fast = sh >= 32 && m < (1ull << 32);
     p.mod_m = p.mod_fast ? (uint32_t)m : 0;
     p.mod_c = p.mod_fast ? 0xFFFFFFFFFFFFFFFFull / m + 1 : 0;
   }
   p.k = ctx->prm.k; p.c = ctx->prm.c; p.single = ctx->prm.single;
-  p.mq = ctx->prm.min_quality ? ctx->prm.min_quality + 33 : 0;  // FastqSplitter.hpp:70
-  p.n = n;
+  // FastqSplitter.hpp:52,:70 with the reference's `char min_quality` (argument_parser.hpp:59,:144): no masking when the
+  // char is 0; otherwise the threshold is (char)(min_quality + 33), which wraps for -q > 94 just as it does there
+  p.hasq = ctx->q8 != 0;
+  p.mq = (int32_t)(int8_t)(uint8_t)((int)ctx->q8 + 33);
+  p.n = b->n;
   p.seq1 = (const uint8_t *)b->seq1; p.off1 = b->off1;
   p.seq2 = (const uint8_t *)b->seq2; p.off2 = b->off2;
   p.qual1 = (const uint8_t *)b->qual1; p.qual2 = (const uint8_t *)b->qual2;
-  ClassifyOut ho;
-  ho.count = ctx->d_count; ho.inl = ctx->d_inl;
-  ho.counters = ctx->d_counters; ho.long_queue = ctx->d_long_queue; ho.tie_queue = ctx->d_tie_queue;
-  SHK_HIP(ctx, hipMemcpyAsync(ctx->d_out, &ho, sizeof(ho), hipMemcpyHostToDevice, st));   // (pageable source: staged before return)
-  p.out = ctx->d_out;
-  p.gene_counts = wc ? nullptr : ctx->d_gene_counts;
-  p.work_counters = nullptr;
+  p.out = s.d_out;
+  p.flags = s.d_counters;
+#ifdef SHK_ABLATION
   p.ablate = getenv("SHK_ABLATE") ? (uint32_t)atoi(getenv("SHK_ABLATE")) : 0u;
+#endif
+  s.p = p;
+}
 
-  const bool paired = b->seq2 != nullptr;
-  uint32_t max_slots = max_read_len ? slots_for_len(max_read_len, p.k, paired) : 0;
+// scratch of the general kernel for `n_items` work items of at most `slots` k-mer slots
+static int size_scratch(Ctx *ctx, ClassifyParams &p, uint32_t slots, uint64_t n_items, unsigned *n_waves)
+{
+  const uint32_t S = ((slots + 63) / 64) * 64;
+  const uint64_t stride = (uint64_t)stage_words_for(S) + (3ull * S) / 2 + 2;   // staging area + 3 u32 slot records
+  uint64_t waves = std::min<uint64_t>(std::max<uint64_t>(n_items, 1), 4096);
+  const uint64_t budget_words = (1ull << 31) / 8;  // at most 2 GiB of scratch
+  if (waves * stride > budget_words) waves = std::max<uint64_t>(1, budget_words / stride);
+  waves = ((waves + 3) / 4) * 4;
+  int r = ensure_capacity(ctx, &ctx->d_scratch, &ctx->cap_scratch, waves * stride);
+  if (r) return r;
+  p.scratch = ctx->d_scratch;
+  p.scratch_stride_words = stride;
+  p.scratch_slots = S;
+  *n_waves = (unsigned)waves;
+  return SHK_OK;
+}
+
+// reads queued for the general kernel because they exceed the fast kernel's slot capacity
+static int run_long_reads(Ctx *ctx, Slot &s, uint32_t n_long)
+{
+  if (!n_long) return SHK_OK;
+  ClassifyParams p = s.p;
+  unsigned n_waves = 0;
+  int rc;
+  if ((rc = size_scratch(ctx, p, s.gen_slots, n_long, &n_waves))) return rc;
+  p.work = s.d_long_queue;
+  p.n_work = n_long;
+  p.work_count = nullptr;
+  return launch_classify_general(ctx, p, false, n_waves, ctx->stream);
+}
+
+// Everything behind the classify kernels, WITHOUT a host round trip: per-read counts -> offsets (scan), inline ids ->
+// CSR (gather), reads with more than SHK_INLINE_IDS genes (EMIT pass of the general kernel over the tie queue, whose
+// length stays on the device), per-gene histogram, counters -> pinned host memory, event.
+static int enqueue_tail(Ctx *ctx, Slot &s, bool skip_hist_if_long, bool count_genes)
+{
+  hipStream_t st = ctx->stream;
+  const uint64_t n = s.n;
+  int rc;
+  const uint64_t *d_total = exclusive_scan_u32(s.d_count, s.d_gene_off, n + 1, s.d_scan_temp, st);
+  SHK_HIP(ctx, hipGetLastError());
+  if ((rc = launch_finalize_total(d_total, s.d_counters, s.cap_gene_ids, st))) return rc;
+  if ((rc = launch_gather_inline(s.d_count, s.d_inl, s.d_gene_off, s.d_gene_ids, n, s.d_counters, st))) return rc;
+  {
+    ClassifyParams p = s.p;
+    unsigned n_waves = 0;
+    if ((rc = size_scratch(ctx, p, s.gen_slots, std::min<uint64_t>(n, 1024), &n_waves))) return rc;
+    p.work = s.d_tie_queue;
+    p.n_work = 0;
+    p.work_count = s.d_counters + CTR_TIE;
+    p.gene_off = s.d_gene_off;
+    p.gene_ids = s.d_gene_ids;
+    if ((rc = launch_classify_general(ctx, p, true, n_waves, st))) return rc;
+  }
+  if (count_genes && (rc = launch_gene_hist(s.d_gene_ids, s.d_counters, skip_hist_if_long, ctx->d_gene_counts, n, st))) return rc;
+  SHK_HIP(ctx, hipMemcpyAsync(s.h_counters, s.d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  SHK_HIP(ctx, hipEventRecord(s.ev_done, st));
+  return SHK_OK;
+}
+
+enum LongMode {
+  LONG_NONE_EXPECTED = 0,   // the caller's length bound says every read fits the fast kernel; checked after the fact
+  LONG_KNOWN = 1,           // the host has counted the reads that do not fit (host batches)
+  LONG_UNKNOWN = 2          // no bound: one host round trip behind the fast kernel
+};
+
+// all kernels of one batch whose inputs are (or will be, in stream order) resident in HBM; batch pointers are device
+// pointers.  Returns with the work enqueued on ctx->stream; finish_classify() completes the rare slow paths.
+static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_slots, int long_mode, uint32_t n_long_host,
+                            uint32_t long_slots_host, bool count_genes)
+{
+  hipStream_t st = ctx->stream;
+  const uint64_t n = b->n;
+  int rc;
+  if ((rc = slot_reserve(ctx, s, n))) return rc;
+  s.n = n;
+  fill_params(ctx, s, b);
+  SHK_HIP(ctx, hipMemsetAsync(s.d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
+  SHK_HIP(ctx, hipMemsetAsync(s.d_count + n, 0, sizeof(uint32_t), st));
   if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
-  const uint32_t fast_cap = 64 * fast_kernel_unroll(max_slots);
+  s.fast_cap = 64 * fast_kernel_unroll(max_slots);
+  s.gen_slots = s.fast_cap;
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
@@ -107,72 +240,79 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
     ctx->ev_used++;
     SHK_HIP(ctx, hipEventRecord(e0, st));
   }
-  if ((rc = launch_classify_fast(ctx, p, max_slots, st))) return rc;
+  if ((rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
   if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
 
-  SHK_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  SHK_HIP(ctx, hipStreamSynchronize(st));
-  const uint32_t n_long = ctx->h_counters[CTR_LONG];
-  uint32_t gen_slots = fast_cap;
-
-  auto size_scratch = [&](uint64_t n_items, unsigned *n_waves) -> int {
-    const uint32_t S = ((gen_slots + 63) / 64) * 64;
-    const uint64_t stride = (uint64_t)stage_words_for(S) + (3ull * S) / 2 + 2;   // staging area + 3 u32 slot records
-    uint64_t waves = std::min<uint64_t>(n_items, 4096);
-    const uint64_t budget_words = (1ull << 31) / 8;  // at most 2 GiB of scratch
-    if (waves * stride > budget_words) waves = std::max<uint64_t>(1, budget_words / stride);
-    waves = ((waves + 3) / 4) * 4;
-    int r = ensure_capacity(ctx, &ctx->d_scratch, &ctx->cap_scratch, waves * stride);
-    if (r) return r;
-    p.scratch = ctx->d_scratch;
-    p.scratch_stride_words = stride;
-    p.scratch_slots = S;
-    *n_waves = (unsigned)waves;
-    return SHK_OK;
-  };
-
-  if (n_long) {
-    gen_slots = std::max(gen_slots, ctx->h_counters[CTR_MAX_SLOTS]);
-    unsigned n_waves = 0;
-    if ((rc = size_scratch(n_long, &n_waves))) return rc;
-    p.work = ctx->d_long_queue;
-    p.n_work = n_long;
-    if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  uint32_t n_long = 0;
+  if (long_mode == LONG_UNKNOWN) {
+    SHK_HIP(ctx, hipMemcpyAsync(s.h_counters, s.d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SHK_HIP(ctx, hipStreamSynchronize(st));
+    n_long = s.h_counters[CTR_LONG];
+    s.gen_slots = std::max(s.fast_cap, s.h_counters[CTR_MAX_SLOTS]);
+  } else if (long_mode == LONG_KNOWN) {
+    n_long = n_long_host;
+    s.gen_slots = std::max(s.fast_cap, long_slots_host);
   }
-  const uint32_t n_tie = ctx->h_counters[CTR_TIE];
+  if ((rc = run_long_reads(ctx, s, n_long))) return rc;
+  return enqueue_tail(ctx, s, long_mode == LONG_NONE_EXPECTED, count_genes);
+}
 
-  // associations -> CSR (gene_off, gene_ids); the grand total of the scan is the number of associations
-  const uint64_t *d_total = exclusive_scan_u32(ctx->d_count, ctx->d_gene_off, n + 1, ctx->d_scan_temp, st);
-  SHK_HIP(ctx, hipGetLastError());
-  uint64_t *h_total = reinterpret_cast<uint64_t *>(ctx->h_counters + CTR_WORDS);
-  SHK_HIP(ctx, hipMemcpyAsync(h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  SHK_HIP(ctx, hipStreamSynchronize(st));
-  const uint64_t n_assoc = *h_total;
-  if (n_assoc >= 0xFFFFFFFFull) { ctx->last_error = "more than 2^32-1 associations in one batch"; return SHK_ERR_ARG; }
-  if ((rc = ensure_capacity(ctx, &ctx->d_gene_ids, &ctx->cap_gene_ids, n_assoc + 8))) return rc;
-  if ((rc = launch_gather_inline(ctx->d_count, ctx->d_inl, ctx->d_gene_off, ctx->d_gene_ids, n, wc ? nullptr : ctx->d_gene_counts, st))) return rc;
-  if (n_tie) {
-    unsigned n_waves = 0;
-    if ((rc = size_scratch(n_tie, &n_waves))) return rc;
-    p.work = ctx->d_tie_queue;
-    p.n_work = n_tie;
-    p.gene_off = ctx->d_gene_off;
-    p.gene_ids = ctx->d_gene_ids;
-    if ((rc = launch_classify_general(ctx, p, true, n_waves, st))) return rc;
+// after ev_done: complete what the enqueued work could not (both paths are rare and synchronous)
+//  * a length bound that did not hold: reads sit in the long queue -> general kernel, tail again
+//  * more associations than gene_ids holds -> grow it, tail again
+// The histogram kernel skipped itself in exactly these cases, so no batch is counted twice.
+static int finish_classify(Ctx *ctx, Slot &s, bool long_was_speculative, bool count_genes, bool *redone)
+{
+  hipStream_t st = ctx->stream;
+  int rc;
+  *redone = false;
+  if (long_was_speculative && s.h_counters[CTR_LONG]) {
+    s.gen_slots = std::max(s.fast_cap, s.h_counters[CTR_MAX_SLOTS]);
+    if ((rc = run_long_reads(ctx, s, s.h_counters[CTR_LONG]))) return rc;
+    if ((rc = enqueue_tail(ctx, s, false, count_genes))) return rc;
+    SHK_HIP(ctx, hipStreamSynchronize(st));
+    *redone = true;
   }
+  if (s.h_counters[CTR_OVERFLOW]) {
+    const uint64_t n_assoc = ((uint64_t)s.h_counters[CTR_ASSOC_HI] << 32) | s.h_counters[CTR_ASSOC_LO];
+    if (n_assoc >= 0xFFFFFFFFull) { ctx->last_error = "more than 2^32-1 associations in one batch"; return SHK_ERR_ARG; }
+    SHK_HIP(ctx, hipStreamSynchronize(st));     // gene_ids is about to be replaced
+    if ((rc = ensure_capacity(ctx, &s.d_gene_ids, &s.cap_gene_ids, n_assoc + 8))) return rc;
+    if ((rc = enqueue_tail(ctx, s, false, count_genes))) return rc;
+    SHK_HIP(ctx, hipStreamSynchronize(st));
+    *redone = true;
+  }
+  return SHK_OK;
+}
+
+// a batch resident in HBM, start to finish (shk_classify_device, shk_count_work)
+static int classify_resident(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, shk_result *res, shk_work_counters *wc = nullptr)
+{
+  hipStream_t st = ctx->stream;
+  Slot &s = ctx->slots[PIPE_DEPTH];
+  const uint64_t n = b->n;
+  if (n >= 0xFFFFFFFFull) { ctx->last_error = "batch too large (n must be < 2^32-1)"; return SHK_ERR_ARG; }
+  const bool paired = b->seq2 != nullptr;
+  const uint32_t max_slots = max_read_len ? slots_for_len(max_read_len, ctx->prm.k, paired) : 0;
+  const int long_mode = (max_read_len && max_slots <= fast_kernel_max_slots()) ? LONG_NONE_EXPECTED : LONG_UNKNOWN;
+  int rc;
+  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr))) return rc;
   SHK_HIP(ctx, hipStreamSynchronize(st));
+  bool redone = false;
+  if ((rc = finish_classify(ctx, s, long_mode == LONG_NONE_EXPECTED, wc == nullptr, &redone))) return rc;
+  const uint64_t n_assoc = ((uint64_t)s.h_counters[CTR_ASSOC_HI] << 32) | s.h_counters[CTR_ASSOC_LO];
 
   if (wc) {
     // measurement only: re-run every read through the general kernel with the
     // exact work counters switched on (results are rewritten with equal values)
+    ClassifyParams p = s.p;
     unsigned n_waves = 0;
-    if ((rc = size_scratch(n, &n_waves))) return rc;
-    SHK_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
+    if ((rc = size_scratch(ctx, p, s.gen_slots, n, &n_waves))) return rc;
+    SHK_HIP(ctx, hipMemsetAsync(s.d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
     SHK_HIP(ctx, hipMemsetAsync(ctx->d_work_counters, 0, 4 * sizeof(unsigned long long), st));
     p.work = nullptr;
     p.n_work = n;
+    p.work_count = nullptr;
     p.work_counters = ctx->d_work_counters;
     if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
     unsigned long long h[4] = {0, 0, 0, 0};
@@ -182,16 +322,75 @@ static int classify_core(Ctx *ctx, const shk_batch *b, uint32_t max_read_len, sh
   }
 
   ctx->last.last_n_reads = n;
-  ctx->last.last_n_long = n_long;
-  ctx->last.last_n_tie = n_tie;
+  ctx->last.last_n_long = s.h_counters[CTR_LONG];
+  ctx->last.last_n_tie = s.h_counters[CTR_TIE];
   ctx->last.last_n_assoc = n_assoc;
   res->n = n;
-  res->gene_off = ctx->d_gene_off;
-  res->gene_ids = ctx->d_gene_ids;
+  res->gene_off = s.d_gene_off;
+  res->gene_ids = s.d_gene_ids;
   res->n_assoc = n_assoc;
   return SHK_OK;
 }
 
+}  // namespace shk
+
+// ---- RCCL, loaded on first use so that single-GPU users never pay for (or conflict over) it ----
+namespace shk {
+typedef void *rccl_comm_t;
+struct rccl_uid { char internal[128]; };   // ncclUniqueId
+struct RcclApi {
+  void *lib = nullptr;
+  int (*CommInitAll)(rccl_comm_t *, int, const int *) = nullptr;
+  int (*CommInitRank)(rccl_comm_t *, int, rccl_uid, int) = nullptr;
+  int (*GetUniqueId)(rccl_uid *) = nullptr;
+  int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  bool ok = false;
+};
+static RcclApi &rccl()
+{
+  static RcclApi api;
+  if (!api.lib) {
+    api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) {
+      api.CommInitAll = (int (*)(rccl_comm_t *, int, const int *))dlsym(api.lib, "ncclCommInitAll");
+      api.CommInitRank = (int (*)(rccl_comm_t *, int, rccl_uid, int))dlsym(api.lib, "ncclCommInitRank");
+      api.GetUniqueId = (int (*)(rccl_uid *))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommDestroy = (int (*)(rccl_comm_t))dlsym(api.lib, "ncclCommDestroy");
+      api.AllReduce = (int (*)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+      api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+      api.ok = api.CommInitAll && api.CommInitRank && api.GetUniqueId && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+    }
+  }
+  return api;
+}
+
+// RCCL may print a version banner on stdout when it initialises; stdout is the ssv stream of the CLI
+// (ReadOutput.hpp:43), so anything RCCL prints during init is sent to stderr instead
+template <typename F>
+static int with_stdout_on_stderr(F f)
+{
+  fflush(stdout);
+  const int saved_stdout = dup(1);
+  if (saved_stdout >= 0) (void)dup2(2, 1);
+  const int rc = f();
+  if (saved_stdout >= 0) {
+    fflush(stdout);
+    (void)dup2(saved_stdout, 1);
+    close(saved_stdout);
+  }
+  return rc;
+}
+
+static void dist_release(Ctx *ctx)
+{
+  if (ctx->dist_comm) { (void)rccl().CommDestroy(ctx->dist_comm); ctx->dist_comm = nullptr; }
+  if (ctx->group_comm) { (void)rccl().CommDestroy(ctx->group_comm); ctx->group_comm = nullptr; }
+}
 }  // namespace shk
 
 using namespace shk;
@@ -225,7 +424,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   *out = nullptr;
   if (prm->k == 0 || prm->k > 31) return SHK_ERR_ARG;                  // argument_parser.hpp:115
   if (!(prm->c >= 0.0 && prm->c <= 1.0)) return SHK_ERR_ARG;           // :124
-  if (prm->min_quality < 0 || prm->min_quality > 94) return SHK_ERR_ARG; // :138; Q+33 must fit a char
+  if (prm->min_quality < 0) return SHK_ERR_ARG;                        // :138
   if (prm->bf_bits == 0) return SHK_ERR_ARG;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return SHK_ERR_NO_DEVICE;
@@ -234,10 +433,13 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   if (!ctx) return SHK_ERR_NOMEM;
   ctx->prm = *prm;
   ctx->prm.single = prm->single ? 1 : 0;
+  ctx->q8 = (int8_t)(uint8_t)(prm->min_quality & 0xFF);                // static_cast<char>(mq), argument_parser.hpp:144
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };
 #define CR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP); } while (0)
   CR_HIP(hipSetDevice(prm->device));
   CR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  CR_HIP(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+  CR_HIP(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
   DeviceIndex &ix = ctx->idx;
   ix.bf_bits = prm->bf_bits;
   ix.pow2 = (prm->bf_bits & (prm->bf_bits - 1)) == 0;
@@ -245,12 +447,12 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   // BF::BF(size): size zero bits (bloomfilter.h:48-53)
   CR_HIP(hipMalloc((void **)&ix.bf64, ix.bf_words64 * sizeof(uint64_t)));
   CR_HIP(hipMemsetAsync(ix.bf64, 0, ix.bf_words64 * sizeof(uint64_t), ctx->stream));
-  CR_HIP(hipMalloc((void **)&ctx->d_counters, CTR_WORDS * sizeof(uint32_t)));
-  CR_HIP(hipMalloc((void **)&ctx->d_out, sizeof(ClassifyOut)));
+  for (Slot &sl : ctx->slots)
+    if (slot_init(ctx, sl) != SHK_OK) return fail(SHK_ERR_HIP);
   CR_HIP(hipMalloc((void **)&ctx->d_gene_counts, 65536 * sizeof(unsigned long long)));
   CR_HIP(hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
+  CR_HIP(hipMalloc((void **)&ctx->d_gene_totals, 65536 * sizeof(unsigned long long)));
   CR_HIP(hipMalloc((void **)&ctx->d_work_counters, 4 * sizeof(unsigned long long)));
-  CR_HIP(hipHostMalloc((void **)&ctx->h_counters, (CTR_WORDS + 2) * sizeof(uint32_t), hipHostMallocDefault));
   CR_HIP(hipStreamSynchronize(ctx->stream));
 #undef CR_HIP
   *out = ctx;
@@ -263,14 +465,13 @@ void shk_destroy(shk_ctx *ctx)
   (void)hipSetDevice(ctx->prm.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_index(ctx->idx);
-  hipFree(ctx->d_seq1); hipFree(ctx->d_seq2); hipFree(ctx->d_qual1); hipFree(ctx->d_qual2);
-  hipFree(ctx->d_off1); hipFree(ctx->d_off2);
-  hipFree(ctx->d_count); hipFree(ctx->d_inl); hipFree(ctx->d_gene_off); hipFree(ctx->d_gene_ids);
-  hipFree(ctx->d_long_queue); hipFree(ctx->d_tie_queue); hipFree(ctx->d_counters); hipFree(ctx->d_out);
-  hipFree(ctx->d_scan_temp); hipFree(ctx->d_scratch); hipFree(ctx->d_gene_counts); hipFree(ctx->d_work_counters);
-  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  for (Slot &sl : ctx->slots) slot_free(sl);
+  hipFree(ctx->d_scratch); hipFree(ctx->d_gene_counts); hipFree(ctx->d_gene_totals); hipFree(ctx->d_work_counters);
+  dist_release(ctx);
   for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
+  if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
+  if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -353,7 +554,7 @@ static int check_batch(const shk_ctx *ctx, const shk_batch *b)
   if (b->n == 0) return SHK_OK;
   if (!b->seq1 || !b->off1) return SHK_ERR_ARG;
   if ((b->seq2 == nullptr) != (b->off2 == nullptr)) return SHK_ERR_ARG;
-  if (ctx->prm.min_quality != 0 && (!b->qual1 || (b->seq2 && !b->qual2))) return SHK_ERR_ARG;
+  if (ctx->q8 != 0 && (!b->qual1 || (b->seq2 && !b->qual2))) return SHK_ERR_ARG;
   return SHK_OK;
 }
 
@@ -364,75 +565,146 @@ int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_
   int rc = check_batch(ctx, batch);
   if (rc) return rc;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
-  return classify_core(ctx, batch, max_read_len, result);
+  return classify_resident(ctx, batch, max_read_len, result);
+}
+
+// ---- host batches: a pipeline of PIPE_DEPTH batches per context ---------------------------------
+// submit(i): host scan of the offsets, H2D on the copy stream, every kernel on the compute stream behind an event,
+//            no host round trip.  wait(i): the batch's event, then D2H of exactly its results into the slot's pinned
+//            buffers.  While the host waits for batch i, the H2D of batch i+1 and i+2 overlaps the kernels of batch i
+//            (the reference overlaps split / analyze / output across its worker threads, main.cpp:66-77).
+int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
+{
+  if (!ctx || !ticket) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  int rc = check_batch(ctx, b);
+  if (rc) return rc;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  Slot &s = ctx->slots[(ctx->next_ticket - 1) % PIPE_DEPTH];
+  if (s.ticket != 0 && !s.waited) {
+    ctx->last_error = "pipeline full: shk_classify_wait the oldest ticket before submitting another batch";
+    return SHK_ERR_STATE;
+  }
+  const uint64_t n = b->n;
+  if (n >= 0xFFFFFFFFull) { ctx->last_error = "batch too large (n must be < 2^32-1)"; return SHK_ERR_ARG; }
+  const bool paired = b->seq2 != nullptr;
+  const uint32_t k = ctx->prm.k;
+  // one pass over the offsets: validation, the longest mate (selects the kernel specialisation), and whether every
+  // read has the same length (then the offsets are generated on the device instead of crossing PCIe)
+  uint64_t max1 = 0, max2 = 0, bad = 0;
+  const uint64_t f1 = n ? b->off1[1] - b->off1[0] : 0, f2 = (n && paired) ? b->off2[1] - b->off2[0] : 0;
+  uint64_t nonuni = n ? (b->off1[0] | (paired ? b->off2[0] : 0)) : 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t a = b->off1[i], e = b->off1[i + 1];
+    bad |= (uint64_t)(e < a);
+    const uint64_t l = e - a;
+    max1 = l > max1 ? l : max1;
+    nonuni |= l ^ f1;
+  }
+  if (paired)
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t a = b->off2[i], e = b->off2[i + 1];
+      bad |= (uint64_t)(e < a);
+      const uint64_t l = e - a;
+      max2 = l > max2 ? l : max2;
+      nonuni |= l ^ f2;
+    }
+  if (bad) return SHK_ERR_ARG;
+  const bool uniform = n && !nonuni;
+  const uint64_t bytes1 = n ? b->off1[n] : 0;
+  const uint64_t bytes2 = (n && paired) ? b->off2[n] : 0;
+  // slot count of the longest read decides the specialisation; only when even the largest one is too small do reads
+  // go to the general kernel, and then the host counts them here (so the device never has to be asked)
+  uint32_t max_slots = slots_of_read(max1, max2, k);   // an upper bound for every read: the slot count is monotone in both lengths
+  uint32_t n_long = 0, long_slots = 0;
+  if (max_slots > fast_kernel_max_slots()) {
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t ns = slots_of_read(b->off1[i + 1] - b->off1[i], paired ? b->off2[i + 1] - b->off2[i] : 0, k);
+      long_slots = std::max(long_slots, ns);
+      n_long += ns > fast_kernel_max_slots();
+    }
+    max_slots = fast_kernel_max_slots();
+  }
+
+  hipStream_t up = ctx->h2d_stream, st = ctx->stream;
+  shk_batch d{};
+  d.n = n;
+  if ((rc = ensure_capacity(ctx, &s.d_seq1, &s.cap_seq1, bytes1 + 16))) return rc;
+  if ((rc = ensure_capacity(ctx, &s.d_off1, &s.cap_off1, n + 1))) return rc;
+  if (paired) {
+    if ((rc = ensure_capacity(ctx, &s.d_seq2, &s.cap_seq2, bytes2 + 16))) return rc;
+    if ((rc = ensure_capacity(ctx, &s.d_off2, &s.cap_off2, n + 1))) return rc;
+  }
+  const bool hasq = ctx->q8 != 0;
+  if (hasq) {
+    if ((rc = ensure_capacity(ctx, &s.d_qual1, &s.cap_qual1, bytes1 + 16))) return rc;
+    if (paired && (rc = ensure_capacity(ctx, &s.d_qual2, &s.cap_qual2, bytes2 + 16))) return rc;
+  }
+  if (n) {
+    SHK_HIP(ctx, hipMemcpyAsync(s.d_seq1, b->seq1, bytes1, hipMemcpyHostToDevice, up));
+    if (paired) SHK_HIP(ctx, hipMemcpyAsync(s.d_seq2, b->seq2, bytes2, hipMemcpyHostToDevice, up));
+    if (hasq) {
+      SHK_HIP(ctx, hipMemcpyAsync(s.d_qual1, b->qual1, bytes1, hipMemcpyHostToDevice, up));
+      if (paired) SHK_HIP(ctx, hipMemcpyAsync(s.d_qual2, b->qual2, bytes2, hipMemcpyHostToDevice, up));
+    }
+    if (uniform) {
+      if ((rc = launch_fill_offsets(s.d_off1, n + 1, f1, st))) return rc;
+      if (paired && (rc = launch_fill_offsets(s.d_off2, n + 1, f2, st))) return rc;
+    } else {
+      SHK_HIP(ctx, hipMemcpyAsync(s.d_off1, b->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+      if (paired) SHK_HIP(ctx, hipMemcpyAsync(s.d_off2, b->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+    }
+  }
+  SHK_HIP(ctx, hipEventRecord(s.ev_h2d, up));
+  SHK_HIP(ctx, hipStreamWaitEvent(st, s.ev_h2d, 0));
+  d.seq1 = (const char *)s.d_seq1; d.off1 = s.d_off1;
+  if (paired) { d.seq2 = (const char *)s.d_seq2; d.off2 = s.d_off2; }
+  if (hasq) { d.qual1 = (const char *)s.d_qual1; if (paired) d.qual2 = (const char *)s.d_qual2; }
+  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true))) return rc;
+  s.host_batch = true;
+  s.ticket = ctx->next_ticket++;
+  s.waited = false;
+  *ticket = s.ticket;
+  return SHK_OK;
+}
+
+int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
+{
+  if (!ctx || !result || ticket == 0) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  Slot &s = ctx->slots[(ticket - 1) % PIPE_DEPTH];
+  if (s.ticket != ticket || s.waited) { ctx->last_error = "unknown or already waited ticket"; return SHK_ERR_STATE; }
+  SHK_HIP(ctx, hipEventSynchronize(s.ev_done));
+  bool redone = false;
+  int rc = finish_classify(ctx, s, false, true, &redone);
+  if (rc) { s.waited = true; return rc; }
+  const uint64_t n = s.n;
+  const uint64_t n_assoc = ((uint64_t)s.h_counters[CTR_ASSOC_HI] << 32) | s.h_counters[CTR_ASSOC_LO];
+  if ((rc = ensure_pinned(ctx, &s.h_gene_off, &s.cap_h_gene_off, n + 1))) return rc;
+  if ((rc = ensure_pinned(ctx, &s.h_gene_ids, &s.cap_h_gene_ids, n_assoc + 1))) return rc;
+  hipStream_t down = ctx->d2h_stream;
+  SHK_HIP(ctx, hipMemcpyAsync(s.h_gene_off, s.d_gene_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, down));
+  if (n_assoc) SHK_HIP(ctx, hipMemcpyAsync(s.h_gene_ids, s.d_gene_ids, n_assoc * sizeof(uint16_t), hipMemcpyDeviceToHost, down));
+  SHK_HIP(ctx, hipStreamSynchronize(down));
+  s.waited = true;
+  ctx->last.last_n_reads = n;
+  ctx->last.last_n_long = s.h_counters[CTR_LONG];
+  ctx->last.last_n_tie = s.h_counters[CTR_TIE];
+  ctx->last.last_n_assoc = n_assoc;
+  result->n = n;
+  result->gene_off = s.h_gene_off;
+  result->gene_ids = s.h_gene_ids;
+  result->n_assoc = n_assoc;
+  return SHK_OK;
 }
 
 int shk_classify(shk_ctx *ctx, const shk_batch *b, shk_result *result)
 {
   if (!ctx || !result) return SHK_ERR_ARG;
-  if (ctx->mode != 2) return SHK_ERR_STATE;
-  int rc = check_batch(ctx, b);
+  uint64_t t = 0;
+  int rc = shk_classify_submit(ctx, b, &t);
   if (rc) return rc;
-  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
-  hipStream_t st = ctx->stream;
-  const uint64_t n = b->n;
-  const uint64_t bytes1 = n ? b->off1[n] : 0;
-  const uint64_t bytes2 = (n && b->seq2) ? b->off2[n] : 0;
-  // longest mate: selects the kernel specialisation only
-  uint32_t max_len = 1;
-  for (uint64_t i = 0; i < n; ++i) {
-    if (b->off1[i + 1] < b->off1[i]) return SHK_ERR_ARG;
-    max_len = std::max<uint64_t>(max_len, std::min<uint64_t>(b->off1[i + 1] - b->off1[i], 0xFFFFFFFFull));
-    if (b->seq2) {
-      if (b->off2[i + 1] < b->off2[i]) return SHK_ERR_ARG;
-      max_len = std::max<uint64_t>(max_len, std::min<uint64_t>(b->off2[i + 1] - b->off2[i], 0xFFFFFFFFull));
-    }
-  }
-  shk_batch d{};
-  d.n = n;
-  if ((rc = ensure_capacity(ctx, &ctx->d_seq1, &ctx->cap_seq1, bytes1 + 16))) return rc;
-  if ((rc = ensure_capacity(ctx, &ctx->d_off1, &ctx->cap_off1, n + 1))) return rc;
-  if (n) {
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_seq1, b->seq1, bytes1, hipMemcpyHostToDevice, st));
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_off1, b->off1, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-  }
-  d.seq1 = (const char *)ctx->d_seq1;
-  d.off1 = ctx->d_off1;
-  if (b->seq2 && n) {
-    if ((rc = ensure_capacity(ctx, &ctx->d_seq2, &ctx->cap_seq2, bytes2 + 16))) return rc;
-    if ((rc = ensure_capacity(ctx, &ctx->d_off2, &ctx->cap_off2, n + 1))) return rc;
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_seq2, b->seq2, bytes2, hipMemcpyHostToDevice, st));
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_off2, b->off2, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    d.seq2 = (const char *)ctx->d_seq2;
-    d.off2 = ctx->d_off2;
-  }
-  if (ctx->prm.min_quality != 0 && n) {
-    if ((rc = ensure_capacity(ctx, &ctx->d_qual1, &ctx->cap_qual1, bytes1 + 16))) return rc;
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->d_qual1, b->qual1, bytes1, hipMemcpyHostToDevice, st));
-    d.qual1 = (const char *)ctx->d_qual1;
-    if (b->seq2) {
-      if ((rc = ensure_capacity(ctx, &ctx->d_qual2, &ctx->cap_qual2, bytes2 + 16))) return rc;
-      SHK_HIP(ctx, hipMemcpyAsync(ctx->d_qual2, b->qual2, bytes2, hipMemcpyHostToDevice, st));
-      d.qual2 = (const char *)ctx->d_qual2;
-    }
-  }
-  shk_result dr{};
-  if ((rc = classify_core(ctx, &d, max_len, &dr))) return rc;
-  try {
-    ctx->h_gene_off.resize(n + 1);
-    ctx->h_gene_ids.resize(dr.n_assoc + 1);
-  } catch (...) {
-    return SHK_ERR_NOMEM;
-  }
-  SHK_HIP(ctx, hipMemcpyAsync(ctx->h_gene_off.data(), dr.gene_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  if (dr.n_assoc)
-    SHK_HIP(ctx, hipMemcpyAsync(ctx->h_gene_ids.data(), dr.gene_ids, dr.n_assoc * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
-  SHK_HIP(ctx, hipStreamSynchronize(st));
-  result->n = n;
-  result->gene_off = ctx->h_gene_off.data();
-  result->gene_ids = ctx->h_gene_ids.data();
-  result->n_assoc = dr.n_assoc;
-  return SHK_OK;
+  return shk_classify_wait(ctx, t, result);
 }
 
 int shk_gene_counts(shk_ctx *ctx, uint64_t *counts, uint32_t n)
@@ -453,37 +725,11 @@ int shk_gene_counts_reset(shk_ctx *ctx)
   return SHK_OK;
 }
 
-// ---- RCCL, loaded on first use so that single-GPU users never pay for (or conflict over) it ----
-namespace {
-typedef void *rccl_comm_t;
-struct RcclApi {
-  void *lib = nullptr;
-  int (*CommInitAll)(rccl_comm_t *, int, const int *) = nullptr;
-  int (*CommDestroy)(rccl_comm_t) = nullptr;
-  int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  bool ok = false;
-};
-RcclApi &rccl()
-{
-  static RcclApi api;
-  if (!api.lib) {
-    api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (api.lib) {
-      api.CommInitAll = (int (*)(rccl_comm_t *, int, const int *))dlsym(api.lib, "ncclCommInitAll");
-      api.CommDestroy = (int (*)(rccl_comm_t))dlsym(api.lib, "ncclCommDestroy");
-      api.AllReduce = (int (*)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.lib, "ncclAllReduce");
-      api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
-      api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
-      api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
-    }
-  }
-  return api;
-}
-}  // namespace
+// ---- the path's one exchange step: all-reduce of the per-gene counters over RCCL ------------------
+// Both forms reduce INTO the contexts' separate totals buffers: the per-GPU counters stay local, so classifying more
+// reads and reducing again gives the totals again (not totals times the number of GPUs).
 
+// one process, several GPUs (one context per GPU): `shark --gpus N`
 int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint32_t n)
 {
   if (!ctxs || n_ctx < 1 || n > 65536) return SHK_ERR_ARG;
@@ -495,42 +741,91 @@ int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint3
     SHK_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
   }
   const char *force = getenv("SHK_FORCE_RCCL");
+  const unsigned long long *src = c0->d_gene_counts;
   if (n_ctx > 1 || (force && force[0] == '1')) {
     RcclApi &api = rccl();
     if (!api.ok) { c0->last_error = "librccl.so.1 could not be loaded"; return SHK_ERR_HIP; }
     std::vector<int> devs((size_t)n_ctx);
     for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->prm.device;
-    std::vector<rccl_comm_t> comms((size_t)n_ctx, nullptr);
-    // RCCL may print a version banner on stdout when it initialises; stdout is the ssv stream of
-    // the CLI (ReadOutput.hpp:43), so anything RCCL prints during init is sent to stderr instead
-    fflush(stdout);
-    const int saved_stdout = dup(1);
-    if (saved_stdout >= 0) (void)dup2(2, 1);
-    const int init_rc = api.CommInitAll(comms.data(), n_ctx, devs.data());
-    if (saved_stdout >= 0) {
-      fflush(stdout);
-      (void)dup2(saved_stdout, 1);
-      close(saved_stdout);
+    // the communicators of a group of contexts are created once and live in the contexts
+    bool have = true;
+    for (int i = 0; i < n_ctx; ++i) have = have && ctxs[i]->group_comm && ctxs[i]->group_devs == devs;
+    if (!have) {
+      for (int i = 0; i < n_ctx; ++i)
+        if (ctxs[i]->group_comm) { (void)api.CommDestroy(ctxs[i]->group_comm); ctxs[i]->group_comm = nullptr; }
+      std::vector<rccl_comm_t> comms((size_t)n_ctx, nullptr);
+      const int init_rc = with_stdout_on_stderr([&] { return api.CommInitAll(comms.data(), n_ctx, devs.data()); });
+      if (init_rc != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
+      for (int i = 0; i < n_ctx; ++i) { ctxs[i]->group_comm = comms[(size_t)i]; ctxs[i]->group_devs = devs; }
     }
-    if (init_rc != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
     int rc = api.GroupStart();
     for (int i = 0; i < n_ctx && rc == 0; ++i) {
       (void)hipSetDevice(devs[(size_t)i]);
-      // ncclUint64 = 5, ncclSum = 0; in place on every GPU's 65 536 x 8 B counter block
-      rc = api.AllReduce(ctxs[i]->d_gene_counts, ctxs[i]->d_gene_counts, 65536, 5, 0, comms[(size_t)i], ctxs[i]->stream);
+      // ncclUint64 = 5, ncclSum = 0; 65 536 x 8 B per GPU
+      rc = api.AllReduce(ctxs[i]->d_gene_counts, ctxs[i]->d_gene_totals, 65536, 5, 0, ctxs[i]->group_comm, ctxs[i]->stream);
     }
     if (rc == 0) rc = api.GroupEnd();
     for (int i = 0; i < n_ctx; ++i) {
       (void)hipSetDevice(devs[(size_t)i]);
       (void)hipStreamSynchronize(ctxs[i]->stream);
-      (void)api.CommDestroy(comms[(size_t)i]);
     }
     if (rc != 0) { c0->last_error = "ncclAllReduce failed"; return SHK_ERR_HIP; }
+    src = c0->d_gene_totals;
   }
   if (totals) {
     SHK_HIP(c0, hipSetDevice(c0->prm.device));
-    SHK_HIP(c0, hipMemcpy(totals, c0->d_gene_counts, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    SHK_HIP(c0, hipMemcpy(totals, src, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
+  return SHK_OK;
+}
+
+// one process per GPU (torch.distributed.run / mpirun style launchers): rank 0 makes an id, the launcher's own
+// channel carries its SHK_DIST_ID_BYTES bytes to the other ranks, every rank joins with its context
+int shk_dist_unique_id(uint8_t *id)
+{
+  if (!id) return SHK_ERR_ARG;
+  RcclApi &api = rccl();
+  if (!api.ok) return SHK_ERR_HIP;
+  rccl_uid u;
+  if (api.GetUniqueId(&u) != 0) return SHK_ERR_HIP;
+  static_assert(sizeof(u) == SHK_DIST_ID_BYTES, "ncclUniqueId is 128 bytes");
+  memcpy(id, &u, sizeof(u));
+  return SHK_OK;
+}
+
+int shk_dist_init(shk_ctx *ctx, const uint8_t *id, int rank, int world)
+{
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return SHK_ERR_ARG;
+  RcclApi &api = rccl();
+  if (!api.ok) { ctx->last_error = "librccl.so.1 could not be loaded"; return SHK_ERR_HIP; }
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  if (ctx->dist_comm) { (void)api.CommDestroy(ctx->dist_comm); ctx->dist_comm = nullptr; }
+  rccl_uid u;
+  memcpy(&u, id, sizeof(u));
+  rccl_comm_t comm = nullptr;
+  const int rc = with_stdout_on_stderr([&] { return api.CommInitRank(&comm, world, u, rank); });
+  if (rc != 0) { ctx->last_error = "ncclCommInitRank failed"; return SHK_ERR_HIP; }
+  ctx->dist_comm = comm;
+  ctx->dist_rank = rank;
+  ctx->dist_world = world;
+  return SHK_OK;
+}
+
+int shk_dist_gene_counts_allreduce(shk_ctx *ctx, uint64_t *totals, uint32_t n)
+{
+  if (!ctx || n > 65536) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  const unsigned long long *src = ctx->d_gene_counts;
+  if (ctx->dist_comm) {
+    // stream order: behind every classify call enqueued so far
+    if (rccl().AllReduce(ctx->d_gene_counts, ctx->d_gene_totals, 65536, 5, 0, ctx->dist_comm, ctx->stream) != 0) {
+      ctx->last_error = "ncclAllReduce failed";
+      return SHK_ERR_HIP;
+    }
+    src = ctx->d_gene_totals;
+  }
+  SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (totals) SHK_HIP(ctx, hipMemcpy(totals, src, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SHK_OK;
 }
 
@@ -567,7 +862,7 @@ int shk_count_work(shk_ctx *ctx, const shk_batch *b, shk_work_counters *out)
   if (rc) return rc;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
   shk_result tmp{};
-  return classify_core(ctx, b, 0, &tmp, out);
+  return classify_resident(ctx, b, 0, &tmp, out);
 }
 
 void *shk_alloc_pinned(size_t bytes)

@@ -35,9 +35,8 @@ namespace shk {
 //              16-byte load instead of filter word + rank word + entry.
 //              Buckets of two 8-byte slots, linear probing over buckets, home
 //              bucket = pos & (n_buckets-1) (pos is already a hash).  Slot:
-//                [63:40] tag = pos >> tab_lg   [39] valid   [38] multi
-//                [37:32] displacement (buckets from home)
-//                [31:0]  gene (single-gene list) or rank r (multi: ent[r])
+//                high word: [31:8] tag = pos >> tab_lg   [7] valid   [5:0] displacement (buckets from home)
+//                low word : [31] multi   [30:0] gene (single-gene list) or rank r (multi: ent[r])
 //              The filter itself stays in HBM as the ground truth (it defines
 //              rank, is exported, and is what the tests compare bit for bit).
 constexpr uint32_t LDS_SUM_LOG2 = 18;                 // 2^18 bits = 32 KiB of LDS per workgroup
@@ -107,7 +106,8 @@ struct ClassifyParams {
   uint64_t bf_mask;
   // options
   uint32_t k;
-  int32_t mq;        // 0 = no masking, else min_quality + 33 (FastqSplitter.hpp:70)
+  uint32_t hasq;     // 0 = no masking (the reference's `char min_quality` is 0, FastqSplitter.hpp:52)
+  int32_t mq;        // (signed char)(min_quality + 33), FastqSplitter.hpp:70 -- wraps for -q > 94 exactly as the reference's char does
   int32_t single;
   double c;
   // batch
@@ -124,6 +124,8 @@ struct ClassifyParams {
   // work list for the general kernel (nullptr => all reads 0..n)
   const uint32_t *work;
   uint64_t n_work;
+  const uint32_t *work_count;      // non-null: the number of work items is read from the device (tie queue) instead of n_work
+  const uint32_t *flags;           // the launch's counters (CTR_OVERFLOW is honoured by the kernels that write gene_ids)
   // general-kernel scratch (per wave)
   uint64_t *scratch;
   uint64_t scratch_stride_words;   // per wave
@@ -141,11 +143,46 @@ struct ClassifyParams {
 enum {
   CTR_LONG = 0,      // entries in long_queue
   CTR_TIE = 1,       // entries in tie_queue
-  CTR_UNUSED2 = 2,
+  CTR_OVERFLOW = 2,  // 1 = the batch has more associations than gene_ids holds (finalize_total_kernel)
   CTR_UNUSED3 = 3,
   CTR_MAX_SLOTS = 4, // max k-mer slots over queued long reads
   CTR_UNUSED5 = 5,
+  CTR_ASSOC_LO = 6,  // number of associations of the batch (the scan's total), 64 bits
+  CTR_ASSOC_HI = 7,
   CTR_WORDS = 8
+};
+
+// ---- one batch in flight ---------------------------------------------------------------------
+constexpr int PIPE_DEPTH = 3;      // batches shk_classify_submit keeps in flight per context
+
+struct Slot {
+  // device copies of a host batch (host-buffer entry points only)
+  uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr, *d_qual1 = nullptr, *d_qual2 = nullptr;
+  uint64_t *d_off1 = nullptr, *d_off2 = nullptr;
+  size_t cap_seq1 = 0, cap_seq2 = 0, cap_qual1 = 0, cap_qual2 = 0, cap_off1 = 0, cap_off2 = 0;
+  // device results
+  uint32_t *d_count = nullptr;    size_t cap_count = 0;
+  uint16_t *d_inl = nullptr;      size_t cap_inl = 0;
+  uint32_t *d_gene_off = nullptr; size_t cap_gene_off = 0;
+  uint16_t *d_gene_ids = nullptr; size_t cap_gene_ids = 0;
+  uint32_t *d_long_queue = nullptr; size_t cap_long_queue = 0;
+  uint32_t *d_tie_queue = nullptr;  size_t cap_tie_queue = 0;
+  uint32_t *d_counters = nullptr;
+  uint64_t *d_scan_temp = nullptr; size_t cap_scan_temp = 0;
+  ClassifyOut *d_out = nullptr;
+  ClassifyOut out_shadow{};        // what *d_out holds (rewritten only when a buffer moved)
+  // pinned host: counters, result offsets and ids
+  uint32_t *h_counters = nullptr;  // CTR_WORDS
+  uint32_t *h_gene_off = nullptr;  size_t cap_h_gene_off = 0;
+  uint16_t *h_gene_ids = nullptr;  size_t cap_h_gene_ids = 0;
+  hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
+  // the batch
+  uint64_t ticket = 0;             // 0 = free
+  bool waited = true;              // its results were handed out (the slot may be reused by a later submit)
+  uint64_t n = 0;
+  ClassifyParams p{};              // launch parameters (kept for the slow paths)
+  uint32_t fast_cap = 0, gen_slots = 0;
+  bool host_batch = false;
 };
 
 struct Ctx;
@@ -158,7 +195,10 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
 const char *probe_mode_name(const Ctx *ctx);
 int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream);
 int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n,
-                         unsigned long long *gene_counts, hipStream_t stream);
+                         const uint32_t *counters, hipStream_t stream);
+int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t gene_ids_cap, hipStream_t stream);
+int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, hipStream_t stream);
+int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
 uint32_t fast_kernel_max_slots();
 uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
 
@@ -175,27 +215,21 @@ struct Ctx {
   DeviceIndex idx;
   uint64_t n_records = 0, nidx = 0, n_ref_kmers = 0;
 
-  // classify workspace (device), grown on demand
-  uint8_t *d_seq1 = nullptr, *d_seq2 = nullptr, *d_qual1 = nullptr, *d_qual2 = nullptr;
-  uint64_t *d_off1 = nullptr, *d_off2 = nullptr;
-  size_t cap_seq1 = 0, cap_seq2 = 0, cap_qual1 = 0, cap_qual2 = 0, cap_off1 = 0, cap_off2 = 0;
-  uint32_t *d_count = nullptr;    size_t cap_count = 0;
-  uint16_t *d_inl = nullptr;      size_t cap_inl = 0;
-  uint32_t *d_gene_off = nullptr; size_t cap_gene_off = 0;
-  uint16_t *d_gene_ids = nullptr; size_t cap_gene_ids = 0;
-  uint32_t *d_long_queue = nullptr; size_t cap_long_queue = 0;
-  uint32_t *d_tie_queue = nullptr;  size_t cap_tie_queue = 0;
-  uint32_t *d_counters = nullptr;
-  uint64_t *d_scan_temp = nullptr; size_t cap_scan_temp = 0;
+  // classify workspace: one Slot per batch in flight (PIPE_DEPTH for shk_classify_submit/_wait plus one for
+  // shk_classify_device); the general kernel's scratch is shared (kernels of one context run on one stream)
+  Slot slots[PIPE_DEPTH + 1];
+  uint64_t next_ticket = 1;
+  hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
   uint64_t *d_scratch = nullptr;   size_t cap_scratch = 0;
   unsigned long long *d_gene_counts = nullptr;
+  unsigned long long *d_gene_totals = nullptr;   // result of the all-reduce (the per-GPU counters stay local)
   unsigned long long *d_work_counters = nullptr;
-  ClassifyOut *d_out = nullptr;
-  uint32_t *h_counters = nullptr;  // pinned, CTR_WORDS + 2 (the scan total lands behind the counters)
-
-  // host result buffers
-  std::vector<uint32_t> h_gene_off;
-  std::vector<uint16_t> h_gene_ids;
+  int8_t q8 = 0;                                  // min_quality as the reference's `char` (argument_parser.hpp:59,:144)
+  // RCCL communicators, created once: one-process-per-GPU (shk_dist_init) and one-process-many-GPUs (allreduce over contexts)
+  void *dist_comm = nullptr;
+  int dist_rank = 0, dist_world = 1;
+  void *group_comm = nullptr;
+  std::vector<int> group_devs;
 
   // timing
   bool timing = false;

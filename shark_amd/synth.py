@@ -19,6 +19,19 @@ def make_reference(n_genes, gene_len, seed=SEED):
     return [acgt[rng.integers(0, 4, size=L)] for L in lens]
 
 
+def make_gencode_like_reference(n_genes=60000, seed=SEED):
+    """BASELINE configs[2..4] reference: gene lengths lognormal(median 2 kb) clipped to
+    [200, 20 000] (60 000 genes = 1.78e8 bases), uniform ACGT, every 10th gene shares its first half
+    with its predecessor (forces multi-gene lists and ties).  Returns a list of numpy uint8 arrays."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.exp(rng.normal(np.log(2000), 0.9, size=n_genes)), 200, 20000).astype(np.int64)
+    genes = make_reference(n_genes, lens, seed=seed)
+    for g in range(9, n_genes, 10):
+        h = min(len(genes[g - 1]) // 2, len(genes[g]))
+        genes[g][:h] = genes[g - 1][:h]
+    return genes
+
+
 def make_pairs_device(n, genes, device, seed=SEED, read_len=150, on_target=0.5, sub_rate=0.01, n_rate=0.002,
                       with_qual=False, chunk=1 << 20):
     """n pairs of fixed-length mates resident on `device`.

@@ -332,23 +332,42 @@ def test_non_ascii_and_control_bytes_are_invalid(oracle):
     assert 200 < goff[-1] < 1500
 
 
-def test_bench_two_ranks_dry_run(tmp_path):
-    """the N>1 code path of bench.py (rank env, barrier, MAX over ranks, count all-reduce) with two ranks sharing
-    the one GPU of the test box over gloo; the real multi-GPU run uses RCCL"""
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_dry_run(tmp_path, scaling):
+    """the N>1 code path of bench.py (rank env, shards of one read set, barrier, MAX over ranks, count all-reduce) with
+    two ranks sharing the one GPU of the test box over gloo; the real multi-GPU run uses RCCL inside the library"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SHARK_DIST_BACKEND="gloo")
+    base = [os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "250000", "--total-pairs", "1000000",
+            "--scaling", scaling, "--no-configs", "--no-boundary", "--no-cpu-baseline"]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--pairs", "500000"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+                        "--master-port", str(_free_port())] + base + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
-    j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["config"]["reads_per_step"] == 2 * 2 * 500000
-    assert j["cpu_baseline"] is None and j["scaling"] == "weak"
-    assert j["config"]["gene_count_checksum"] == 2 * j["config"]["assoc_per_step"]   # 2 steps, both ranks summed
+    j = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["cpu_baseline"] is None
+    assert j["config"]["gene_count_checksum"] == j["config"]["assoc_per_step"] > 0
+    if scaling == "strong":
+        # the same read set on one GPU: same reads per step, same associations
+        r1 = subprocess.run([sys.executable] + base + ["--gpus", "1"], capture_output=True, text=True, cwd=root, timeout=600)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        j1 = json.loads([x for x in r1.stdout.splitlines() if x.startswith("{")][-1])
+        assert j["config"]["reads_per_step"] == j1["config"]["reads_per_step"] == 2 * 1000000
+        assert j["config"]["assoc_per_step"] == j1["config"]["assoc_per_step"]
+        assert j1["config"]["launches_per_step_per_gpu"] == 2 * j["config"]["launches_per_step_per_gpu"]
+    else:
+        assert j["config"]["reads_per_step"] == 2 * 2 * 250000
 
 
 def test_cli_block_reader_handover_on_irregular_records(oracle, tmp_path):
@@ -561,3 +580,98 @@ def test_cli_filter_size_not_a_power_of_two(oracle, bf_bits):
     batch = synth.make_reads(rng, genes, 4000, read_len=150, paired=True, on_target=0.5, n_rate=0.005)
     goff, _ = _compare_classify(o, h, batch)
     assert goff[-1] > 1000
+
+
+# ---------------------------------------------------------------------------
+# the pipelined boundary (shk_classify_submit / shk_classify_wait) and the paths without a host round trip
+# ---------------------------------------------------------------------------
+def test_pipelined_submit_wait_equals_oracle(oracle):
+    """PIPE_DEPTH batches in flight; every batch equals the oracle; tickets are waited in order; a fourth
+    outstanding submit is refused; gene counters equal the histogram over all batches"""
+    from shark_amd import SharkHipError
+    from shark_amd.capi import SHK_PIPE_DEPTH
+    rng = np.random.default_rng(31)
+    genes = synth.make_genes(rng, 20, 300, 1500, share_every=3)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 24)
+    batches = [synth.make_reads(rng, genes, 700 + 200 * i, read_len=150 if i % 2 == 0 else 100, paired=True, on_target=0.7,
+                                var_len=(i == 3)) for i in range(7)]
+    batches.append(synth.batch_from_lists([], []))                     # an empty batch in the middle of a stream
+    batches.append(synth.make_reads(rng, genes, 300, read_len=80, paired=False, on_target=0.7))
+    want = [o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"]) if len(b["off1"]) > 1 else (np.zeros(1, np.uint32), np.zeros(0, np.uint16))
+            for b in batches]
+    h.gene_counts_reset()
+    tickets, got = [], []
+    for i, b in enumerate(batches):
+        if len(tickets) == SHK_PIPE_DEPTH:
+            with pytest.raises(SharkHipError, match="not allowed"):
+                h.submit(b["seq1"], b["off1"], b["seq2"], b["off2"])
+            got.append(h.wait(tickets.pop(0)))
+        tickets.append(h.submit(b["seq1"], b["off1"], b["seq2"], b["off2"]))
+    while tickets:
+        got.append(h.wait(tickets.pop(0)))
+    for (wg, wi), (gg, gi) in zip(want, got):
+        assert np.array_equal(wg, gg) and np.array_equal(wi, gi)
+    allids = np.concatenate([w[1] for w in want])
+    assert np.array_equal(h.gene_counts(32), np.bincount(allids, minlength=32)[:32].astype(np.uint64))
+
+
+def test_more_associations_than_reserved(oracle):
+    """every read ties over 6 genes: 6n associations exceed the 2n+4096 the slot reserves, so the batch is finished by
+    the overflow path (grow, redo the tail) -- and is still counted exactly once"""
+    rng = np.random.default_rng(37)
+    core = synth.random_seq(rng, 1200)
+    genes = [core.copy() for _ in range(6)]
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 24)
+    b = synth.make_reads(rng, [core], 6000, read_len=100, paired=True, on_target=1.0, sub_rate=0.0, n_rate=0.0)
+    h.gene_counts_reset()
+    goff, gids = _compare_classify(o, h, b)
+    assert int(goff[-1]) == 6 * 6000 > 2 * 6000 + 4096
+    assert np.array_equal(h.gene_counts(8), np.array([6000] * 6 + [0, 0], dtype=np.uint64))
+    goff2, gids2 = _compare_classify(o, h, b)                          # now the buffer is large enough: fast path
+    assert np.array_equal(h.gene_counts(8), np.array([12000] * 6 + [0, 0], dtype=np.uint64))
+
+
+def test_device_api_with_a_wrong_length_bound(oracle):
+    """shk_classify_device trusts max_read_len only for the choice of kernel: reads longer than the bound are found
+    after the fact and finished by the general kernel; per-gene counts are still exact"""
+    from shark_amd.capi import hip_memcpy_dtoh
+    rng = np.random.default_rng(41)
+    genes = synth.make_genes(rng, 6, 3000, 6000)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 24)
+    b1 = synth.make_reads(rng, genes, 300, read_len=100, paired=True, on_target=0.8)
+    b2 = synth.make_reads(rng, genes, 100, read_len=900, paired=True, on_target=0.8)   # 900+884 slots > 512
+    m1 = [bytes(b1["seq1"][int(b1["off1"][i]):int(b1["off1"][i + 1])]) for i in range(300)] + \
+         [bytes(b2["seq1"][int(b2["off1"][i]):int(b2["off1"][i + 1])]) for i in range(100)]
+    m2 = [bytes(b1["seq2"][int(b1["off2"][i]):int(b1["off2"][i + 1])]) for i in range(300)] + \
+         [bytes(b2["seq2"][int(b2["off2"][i]):int(b2["off2"][i + 1])]) for i in range(100)]
+    order = rng.permutation(400)
+    b = synth.batch_from_lists([m1[i] for i in order], [m2[i] for i in order])
+    og, oi = o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"])
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for k, v in b.items() if v is not None}
+    for bound in (100, 0, 900):
+        h.gene_counts_reset()
+        r = h.classify_device(400, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=bound)
+        goff = np.empty(401, np.uint32)
+        hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+        gids = np.empty(int(r.n_assoc), np.uint16)
+        hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+        assert np.array_equal(goff, og) and np.array_equal(gids, oi), bound
+        assert h.timing()["last_n_long"] == 100
+        assert np.array_equal(h.gene_counts(8), np.bincount(oi, minlength=8)[:8].astype(np.uint64)), bound
+
+
+@pytest.mark.parametrize("q", [94, 95, 100, 222, 223, 256, 300])
+def test_min_quality_wraps_like_the_reference_char(oracle, q):
+    """argument_parser.hpp:144 stores -q in a `char` and FastqSplitter.hpp:70 adds 33 in a `char`: values above 94 wrap
+    (and 256 is `no masking`); quality bytes are compared as signed chars, so bytes >= 128 are below most thresholds"""
+    rng = np.random.default_rng(43)
+    genes = synth.make_genes(rng, 8, 300, 900)
+    o, h, _ = _build_both(oracle, genes, k=15, bf_bits=1 << 22, min_quality=q, c=0.3)
+    b = synth.make_reads(rng, genes, 800, read_len=100, paired=True, on_target=0.8, qual=True)
+    for key in ("qual1", "qual2"):                                      # sprinkle every byte value, negative chars included
+        qa = b[key]
+        idx = rng.random(len(qa)) < 0.08
+        qa[idx] = rng.integers(0, 256, size=int(idx.sum())).astype(np.uint8)
+    goff, _ = _compare_classify(o, h, b)
+    assert goff[-1] > 0

@@ -1,0 +1,103 @@
+"""GPU parity at the index sizes shark is used at: BASELINE configs[2] and configs[4] shapes.
+
+  configs[2]/[3]: GENCODE-shaped reference (60 000 genes, 1.78e8 bases), k=17, 2^36-bit filter (-b 8)
+  configs[4]    : same reference, k=31, -q 20, --single, 2^37-bit filter (-b 16)
+
+10 M device-resident 2x150 bp pairs each (one launch of the 100 M / 200 M-pair streams the configs
+name; the per-GPU shard of the 8-GPU configs).  Checked per config:
+  * the index built on the device equals the oracle's: set bits, list total, every gene list
+    (and, for the 8 GiB filter, every filter word)
+  * both probe chains (position table vs filter words + rank directory) give identical results
+  * a 200 000-pair sample of the batch is bit-equal to the oracle's associations
+  * per-gene counters equal the histogram of the per-read results
+The oracle builds each index in ~80 s single-threaded (pass 2 of the reference is single-threaded,
+main.cpp:154-189), which is what sizes this file's run time (~4 min)."""
+import os
+
+import numpy as np
+import pytest
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = 10_000_000
+SAMPLE = 200_000
+L = 150
+
+
+def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words):
+    from shark_amd import SharkHip, synth
+    from shark_amd.capi import hip_memcpy_dtoh
+    genes = synth.make_gencode_like_reference(60000)
+    gbytes = [g.tobytes() for g in genes]
+    dev = torch.device("cuda:0")
+    batch = synth.make_pairs_device(PAIRS, genes, dev, seed=synth.SEED + 7, read_len=L, with_qual=q > 0)
+    torch.cuda.synchronize()
+    ptr = {kk: (v.data_ptr() if v is not None else 0) for kk, v in batch.items()}
+
+    o = oracle.Shark(k=k, c=0.6, bf_bits=1 << bf_log2, min_quality=q, single=single)
+    nidx = o.build(gbytes)
+
+    res = {}
+    for mode in ("auto", "bitvector"):
+        if mode == "bitvector":
+            monkeypatch.setenv("SHK_PROBE", "bitvector")
+        else:
+            monkeypatch.delenv("SHK_PROBE", raising=False)
+        h = SharkHip(k=k, c=0.6, bf_bits=1 << bf_log2, min_quality=q, single=single)
+        info = h.build(gbytes)
+        assert ("table" in h.probe_mode()) == (mode == "auto"), h.probe_mode()
+        assert info["nidx"] == nidx == 60000
+        assert info["n_set_bits"] == o.num_kmer()
+        if mode == "auto":
+            off, ids = h.copy_lists()
+            oi = o.index_kmer()
+            assert info["tot_idx"] == len(oi) == int(off[-1])
+            assert np.array_equal(ids, oi), "gene lists differ from the oracle's _index_kmer"
+            del off, ids, oi
+            if compare_words:
+                hw = h.copy_bf()
+                assert np.array_equal(hw, o.bf_words()), "filter words differ"
+                del hw
+        h.gene_counts_reset()
+        r = h.classify_device(PAIRS, ptr["seq1"], ptr["off1"], ptr["seq2"], ptr["off2"], ptr["qual1"], ptr["qual2"],
+                              max_read_len=L)
+        goff = np.empty(PAIRS + 1, np.uint32)
+        hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+        gids = np.empty(int(r.n_assoc), np.uint16)
+        if len(gids):
+            hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+        counts = h.gene_counts(65536)
+        assert np.array_equal(counts, np.bincount(gids, minlength=65536).astype(np.uint64))
+        res[mode] = (goff, gids)
+        h.close()
+    assert np.array_equal(res["auto"][0], res["bitvector"][0]) and np.array_equal(res["auto"][1], res["bitvector"][1]), \
+        "the two probe chains disagree"
+
+    hb = synth.to_host_sample(batch, SAMPLE, L)
+    og, oi = o.classify(hb["seq1"], hb["off1"], hb["seq2"], hb["off2"], hb["qual1"], hb["qual2"],
+                        nthreads=min(os.cpu_count() or 1, 64))
+    goff, gids = res["auto"]
+    assert np.array_equal(og, goff[:SAMPLE + 1]), "gene_off differs at read %d" % int(np.argmax(og != goff[:SAMPLE + 1]))
+    assert np.array_equal(oi, gids[:int(goff[SAMPLE])])
+    o.close()
+    return goff, gids
+
+
+def test_config2_gencode_scale_k17_8gb(oracle, monkeypatch):
+    """BASELINE configs[2] (and [3]'s per-GPU shard): 60 000 genes, k=17, c=0.6, bf = 2^36 bits."""
+    goff, gids = _scale_case(oracle, monkeypatch, k=17, bf_log2=36, q=0, single=False, compare_words=True)
+    cnt = np.diff(goff.astype(np.int64))
+    assert 0.45 * PAIRS < (cnt > 0).sum() < 0.60 * PAIRS     # half the pairs are drawn from genes
+    assert (cnt > 1).sum() > 100_000                          # shared gene halves: genuine ties
+
+
+def test_config4_gencode_scale_k31_q20_single_16gb(oracle, monkeypatch):
+    """BASELINE configs[4]: k=31 (max k), -q 20 (quality-mask path), --single, bf = 2^37 bits."""
+    goff, gids = _scale_case(oracle, monkeypatch, k=31, bf_log2=37, q=20, single=True, compare_words=False)
+    cnt = np.diff(goff.astype(np.int64))
+    assert cnt.max() == 1 and cnt.sum() > 50_000              # --single: never more than one gene per read
