@@ -674,4 +674,7 @@ def test_min_quality_wraps_like_the_reference_char(oracle, q):
         idx = rng.random(len(qa)) < 0.08
         qa[idx] = rng.integers(0, 256, size=int(idx.sum())).astype(np.uint8)
     goff, _ = _compare_classify(o, h, b)
-    assert goff[-1] > 0
+    if q in (95, 100, 256):                                             # thresholds that mask (almost) nothing
+        assert goff[-1] > 300
+    if q == 94:                                                         # threshold 127: every base is masked
+        assert goff[-1] == 0
