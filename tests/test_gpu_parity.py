@@ -678,3 +678,38 @@ def test_min_quality_wraps_like_the_reference_char(oracle, q):
         assert goff[-1] > 300
     if q == 94:                                                         # threshold 127: every base is masked
         assert goff[-1] == 0
+
+
+# ---------------------------------------------------------------------------
+# hand-worked cases (tests/golden/handworked.json): expected values derived on paper from the reference source
+# ---------------------------------------------------------------------------
+def _handworked():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "handworked.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _handworked(), ids=lambda c: c["name"])
+def test_handworked_cases(case, probe, tmp_path):
+    from tests.test_oracle import _handworked_batch
+    h = _hip(k=case["k"], c=case["c"], bf_bits=case["bf_bits"], min_quality=case["q"], single=case["single"])
+    info = h.build([seq.encode() for _, seq in case["fasta"]])
+    assert info["n_set_bits"] == case["distinct_kmers"]
+    batch, paired = _handworked_batch(case)
+    goff, gids = h.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"])
+    assert [list(map(int, gids[goff[i]:goff[i + 1]])) for i in range(len(case["reads"]))] == [r["genes"] for r in case["reads"]]
+    # end to end through the shark CLI: ssv bytes (-b 1 = 2^33 bits; the few k-mers of a case do not collide there either)
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">%s\n%s\n" % (n_, s_) for n_, s_ in case["fasta"]))
+    f1 = tmp_path / "r1.fq"
+    f1.write_text("".join("@%s\n%s\n+\n%s\n" % (r["id"], r["m1"], r["q1"]) for r in case["reads"]))
+    args = ["-r", str(fa), "-1", str(f1), "-k", str(case["k"]), "-c", str(case["c"]), "-q", str(case["q"]), "-b", "1",
+            "-o", str(tmp_path / "o1.fq")]
+    if paired:
+        f2 = tmp_path / "r2.fq"
+        f2.write_text("".join("@%s\n%s\n+\n%s\n" % (r["id"], r["m2"], r["q2"]) for r in case["reads"]))
+        args += ["-2", str(f2), "-p", str(tmp_path / "o2.fq")]
+    if case["single"]:
+        args.append("-s")
+    r = _run_shark(args, str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert r.stdout.decode() == case["ssv"]

@@ -219,3 +219,55 @@ def test_gene_numbering_quirk_in_oracle(oracle):
     o = oracle.Shark(k=17, c=0.6, bf_bits=1 << 22)
     assert o.build(recs) == 5                                   # main.cpp:165 skips ++nidx twice
     assert set(np.unique(o.index_kmer())) == {0, 2, 4}
+
+
+# ---------------------------------------------------------------------------
+# hand-worked cases: expected values derived on paper from the reference source
+# (tests/golden/handworked.json), so that a misreading shared by the oracle and
+# the kernels would show up here
+# ---------------------------------------------------------------------------
+def _handworked():
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "handworked.json")))["cases"]
+
+
+def _handworked_batch(case):
+    from tests import synth
+    paired = case["reads"][0]["m2"] is not None
+    m1 = [r["m1"].encode() for r in case["reads"]]
+    q1 = [r["q1"].encode() for r in case["reads"]]
+    m2 = [r["m2"].encode() for r in case["reads"]] if paired else None
+    q2 = [r["q2"].encode() for r in case["reads"]] if paired else None
+    return synth.batch_from_lists(m1, m2, q1, q2), paired
+
+
+@pytest.mark.parametrize("case", _handworked(), ids=lambda c: c["name"])
+def test_handworked_cases(oracle, case, tmp_path):
+    o = oracle.Shark(k=case["k"], c=case["c"], bf_bits=case["bf_bits"], min_quality=case["q"], single=case["single"])
+    o.build([seq.encode() for _, seq in case["fasta"]])
+    assert o.num_kmer() == case["distinct_kmers"]                      # no filter collision: the derivations' one assumption
+    L = oracle.lib()
+    batch, paired = _handworked_batch(case)
+    for r in case["reads"]:
+        s1, s2 = r["m1"].encode(), (r["m2"] or "").encode()
+        out = C.create_string_buffer(len(s1) + len(s2) + 2)
+        n = L.so_join_mask(s1, len(s1), r["q1"].encode(), s2 if paired else None, len(s2), r["q2"].encode() if paired else None,
+                           int(paired), bytes([case["q"]]), out)
+        genes, mx, mk, ln = o.analyze(out.raw[:n])
+        assert (ln, [mx, mk], genes) == (r["len"], r["best"], r["genes"]), r["id"]
+    goff, gids = o.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"])
+    assert [list(map(int, gids[goff[i]:goff[i + 1]])) for i in range(len(case["reads"]))] == [r["genes"] for r in case["reads"]]
+    # and end to end through the oracle CLI: ssv bytes
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">%s\n%s\n" % (n_, s_) for n_, s_ in case["fasta"]))
+    f1 = tmp_path / "r1.fq"
+    f1.write_text("".join("@%s\n%s\n+\n%s\n" % (r["id"], r["m1"], r["q1"]) for r in case["reads"]))
+    args = ["-r", str(fa), "-1", str(f1), "-k", str(case["k"]), "-c", str(case["c"]), "-q", str(case["q"]), "-b", "1",
+            "-o", str(tmp_path / "o1.fq")]
+    if paired:
+        f2 = tmp_path / "r2.fq"
+        f2.write_text("".join("@%s\n%s\n+\n%s\n" % (r["id"], r["m2"], r["q2"]) for r in case["reads"]))
+        args += ["-2", str(f2), "-p", str(tmp_path / "o2.fq")]
+    if case["single"]:
+        args.append("-s")
+    oracle.run_cli(args, str(tmp_path / "out.ssv"))
+    assert (tmp_path / "out.ssv").read_text() == case["ssv"]
