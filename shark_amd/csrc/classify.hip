@@ -916,6 +916,36 @@ __global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *_
     if (h_cnt[i]) atomicAdd(&gene_counts[h_key[i]], (unsigned long long)h_cnt[i]);
 }
 
+// Results leave the device through KERNEL STORES into pinned host memory, not through copy-engine commands: a
+// device-to-host copy enqueued behind a batch's kernels sits in the copy engine's in-order queue until those kernels
+// have finished, and the next batch's host-to-device copy queues up behind it -- measured on MI355X / ROCm 7.2: H2D and
+// kernels took turns (46 GB/s of a 57 GB/s link) until the last such copy was gone from the stream.
+// counters (8 words) -> host; gene_off[0..n] -> host; gene_ids[0..total) -> host (unless the batch overflowed)
+__global__ __launch_bounds__(256) void publish_results_kernel(const uint32_t *__restrict__ counters, uint32_t *__restrict__ h_counters,
+                                                             const uint32_t *__restrict__ gene_off, uint32_t *__restrict__ h_gene_off, uint64_t n_off,
+                                                             const uint16_t *__restrict__ gene_ids, uint16_t *__restrict__ h_gene_ids, uint64_t h_ids_cap)
+{
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+  if (h_gene_off) {
+    // 16 bytes per lane where aligned (both buffers come from hipMalloc / hipHostMalloc: 256-byte aligned)
+    const uint64_t n4 = n_off / 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(gene_off);
+    uint4 *dst = reinterpret_cast<uint4 *>(h_gene_off);
+    for (uint64_t i = tid; i < n4; i += nth) dst[i] = src[i];
+    for (uint64_t i = n4 * 4 + tid; i < n_off; i += nth) h_gene_off[i] = gene_off[i];
+    if (!counters[CTR_OVERFLOW]) {
+      const uint64_t total = ((uint64_t)counters[CTR_ASSOC_HI] << 32) | counters[CTR_ASSOC_LO];
+      const uint64_t m = total < h_ids_cap ? total : h_ids_cap;
+      const uint64_t m8 = m / 8;
+      const uint4 *s8 = reinterpret_cast<const uint4 *>(gene_ids);
+      uint4 *d8 = reinterpret_cast<uint4 *>(h_gene_ids);
+      for (uint64_t i = tid; i < m8; i += nth) d8[i] = s8[i];
+      for (uint64_t i = m8 * 8 + tid; i < m; i += nth) h_gene_ids[i] = gene_ids[i];
+    }
+  }
+  if (tid < CTR_WORDS) h_counters[tid] = counters[tid];
+}
+
 // off[i] = i * stride: batches whose reads all have one length need no offsets over PCIe
 __global__ void fill_offsets_kernel(uint64_t *__restrict__ off, uint64_t n_plus_1, uint64_t stride)
 {
@@ -1028,6 +1058,15 @@ int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool sk
   const uint64_t want = (n_reads + GI_THREADS - 1) / GI_THREADS;
   const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024));
   hipLaunchKernelGGL(gene_hist_kernel, dim3(grid), dim3(GI_THREADS), 0, stream, gene_ids, counters, skip_if_long ? 1u : 0u, gene_counts);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
+int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
+                           const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, hipStream_t stream)
+{
+  const uint64_t want = h_gene_off ? (n_off / 4 + 255) / 256 : 1;
+  hipLaunchKernelGGL(publish_results_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 512 ? want : 512))), dim3(256), 0, stream, counters, h_counters,
+                     gene_off, h_gene_off, n_off, gene_ids, h_gene_ids, h_ids_cap);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

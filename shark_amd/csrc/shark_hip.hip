@@ -198,7 +198,15 @@ static int enqueue_tail(Ctx *ctx, Slot &s, bool skip_hist_if_long, bool count_ge
     if ((rc = launch_classify_general(ctx, p, true, n_waves, st))) return rc;
   }
   if (count_genes && (rc = launch_gene_hist(s.d_gene_ids, s.d_counters, skip_hist_if_long, ctx->d_gene_counts, n, st))) return rc;
-  SHK_HIP(ctx, hipMemcpyAsync(s.h_counters, s.d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  // counters (and, for host batches, the associations) are stored into pinned host memory by a kernel: no copy-engine
+  // command ever sits in this stream waiting for kernels (see publish_results_kernel)
+  if (s.host_batch) {
+    if ((rc = ensure_pinned(ctx, &s.h_gene_off, &s.cap_h_gene_off, n + 1))) return rc;
+    if ((rc = ensure_pinned(ctx, &s.h_gene_ids, &s.cap_h_gene_ids, s.cap_gene_ids))) return rc;
+  }
+  if ((rc = launch_publish_results(s.d_counters, s.h_counters, s.d_gene_off, s.host_batch ? s.h_gene_off : nullptr, n + 1, s.d_gene_ids,
+                                   s.h_gene_ids, s.cap_h_gene_ids, st)))
+    return rc;
   SHK_HIP(ctx, hipEventRecord(s.ev_done, st));
   return SHK_OK;
 }
@@ -245,7 +253,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
 
   uint32_t n_long = 0;
   if (long_mode == LONG_UNKNOWN) {
-    SHK_HIP(ctx, hipMemcpyAsync(s.h_counters, s.d_counters, CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if ((rc = launch_publish_results(s.d_counters, s.h_counters, nullptr, nullptr, 0, nullptr, nullptr, 0, st))) return rc;
     SHK_HIP(ctx, hipStreamSynchronize(st));
     n_long = s.h_counters[CTR_LONG];
     s.gen_slots = std::max(s.fast_cap, s.h_counters[CTR_MAX_SLOTS]);
@@ -660,8 +668,8 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   d.seq1 = (const char *)s.d_seq1; d.off1 = s.d_off1;
   if (paired) { d.seq2 = (const char *)s.d_seq2; d.off2 = s.d_off2; }
   if (hasq) { d.qual1 = (const char *)s.d_qual1; if (paired) d.qual2 = (const char *)s.d_qual2; }
-  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true))) return rc;
   s.host_batch = true;
+  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true))) return rc;
   s.ticket = ctx->next_ticket++;
   s.waited = false;
   *ticket = s.ticket;
@@ -678,14 +686,10 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
   bool redone = false;
   int rc = finish_classify(ctx, s, false, true, &redone);
   if (rc) { s.waited = true; return rc; }
+  // (finish_classify re-ran the tail when it had to, and the tail publishes the results again)
   const uint64_t n = s.n;
   const uint64_t n_assoc = ((uint64_t)s.h_counters[CTR_ASSOC_HI] << 32) | s.h_counters[CTR_ASSOC_LO];
-  if ((rc = ensure_pinned(ctx, &s.h_gene_off, &s.cap_h_gene_off, n + 1))) return rc;
-  if ((rc = ensure_pinned(ctx, &s.h_gene_ids, &s.cap_h_gene_ids, n_assoc + 1))) return rc;
-  hipStream_t down = ctx->d2h_stream;
-  SHK_HIP(ctx, hipMemcpyAsync(s.h_gene_off, s.d_gene_off, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, down));
-  if (n_assoc) SHK_HIP(ctx, hipMemcpyAsync(s.h_gene_ids, s.d_gene_ids, n_assoc * sizeof(uint16_t), hipMemcpyDeviceToHost, down));
-  SHK_HIP(ctx, hipStreamSynchronize(down));
+  if (s.h_counters[CTR_OVERFLOW] || n_assoc > s.cap_h_gene_ids) { ctx->last_error = "result publication failed"; s.waited = true; return SHK_ERR_HIP; }
   s.waited = true;
   ctx->last.last_n_reads = n;
   ctx->last.last_n_long = s.h_counters[CTR_LONG];

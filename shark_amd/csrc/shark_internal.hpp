@@ -118,6 +118,10 @@ struct ClassifyParams {
   const uint64_t *off2;
   const uint8_t *qual1;
   const uint8_t *qual2;
+  // batches whose reads all have one length per mate (the usual sequencer output) take classify_uni_kernel:
+  // uni_flag == nullptr: the host knows (uni_L1, uni_L2); else {1 = uniform and fits, L1, L2} written by uniform_check_kernel
+  uint32_t uni_L1, uni_L2;
+  const uint32_t *uni_flag;
   // per-read results and queues (device copy of ClassifyOut)
   const ClassifyOut *out;
   unsigned long long *gene_counts;  // 65536 (general kernel, EMIT mode)
@@ -199,6 +203,11 @@ int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint3
 int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t gene_ids_cap, hipStream_t stream);
 int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, hipStream_t stream);
 int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
+int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
+                           const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, hipStream_t stream);
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream);
+int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);
+bool uni_kernel_available(const Ctx *ctx);
 uint32_t fast_kernel_max_slots();
 uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
 
