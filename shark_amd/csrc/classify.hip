@@ -743,6 +743,7 @@ __global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::M
   __shared__ uint64_t lds[G::SUM_WORDS64 + G::WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (pm_lds(MODE) && P.uni_flag && P.uni_flag[0] == 1u) return;   // a uniform batch: classify_uni_kernel has it
   const uint32_t *lsum = nullptr;
   if (pm_lds(MODE)) {
     // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
@@ -794,6 +795,394 @@ __global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::M
     retire_meta(r_nn);
     read = nxt; m_cur = m_nxt; w_cur = w_nxt; q_cur = q_nxt;
     nxt = nn; m_nxt = meta_finish(r_nn);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// classify_uni_kernel: batches whose reads all have ONE length per mate (what a sequencer delivers) on an index
+// in LDS-summary + position-table mode.  Same algorithm and data layout as classify_fast_kernel<.., PM_LDS_TAB>, but
+// everything that depends only on the read lengths is computed once per wave instead of once per read: which mate and
+// which 8 bases a lane stages, tail masks, LDS addresses; a read's bytes are at read * L, so no offsets are loaded at
+// all; the 8 bases are fetched as three unconditional aligned dwords (only the last reads of the batch, where the
+// third dword could leave the buffer, take the guarded loads).  The code for a pair without any hit -- stage, U
+// canonical k-mers, U hashes, U summary probes, table probes of the few that pass -- is one straight line; everything
+// a hit needs (decode, lazy validity, vote, emit) sits behind the wave-uniform "something matched" branch and re-reads
+// its parameters there, so it holds no registers while off-target reads stream through.  count[] is zeroed by the host
+// before the launch; only reads with associations write it.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ Raw8 load8_issue_all(const uint8_t *p, uint32_t nbytes)
+{
+  const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
+  Raw8 r;
+  r.d0 = q[0];
+  r.d1 = q[1];
+  r.d2 = q[2];
+  r.shn = sh | (nbytes << 4);
+  return r;
+}
+
+// kernel arguments re-read where they are needed: scalar loads from the kernarg segment (the ClassifyParams is the
+// kernel's only argument, at offset 0); the empty asm keeps LICM from turning them into loop-long SGPRs.  (Taking the
+// address of the by-value parameter instead would make the compiler copy all of it to scratch memory.)
+typedef const ClassifyParams __attribute__((address_space(4))) * KernargParams;
+__device__ __forceinline__ KernargParams kernarg_params()
+{
+  KernargParams p = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+template <int U, bool HASQ, bool POW2>
+__global__ __launch_bounds__(512, (U <= 5 ? 8 : 6)) void classify_uni_kernel(const ClassifyParams P)
+{
+  constexpr int WAVES = 8;
+  constexpr uint32_t S = 64 * U;
+  constexpr uint32_t WORDS = stage_words_for(S);
+  __shared__ uint64_t lds[LDS_SUM_BITS / 64 + WAVES * WORDS];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
+  if (P.uni_flag) {
+    if (P.uni_flag[0] != 1u) return;   // not a uniform batch (or it does not fit): classify_fast_kernel handles it
+    L1 = P.uni_flag[1];
+    L2 = P.uni_flag[2];
+  }
+  L1 = __builtin_amdgcn_readfirstlane(L1);
+  L2 = __builtin_amdgcn_readfirstlane(L2);
+  {
+    // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = threadIdx.x; i < LDS_SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
+  uint64_t *wbase = lds + LDS_SUM_BITS / 64 + wave * WORDS;
+  uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
+  uint32_t *const rv = fw + code_dwords_for(S);
+  uint64_t *const vbits = wbase + code_dwords_for(S);
+  constexpr uint32_t rcap = stage_cap_bases(S);
+
+  // ---- geometry of every read of the batch ------------------------------------
+  const uint32_t k = P.k;
+  const uint32_t nk1 = L1 >= k ? L1 - k + 1 : 0;
+  const uint32_t nk2 = L2 >= k ? L2 - k + 1 : 0;
+  const uint32_t P2 = (L1 + 7u) & ~7u;
+  const uint32_t g2 = P2 >> 3;
+  const uint32_t n_groups = g2 + ((L2 + 7u) >> 3);     // <= 64 (checked before this kernel is chosen)
+  // lane -> the 8 bases it stages
+  const bool act = (uint32_t)lane < n_groups;
+  const bool m2 = (uint32_t)lane >= g2;
+  const uint32_t b = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
+  const uint32_t Lm = m2 ? L2 : L1;
+  const uint32_t rem = act ? Lm - b : 8u;
+  const uint32_t nbytes = rem < 8u ? rem : 8u;
+  const uint32_t tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
+  const uint8_t *const sbase = (m2 ? P.seq2 : P.seq1) + b;
+  const uint8_t *const qbase = HASQ ? (m2 ? P.qual2 : P.qual1) + b : nullptr;
+  // the unguarded loads read up to 11 bytes behind a group's first byte: fine while that stays inside the mate's buffer
+  const uint32_t n32 = (uint32_t)P.n, stride = gridDim.x * WAVES;
+  const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
+  const uint32_t guard_reads = Lmin >= 12u ? 1u : (Lmin ? (12u + Lmin - 1u) / Lmin : n32);   // trailing reads with guarded loads
+
+  auto issue = [&](const uint32_t r, Raw8 &w, Raw8 &q) {
+    w = Raw8{0u, 0u, 0u, 0u};
+    q = Raw8{0u, 0u, 0u, 0u};
+    if (act) {
+      const uint64_t o = (uint64_t)r * Lm;
+      if (n32 - r > guard_reads) {
+        w = load8_issue_all(sbase + o, nbytes);
+        if (HASQ) q = load8_issue_all(qbase + o, nbytes);
+      } else {
+        w = load8_issue(sbase + o, rem);
+        if (HASQ) q = load8_issue(qbase + o, rem);
+      }
+    }
+  };
+
+  uint32_t read = blockIdx.x * WAVES + wave;
+  if (read >= n32) return;
+  Raw8 w_cur, q_cur;
+  issue(read, w_cur, q_cur);
+  retire_loads(w_cur);
+  retire_loads(q_cur);
+  const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
+  for (;;) {
+    const uint32_t nxt = n32 - read > stride ? read + stride : n32;   // saturates at n32
+    const bool have_nxt = nxt < n32;
+    Raw8 w_nxt = Raw8{0u, 0u, 0u, 0u}, q_nxt = Raw8{0u, 0u, 0u, 0u};
+    if (have_nxt) issue(nxt, w_nxt, q_nxt);
+
+    // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
+    if (act) {
+      const uint32_t sh = w_cur.shn & 3u;
+      const uint32_t lo = __builtin_amdgcn_alignbyte(w_cur.d1, w_cur.d0, sh);
+      const uint32_t hi = __builtin_amdgcn_alignbyte(w_cur.d2, w_cur.d1, sh);
+      uint32_t c_lo, c_hi, i_lo, i_hi;
+      classify4(lo, c_lo, i_lo);
+      classify4(hi, c_hi, i_hi);
+      const uint32_t msb16 = (pack4(c_lo) << 8) | pack4(c_hi);           // first base in bits 15:14
+      // (bytes behind the mate's end are whatever follows in the buffer: their codes land at packed positions that no
+      // existing slot's window covers, and tail_inv marks them invalid)
+      uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4) | tail_inv;
+      if (HASQ) {
+        const uint32_t qs = q_cur.shn & 3u;
+        const uint32_t qlo = __builtin_amdgcn_alignbyte(q_cur.d1, q_cur.d0, qs);
+        const uint32_t qhi = __builtin_amdgcn_alignbyte(q_cur.d2, q_cur.d1, qs);
+        inv8 |= gather4(qmask4(qlo, P.mq)) | (gather4(qmask4(qhi, P.mq)) << 4);
+      }
+      uint32_t lsb = __builtin_bitreverse32(msb16);                      // lands in the high half
+      lsb = ((lsb >> 1) & 0x55555555u) | ((lsb & 0x55555555u) << 1);
+      reinterpret_cast<uint16_t *>(fw)[lane] = (uint16_t)(lsb >> 16);
+      reinterpret_cast<uint16_t *>(rv)[(rcap >> 3) - 1u - (uint32_t)lane] = (uint16_t)msb16;
+      reinterpret_cast<uint8_t *>(vbits)[lane] = (uint8_t)(~inv8 & 0xFFu);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- U canonical k-mers, U hashes, U summary probes --------------------------
+    uint64_t pos[U];
+    {
+      const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
+      const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t *f = fw + ((uint32_t)lane >> 4) + 4 * j;
+        const uint32_t *r = rv + (qU >> 4) + 4 * (U - 1 - j);
+        const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+        const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+        const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
+        const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
+        const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+        const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
+        const uint64_t hsh = xxh64_u64(canon);
+        pos[j] = POW2 ? hsh : bf_pos_np(hsh, P);            // (power-of-two sizes: every use below masks the bits it needs)
+      }
+    }
+    uint32_t okm[U];   // all ones where the summary bit is set, else 0
+    bool something = false;
+    {
+      uint32_t si[U], sw[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low 18 bits = summary index
+        sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (LDS_SUM_BITS / 8 - 4)));
+      }
+      uint32_t any = 0;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        okm[j] = (uint32_t)__builtin_amdgcn_sbfe((int)sw[j], si[j], 1u);   // v_bfe_i32: bit (si & 31), sign extended
+        any |= okm[j];
+      }
+      something = __ballot(any != 0u) != 0ull;
+    }
+    if (something) {
+      // ---- position table: the probes that passed read their home bucket, the others the spare empty bucket ----
+      const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
+      const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
+      const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
+      const uint32_t spare = 1u << P.tab_lg;
+      auto want_of = [&](const int j) -> uint32_t {
+        const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
+        return (tag << 8) | 0x80u;
+      };
+      uint4 bk[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t bb = (uint32_t)pos[j] & bmask;
+        bk[j] = tab16[(bb & okm[j]) | (spare & ~okm[j])];
+      }
+      bool lane_any = false, lane_more = false;
+      bool more[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t want = want_of(j);
+        const bool match = (bk[j].y == want) | (bk[j].w == want);
+        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);
+        lane_any |= match;
+        more[j] = !match & !empty;
+        lane_more |= more[j];
+      }
+      if (__ballot(lane_more)) {   // rare: a full home bucket -> walk the probe path (see process_read)
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          uint32_t d = 0;
+          while (more[j]) {
+            ++d;
+            const uint4 b2 = tab16[((uint32_t)pos[j] + d) & bmask];
+            const uint32_t want = want_of(j) | d;
+            const bool n0 = b2.y == want, n1 = b2.w == want;
+            if (n0 | n1) {
+              bk[j].x = n0 ? b2.x : b2.z;
+              bk[j].y = want_of(j);
+              lane_any = true;
+              more[j] = false;
+            } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
+              more[j] = false;
+            }
+          }
+        }
+      }
+      if (__ballot(lane_any)) {
+        // ================= something matched in the table: the hit path =================
+        KernargParams H = kernarg_params();
+        const uint32_t hk = H->k;
+        const uint64_t kmask = (1ull << hk) - 1ull;
+        uint32_t cur[U], rs[U], re[U];
+        bool hit[U], multi[U];
+        uint32_t payload[U];
+        bool any2 = false;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const uint32_t want = want_of(j);
+          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+          // the probe was issued without looking at the slot: it has to exist and be a valid k-mer (process_read, slot_ok)
+          const uint32_t pp = (uint32_t)lane + 64u * j;
+          const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+          const uint32_t V = pp >> 6, vs = pp & 63u;
+          const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
+          const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+          hit[j] = (m0 | m1) & exists & ((win & kmask) == kmask);
+          any2 |= hit[j];
+          const uint32_t lo = m0 ? bk[j].x : bk[j].z;
+          payload[j] = lo & 0x7FFFFFFFu;
+          multi[j] = (lo >> 31) != 0u;
+        }
+        if (__ballot(any2)) {
+          bool lane_multi = false;
+#pragma unroll
+          for (int j = 0; j < U; ++j) lane_multi |= hit[j] & multi[j];
+          if (__ballot(lane_multi)) {   // multi-gene lists (rare): entry r gives start/len/first gene
+            ListEntry le[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) le[j] = H->ent[(hit[j] & multi[j]) ? payload[j] : 0u];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              if (hit[j] & multi[j]) {
+                rs[j] = le[j].start;
+                re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : H->ent[payload[j] + 1].start;
+                cur[j] = le[j].gene0;
+              } else {
+                rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
+          }
+          // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49)
+          const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
+          uint32_t best_cov = 0, best_nk = 0, n_best = 0;
+          uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
+          // ---- k-way merge over the hit lists, ascending gene id (see process_read for the derivation) ----
+          const uint64_t kthr = 1ull << (64u - hk);
+          for (;;) {
+            uint32_t mymin = GENE_INF;
+#pragma unroll
+            for (int j = 0; j < U; ++j) mymin = cur[j] < mymin ? cur[j] : mymin;
+            const uint32_t g = wave_min_u32(mymin);
+            if (g == GENE_INF) break;
+            uint32_t nk = 0, cov = 0;
+            auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
+              const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
+              return (uint32_t)__builtin_popcountll(__ballot(t >= kthr));
+            };
+            uint64_t Hm[U];
+            bool more_ids = false;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              const bool h = cur[j] == g;
+              Hm[j] = __ballot(h);
+              rs[j] += h ? 1u : 0u;
+              more_ids |= h & (rs[j] < re[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              nk += (uint32_t)__builtin_popcountll(Hm[j]);
+              cov += cover(Hm[j], j ? Hm[j - 1] : 0ull);
+            }
+            cov += cover(0ull, Hm[U - 1]);
+            if (__ballot(more_ids)) {
+#pragma unroll
+              for (int j = 0; j < U; ++j)
+                if ((Hm[j] >> lane) & 1ull) cur[j] = rs[j] < re[j] ? (uint32_t)H->ids[rs[j]] : GENE_INF;
+            } else {
+#pragma unroll
+              for (int j = 0; j < U; ++j) cur[j] = ((Hm[j] >> lane) & 1ull) ? GENE_INF : cur[j];
+            }
+            // arg-max with ties in ascending gene order, as selects (see the compiler note in process_read)
+            const bool gt = (cov > best_cov) | ((cov == best_cov) & (nk > best_nk));
+            const bool eq = (cov == best_cov) & (nk == best_nk);
+            best_id[0] = gt ? g : best_id[0];
+#pragma unroll
+            for (int i = 1; i < SHK_INLINE_IDS; ++i) best_id[i] = (eq & (n_best == (uint32_t)i)) ? g : best_id[i];
+            n_best = gt ? 1u : (eq ? n_best + 1u : n_best);
+            best_cov = gt ? cov : best_cov;
+            best_nk = gt ? nk : best_nk;
+          }
+          // ---- threshold + --single (ReadAnalyzer.hpp:104) ----
+          uint32_t n_out = 0;
+          if (n_best > 0 && (double)best_cov >= H->c * (double)len && (!H->single || n_best == 1)) n_out = n_best;
+          if (n_out > 0 && lane == 0) {
+            const ClassifyOut *O = H->out;
+            O->count[read] = n_out;
+            uint2 pk;
+            pk.x = (best_id[0] & 0xFFFFu) | (best_id[1] << 16);
+            pk.y = (best_id[2] & 0xFFFFu) | (best_id[3] << 16);
+            *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+            if (n_out > SHK_INLINE_IDS) {
+              const uint32_t qi = atomicAdd(&O->counters[CTR_TIE], 1u);
+              O->tie_queue[3 * qi + 0] = read;
+              O->tie_queue[3 * qi + 1] = best_cov;
+              O->tie_queue[3 * qi + 2] = best_nk;
+            }
+          }
+        }
+      }
+    }
+    if (!have_nxt) break;
+    retire_loads(w_nxt);
+    retire_loads(q_nxt);
+    read = nxt; w_cur = w_nxt; q_cur = q_nxt;
+  }
+}
+
+// Does every read of the batch have the same length per mate, and does such a read fit `slot_cap` slots and 64 staging
+// groups?  flag = {1 | 0, L1, L2}.  One pass over the offsets (16 B per pair), a few tens of microseconds for 10 M pairs.
+__global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams P, uint32_t slot_cap, uint32_t *__restrict__ flag)
+{
+  // flag[3] (scratch) counts violations; the last workgroup to finish writes the verdict
+  __shared__ uint32_t bad_s;
+  if (threadIdx.x == 0) bad_s = 0;
+  __syncthreads();
+  const uint64_t n = P.n;
+  const uint64_t L1 = n ? P.off1[1] - P.off1[0] : 0, L2 = (n && P.seq2) ? P.off2[1] - P.off2[0] : 0;
+  uint32_t bad = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n) bad |= (P.off1[0] != 0) | (P.seq2 && P.off2[0] != 0);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    bad |= (P.off1[i + 1] - P.off1[i]) != L1;
+    if (P.seq2) bad |= (P.off2[i + 1] - P.off2[i]) != L2;
+  }
+  if (bad) atomicOr(&bad_s, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (bad_s) atomicOr(&flag[3], 1u);
+    __threadfence();
+    const uint32_t done = atomicAdd(&flag[4], 1u) + 1u;
+    if (done == gridDim.x) {
+      const uint32_t any_bad = atomicOr(&flag[3], 0u);
+      const uint32_t k = P.k;
+      const uint64_t nk1 = L1 >= k ? L1 - k + 1 : 0, nk2 = L2 >= k ? L2 - k + 1 : 0;
+      const uint64_t ns = nk2 ? ((L1 + 7) & ~7ull) + nk2 : nk1;
+      const uint64_t groups = ((L1 + 7) >> 3) + ((L2 + 7) >> 3);
+      const bool ok = n && !any_bad && ns <= slot_cap && groups <= 64 && L1 < (1ull << 31) && L2 < (1ull << 31);
+      flag[1] = (uint32_t)L1;
+      flag[2] = (uint32_t)L2;
+      __threadfence();
+      flag[0] = ok ? 1u : 0u;
+    }
   }
 }
 
@@ -1017,6 +1406,45 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   else launch_fast_u<8>(p, mode, hasq, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
+}
+
+bool uni_kernel_available(const Ctx *ctx) { return pm_lds(probe_mode(ctx->idx)); }
+
+template <int U>
+static void launch_uni_u(const ClassifyParams &p, bool pow2, bool hasq, unsigned grid, hipStream_t s)
+{
+#define LU(HQ_, P2_) hipLaunchKernelGGL((classify_uni_kernel<U, HQ_, P2_>), dim3(grid), dim3(512), 0, s, p)
+  if (pow2) { if (hasq) LU(true, true); else LU(false, true); }
+  else { if (hasq) LU(true, false); else LU(false, false); }
+#undef LU
+}
+
+// the uniform-length kernel (index in LDS-summary mode only); with p.uni_flag set it decides on the device whether it runs
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
+{
+  if (p.n == 0) return SHK_OK;
+  const bool hasq = p.hasq != 0;
+  const uint32_t u = fast_kernel_unroll(max_slots);
+  const uint64_t cap = u <= 5 ? 1024 : 768;   // exactly the resident workgroups
+  const uint64_t want = (p.n + 7) / 8;
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  const bool pow2 = ctx->idx.pow2;
+  if (u == 2) launch_uni_u<2>(p, pow2, hasq, grid, stream);
+  else if (u == 3) launch_uni_u<3>(p, pow2, hasq, grid, stream);
+  else if (u == 4) launch_uni_u<4>(p, pow2, hasq, grid, stream);
+  else if (u == 5) launch_uni_u<5>(p, pow2, hasq, grid, stream);
+  else if (u == 6) launch_uni_u<6>(p, pow2, hasq, grid, stream);
+  else launch_uni_u<8>(p, pow2, hasq, grid, stream);
+  SHK_HIP(ctx, hipGetLastError());
+  return SHK_OK;
+}
+
+int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream)
+{
+  if (hipMemsetAsync(flag, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return SHK_ERR_HIP;
+  const uint64_t want = (p.n + 255) / 256;
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 2048 ? want : 2048))), dim3(256), 0, stream, p, slot_cap, flag);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 
 int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream)

@@ -63,6 +63,7 @@ static int slot_init(Ctx *ctx, Slot &s)
 {
   SHK_HIP(ctx, hipMalloc((void **)&s.d_counters, CTR_WORDS * sizeof(uint32_t)));
   SHK_HIP(ctx, hipMalloc((void **)&s.d_out, sizeof(ClassifyOut)));
+  SHK_HIP(ctx, hipMalloc((void **)&s.d_uni_flag, 8 * sizeof(uint32_t)));
   SHK_HIP(ctx, hipHostMalloc((void **)&s.h_counters, CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
   SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -74,7 +75,7 @@ static void slot_free(Slot &s)
 {
   hipFree(s.d_seq1); hipFree(s.d_seq2); hipFree(s.d_qual1); hipFree(s.d_qual2); hipFree(s.d_off1); hipFree(s.d_off2);
   hipFree(s.d_count); hipFree(s.d_inl); hipFree(s.d_gene_off); hipFree(s.d_gene_ids);
-  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out);
+  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_uni_flag);
   if (s.h_counters) (void)hipHostFree(s.h_counters);
   if (s.h_gene_off) (void)hipHostFree(s.h_gene_off);
   if (s.h_gene_ids) (void)hipHostFree(s.h_gene_ids);
@@ -219,8 +220,14 @@ enum LongMode {
 
 // all kernels of one batch whose inputs are (or will be, in stream order) resident in HBM; batch pointers are device
 // pointers.  Returns with the work enqueued on ctx->stream; finish_classify() completes the rare slow paths.
+enum UniMode {
+  UNI_ASK_DEVICE = 0,  // lengths unknown on the host: uniform_check_kernel decides, both kernels are launched, one returns at once
+  UNI_YES = 1,         // the host has seen the offsets: one length per mate (uni_L1, uni_L2), and such a read fits
+  UNI_NO = 2
+};
+
 static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_slots, int long_mode, uint32_t n_long_host,
-                            uint32_t long_slots_host, bool count_genes)
+                            uint32_t long_slots_host, bool count_genes, int uni_mode = UNI_ASK_DEVICE, uint32_t uni_L1 = 0, uint32_t uni_L2 = 0)
 {
   hipStream_t st = ctx->stream;
   const uint64_t n = b->n;
@@ -229,10 +236,23 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   s.n = n;
   fill_params(ctx, s, b);
   SHK_HIP(ctx, hipMemsetAsync(s.d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
-  SHK_HIP(ctx, hipMemsetAsync(s.d_count + n, 0, sizeof(uint32_t), st));
   if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
   s.fast_cap = 64 * fast_kernel_unroll(max_slots);
   s.gen_slots = s.fast_cap;
+  if (!uni_kernel_available(ctx) || n == 0) uni_mode = UNI_NO;
+  if (uni_mode == UNI_NO) {
+    SHK_HIP(ctx, hipMemsetAsync(s.d_count + n, 0, sizeof(uint32_t), st));
+  } else {
+    // classify_uni_kernel writes count[] only for reads with associations
+    SHK_HIP(ctx, hipMemsetAsync(s.d_count, 0, (n + 1) * sizeof(uint32_t), st));
+    if (uni_mode == UNI_ASK_DEVICE) {
+      if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
+      s.p.uni_flag = s.d_uni_flag;
+    } else {
+      s.p.uni_L1 = uni_L1;
+      s.p.uni_L2 = uni_L2;
+    }
+  }
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
@@ -248,7 +268,11 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     ctx->ev_used++;
     SHK_HIP(ctx, hipEventRecord(e0, st));
   }
-  if ((rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
+  // the timed launch is the one that does the work: the uniform kernel when the host knows it applies (or has to ask
+  // the device: then the generic kernel is launched behind it and returns at once for a uniform batch)
+  if (uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, st))) return rc;
+  if (uni_mode == UNI_NO && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
+  if (uni_mode == UNI_ASK_DEVICE && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
   if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
 
   uint32_t n_long = 0;
@@ -669,7 +693,8 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   if (paired) { d.seq2 = (const char *)s.d_seq2; d.off2 = s.d_off2; }
   if (hasq) { d.qual1 = (const char *)s.d_qual1; if (paired) d.qual2 = (const char *)s.d_qual2; }
   s.host_batch = true;
-  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true))) return rc;
+  const bool uni_fits = uniform && n_long == 0 && ((max1 + 7) >> 3) + ((max2 + 7) >> 3) <= 64;
+  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true, uni_fits ? UNI_YES : UNI_NO, (uint32_t)max1, (uint32_t)max2))) return rc;
   s.ticket = ctx->next_ticket++;
   s.waited = false;
   *ticket = s.ticket;

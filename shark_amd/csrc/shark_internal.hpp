@@ -172,6 +172,7 @@ struct Slot {
   uint32_t *d_long_queue = nullptr; size_t cap_long_queue = 0;
   uint32_t *d_tie_queue = nullptr;  size_t cap_tie_queue = 0;
   uint32_t *d_counters = nullptr;
+  uint32_t *d_uni_flag = nullptr;  // 8 words: verdict of uniform_check_kernel
   uint64_t *d_scan_temp = nullptr; size_t cap_scan_temp = 0;
   ClassifyOut *d_out = nullptr;
   ClassifyOut out_shadow{};        // what *d_out holds (rewritten only when a buffer moved)
