@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsharkhip.so")
+LIB_PATH = os.environ.get("SHK_LIB_PATH") or os.path.join(HERE, "libsharkhip.so")   # (SHK_LIB_PATH: kernel experiments, tools/)
 
 SHK_INLINE_IDS = 4
 

@@ -833,8 +833,11 @@ __device__ __forceinline__ KernargParams kernarg_params()
   return p;
 }
 
+#ifndef SHK_UNI_WAVES
+#define SHK_UNI_WAVES 8
+#endif
 template <int U, bool HASQ, bool POW2>
-__global__ __launch_bounds__(512, (U <= 5 ? 8 : 6)) void classify_uni_kernel(const ClassifyParams P)
+__global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_uni_kernel(const ClassifyParams P)
 {
   constexpr int WAVES = 8;
   constexpr uint32_t S = 64 * U;
@@ -1425,7 +1428,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, h
   if (p.n == 0) return SHK_OK;
   const bool hasq = p.hasq != 0;
   const uint32_t u = fast_kernel_unroll(max_slots);
-  const uint64_t cap = u <= 5 ? 1024 : 768;   // exactly the resident workgroups
+  const uint64_t cap = (u <= 5 && SHK_UNI_WAVES >= 8) ? 1024 : 768;   // exactly the resident workgroups
   const uint64_t want = (p.n + 7) / 8;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   const bool pow2 = ctx->idx.pow2;
