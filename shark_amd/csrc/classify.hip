@@ -834,7 +834,7 @@ __device__ __forceinline__ KernargParams kernarg_params()
 }
 
 #ifndef SHK_UNI_WAVES
-#define SHK_UNI_WAVES 8
+#define SHK_UNI_WAVES 6   // 75 VGPRs, nothing spilled; at 8 waves per SIMD (64 VGPRs) the loop reloads spilled lane constants from scratch and measures 1-6 % slower
 #endif
 template <int U, bool HASQ, bool POW2>
 __global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_uni_kernel(const ClassifyParams P)

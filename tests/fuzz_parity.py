@@ -11,6 +11,7 @@ import torch  # noqa: F401  (one HIP runtime for both)
 from tests import synth
 from oracle import pyoracle
 from shark_amd import SharkHip
+from shark_amd.capi import hip_memcpy_dtoh
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20261003
@@ -52,6 +53,18 @@ for it in range(iters):
     og, oi = o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"], nthreads=4)
     hg, hi = h.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"])
     ok = ok and np.array_equal(og, hg) and np.array_equal(oi, hi)
+    # the same batch resident in HBM (uniformity is then decided on the device), with a true, an unknown or a wrong length bound
+    dev = torch.device("cuda:0")
+    t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in b.items()}
+    pt = {kk: (v.data_ptr() if v is not None and v.numel() else (v.data_ptr() if v is not None else 0)) for kk, v in t.items()}
+    bound = int(rng.choice([0, read_len, max(1, read_len // 3)]))
+    if n_reads:
+        r = h.classify_device(n_reads, pt["seq1"], pt["off1"], pt["seq2"], pt["off2"], pt["qual1"], pt["qual2"], max_read_len=bound)
+        dg = np.empty(n_reads + 1, np.uint32); hip_memcpy_dtoh(dg, r.gene_off, dg.nbytes)
+        di = np.empty(int(r.n_assoc), np.uint16)
+        if len(di):
+            hip_memcpy_dtoh(di, r.gene_ids, di.nbytes)
+        ok = ok and np.array_equal(og, dg) and np.array_equal(oi, di)
     mode = h.probe_mode()
     modes[mode] = modes.get(mode, 0) + 1
     print("%4d seed=%d k=%d bf=%d genes=%d len=%d%s q=%d s=%d c=%.1f reads=%d mode=%s set=%d assoc=%d %s" % (
