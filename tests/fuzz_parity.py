@@ -15,6 +15,7 @@ from shark_amd.capi import hip_memcpy_dtoh
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20261003
+UNI = os.environ.get("FUZZ_UNI") == "1"   # bias the cases towards the uniform-length kernel
 t_start = time.time()
 modes = {}
 for it in range(iters):
@@ -30,7 +31,6 @@ for it in range(iters):
         bf_bits = int(rng.choice([3, 5, 6, 7])) << 32      # direct-remainder positions (1.5 - 3.5 GiB filters)
     n_genes = int(rng.choice([1, 2, 7, 40, 300]))
     gl = int(rng.choice([60, 400, 2500]))
-    genes = synth.make_genes(rng, n_genes, max(20, gl // 3), gl, share_every=int(rng.choice([0, 2, 5])))
     q = int(rng.choice([0, 0, 2, 20, 35]))
     single = bool(rng.random() < 0.3)
     c = float(rng.choice([0.0, 0.3, 0.6, 0.9, 1.0]))
@@ -40,6 +40,15 @@ for it in range(iters):
         os.environ["SHK_PROBE"] = "bitvector"
     else:
         os.environ.pop("SHK_PROBE", None)
+    var_len = bool(rng.random() < 0.6)
+    if UNI:
+        # bias towards what classify_uni_kernel takes: a sparse filter (LDS summary + table) and one length per mate
+        os.environ.pop("SHK_PROBE", None)
+        bf_bits = (1 << int(rng.integers(24, 34))) if rng.random() < 0.7 else int(rng.choice([3, 5, 6, 7])) << 32
+        n_genes = int(rng.choice([1, 2, 7]))
+        read_len = int(rng.choice([1, 8, 16, 17, 31, 33, 50, 76, 100, 125, 150, 151, 200, 250, 256, 259, 300]))
+        var_len = bool(rng.random() < 0.15)
+    genes = synth.make_genes(rng, n_genes, max(20, gl // 3), gl, share_every=int(rng.choice([0, 2, 5])))
     kw = dict(k=k, c=c, bf_bits=bf_bits, min_quality=q, single=single)
     o = pyoracle.Shark(**kw)
     nidx = o.build([bytes(g) for g in genes])
@@ -49,7 +58,7 @@ for it in range(iters):
     n_reads = int(rng.choice([1, 63, 64, 65, 1000, 4000]))
     b = synth.make_reads(rng, genes, n_reads, read_len=read_len, paired=paired, on_target=float(rng.choice([0.0, 0.5, 1.0])),
                          n_rate=float(rng.choice([0.0, 0.002, 0.05])), lower_rate=float(rng.choice([0.0, 0.1])),
-                         var_len=bool(rng.random() < 0.6), qual=q > 0)
+                         var_len=var_len, qual=q > 0)
     og, oi = o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"], nthreads=4)
     hg, hi = h.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"])
     ok = ok and np.array_equal(og, hg) and np.array_equal(oi, hi)
