@@ -261,7 +261,8 @@ def main():
             prof_note = "profiles/pmc_counters.json unreadable: %r" % (ex,)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "kernel": "classify_fast_kernel", "kernel_ms": round(kern_ms, 4), "launches": int(tm["n_launches"]),
+                "kernel": "classify_uni_kernel" if h.probe_mode().startswith("lds-summary") else "classify_fast_kernel",
+                "kernel_ms": round(kern_ms, 4), "launches": int(tm["n_launches"]),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / (2 * n), 1),
                 "kmers": int(w["n_kmers"]), "hits": int(w["n_hits"]),

@@ -1,0 +1,50 @@
+// shark-fastq-parts -- prints the record-aligned byte ranges the `shark` CLI's parallel readers use (fastq_partition.hpp).
+// Host-only (no GPU): lets the CPU tests check the partition against an independent parse, and shows a user how a
+// sample would be split.   usage: shark-fastq-parts BATCH THREADS file_1.fq [file_2.fq]
+// Output: one JSON object: n_records (pairs in the strict part), batches = [[begin1, end1, begin2, end2, records, regular], ...]
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "fastq_partition.hpp"
+
+int main(int argc, char **argv)
+{
+  if (argc < 4) {
+    fprintf(stderr, "usage: %s BATCH THREADS file_1.fq [file_2.fq]\n", argv[0]);
+    return 2;
+  }
+  const uint64_t batch = strtoull(argv[1], nullptr, 10);
+  const unsigned threads = (unsigned)atoi(argv[2]);
+  const bool paired = argc > 4;
+  if (batch == 0 || threads == 0) return 2;
+  shk::BatchTable t1, t2;
+  std::vector<uint64_t> c1, c2;
+  shk::count_file(argv[3], threads, t1, c1);
+  if (paired) shk::count_file(argv[4], threads, t2, c2);
+  if (!t1.ok || (paired && !t2.ok)) {
+    printf("{\"ok\": false}\n");
+    return 0;
+  }
+  const uint64_t n = paired ? std::min(t1.n_records, t2.n_records) : t1.n_records;
+  shk::locate_batches(t1, c1, batch, n, threads);
+  if (paired) shk::locate_batches(t2, c2, batch, n, threads);
+  if (!t1.ok || (paired && !t2.ok)) {
+    printf("{\"ok\": false}\n");
+    return 0;
+  }
+  const uint64_t nb = (n + batch - 1) / batch;
+  printf("{\"ok\": true, \"n_records\": %llu, \"records_1\": %llu, \"records_2\": %llu, \"batches\": [", (unsigned long long)n,
+         (unsigned long long)t1.n_records, (unsigned long long)(paired ? t2.n_records : 0));
+  shk::ParsedBatch p1, p2;
+  for (uint64_t i = 0; i < nb; ++i) {
+    const size_t want = (size_t)std::min<uint64_t>(batch, n - i * batch);
+    const size_t ok1 = shk::parse_strict_batch(t1.fd, t1.off[i], t1.off[i + 1], want, p1);
+    const size_t ok2 = paired ? shk::parse_strict_batch(t2.fd, t2.off[i], t2.off[i + 1], want, p2) : want;
+    printf("%s[%llu, %llu, %llu, %llu, %zu, %s]", i ? ", " : "", (unsigned long long)t1.off[i], (unsigned long long)t1.off[i + 1],
+           (unsigned long long)(paired ? t2.off[i] : 0), (unsigned long long)(paired ? t2.off[i + 1] : 0), want,
+           (ok1 == want && ok2 == want) ? "true" : "false");
+  }
+  printf("]}\n");
+  return 0;
+}

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <iostream>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -33,6 +34,7 @@
 
 #include "../../include/shark_hip.h"
 #include "fastq_block_reader.hpp"
+#include "fastq_partition.hpp"
 #include "fastx_reader.hpp"
 
 namespace {
@@ -60,7 +62,7 @@ const char *USAGE_MESSAGE =
     "\n"
     "MI355X build only:\n"
     "          --gpus N                      number of GPUs to shard the reads over (default:1)\n"
-    "          --batch N                     reads per device batch (default:1048576)\n"
+    "          --batch N                     reads per device batch (default:262144)\n"
     "          --gene-counts FILE            write <gene> <assigned reads> per gene (summed over the GPUs with RCCL)\n"
     "      -t N also sets the number of host threads that parse FASTQ / format output (default: up to 16)\n";
 
@@ -74,7 +76,7 @@ struct Options {
   bool single = false, verbose = false;
   int nThreads = 1;
   int gpus = 1;
-  uint64_t batch = 1u << 20;
+  uint64_t batch = 1u << 18;
   std::string gene_counts_path;
 };
 
@@ -199,27 +201,63 @@ struct default_init_allocator : std::allocator<T> {
   template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
 };
 
-struct Strings {
-  std::vector<char, default_init_allocator<char>> bytes;
-  std::vector<uint64_t> off{0};
-  void push(const std::string &s) { bytes.insert(bytes.end(), s.begin(), s.end()); off.push_back(bytes.size()); }
+// the same, in page-locked host memory (shk_alloc_pinned): what the GPU reads -- sequences, qualities, offsets -- is
+// copied by the DMA engine straight from here, which is what lets shk_classify_submit return before the copy is done.
+// Batches are recycled, so these allocations happen once per pipeline slot.  Falls back to malloc when pinning fails.
+template <typename T>
+struct pinned_allocator {
+  using value_type = T;
+  pinned_allocator() = default;
+  template <typename U> pinned_allocator(const pinned_allocator<U> &) {}
+  template <typename U> struct rebind { using other = pinned_allocator<U>; };
+  T *allocate(size_t n)
+  {
+    // header word in front of the block: 1 = pinned, 0 = malloc
+    const size_t bytes = n * sizeof(T) + 64;
+    char *raw = static_cast<char *>(shk_alloc_pinned(bytes));
+    bool pinned = raw != nullptr;
+    if (!raw) raw = static_cast<char *>(malloc(bytes));
+    if (!raw) throw std::bad_alloc();
+    *reinterpret_cast<uint64_t *>(raw) = pinned ? 1 : 0;
+    return reinterpret_cast<T *>(raw + 64);
+  }
+  void deallocate(T *p, size_t)
+  {
+    char *raw = reinterpret_cast<char *>(p) - 64;
+    if (*reinterpret_cast<uint64_t *>(raw)) shk_free_pinned(raw); else free(raw);
+  }
+  template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+  template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+  template <typename U> bool operator==(const pinned_allocator<U> &) const { return true; }
+  template <typename U> bool operator!=(const pinned_allocator<U> &) const { return false; }
+};
+
+template <typename CharAlloc, typename OffAlloc>
+struct StringsT {
+  std::vector<char, CharAlloc> bytes;
+  std::vector<uint64_t, OffAlloc> off{0};
   void push(const char *p, size_t n) { bytes.insert(bytes.end(), p, p + n); off.push_back(bytes.size()); }
   size_t size() const { return off.size() - 1; }
   const char *at(size_t i) const { return bytes.data() + off[i]; }
   size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
+  void reset() { bytes.clear(); off.assign(1, 0); }
+  void truncate(size_t keep) { off.resize(keep + 1); bytes.resize(off[keep]); }
 };
+using Strings = StringsT<default_init_allocator<char>, std::allocator<uint64_t>>;           // read names (host only)
+using DevStrings = StringsT<pinned_allocator<char>, pinned_allocator<uint64_t>>;             // what the GPU reads
 
 struct ReadBatch {
   uint64_t index = 0;       // position in the input stream (ordering contract)
   uint64_t first_read = 0;  // global index of its first read
-  Strings id1, seq1, qual1, id2, seq2, qual2;
+  Strings id1, id2;
+  DevStrings seq1, qual1, seq2, qual2;
   // result
   std::vector<uint32_t> gene_off;
   std::vector<uint16_t> gene_ids;
   int rc = 0;
   void reset()
   {
-    for (Strings *x : {&id1, &seq1, &qual1, &id2, &seq2, &qual2}) { x->bytes.clear(); x->off.assign(1, 0); }
+    id1.reset(); id2.reset(); seq1.reset(); qual1.reset(); seq2.reset(); qual2.reset();
     gene_off.clear(); gene_ids.clear();
     rc = 0;
   }
@@ -241,7 +279,7 @@ class BatchPool {
   {
     b->reset();
     std::lock_guard<std::mutex> l(m_);
-    if (free_.size() < 8) free_.push_back(std::move(b));
+    if (free_.size() < 64) free_.push_back(std::move(b));
   }
 
  private:
@@ -263,6 +301,15 @@ class BatchSplitter {
   }
   bool ok() const { return r1_.ok() && (!paired_ || r2_->ok()); }
   bool fast_path() const { return fast_; }
+  // continue with the serial kseq-rule reader at a record boundary (behind the batches the parallel feed delivered)
+  void resume_serial(uint64_t off1, uint64_t off2, uint64_t next_index, uint64_t n_reads)
+  {
+    fast_ = false;
+    r1_.seek(off1);
+    if (paired_) r2_->seek(off2);
+    next_index_ = next_index;
+    n_reads_ = n_reads;
+  }
   std::string stage_report() const
   {
     std::ostringstream o;
@@ -309,14 +356,21 @@ class BatchSplitter {
       // the two mate files are parsed (and, for .gz, inflated) by two threads at once; the pair
       // stream ends with the shorter file, as in the reference's read loop (FastqSplitter.hpp:60)
       const size_t have = b->seq1.size(), want = (size_t)maxnum_ - have;
-      auto fill_serial = [want](shk::FastxReader &r, Strings &id, Strings &seq, Strings &qual) {
+      auto fill_serial = [want](shk::FastxReader &r, Strings &id, DevStrings &seq, DevStrings &qual) {
         shk::FastxRecord a;
         size_t got = 0;
         while (got < want && r.read(a) >= 0) {
           // the reference builds std::string from C strings (FastqSplitter.hpp:55,63): stop at NUL
           id.push(a.name.c_str(), strlen(a.name.c_str()));
-          seq.push(a.seq.data(), strnlen(a.seq.data(), a.seq.size()));
-          qual.push(a.qual.data(), strnlen(a.qual.data(), a.qual.size()));
+          const size_t sl = strnlen(a.seq.data(), a.seq.size());
+          seq.push(a.seq.data(), sl);
+          // The device reads qualities at the sequence offsets.  The reference masks position i only for i < qual.length()
+          // (FastqSplitter.hpp:104-109 with the C-string lengths of :55,:63): a record without a quality line, or one cut
+          // short by a NUL, is not masked behind the end of its quality string -- those positions get the top quality.
+          const size_t ql = std::min(sl, strnlen(a.qual.data(), a.qual.size()));
+          a.qual.resize(ql);
+          a.qual.resize(sl, '\x7f');
+          qual.push(a.qual.data(), sl);
           ++got;
         }
         return got;
@@ -328,10 +382,8 @@ class BatchSplitter {
         t2.join();
         const size_t keep = have + std::min(got1, got2);
         if (got1 != got2) {   // one file ended: drop the unpaired surplus, nothing more will be read
-          for (Strings *x : {&b->id1, &b->seq1, &b->qual1, &b->id2, &b->seq2, &b->qual2}) {
-            x->off.resize(keep + 1);
-            x->bytes.resize(x->off[keep]);
-          }
+          b->id1.truncate(keep); b->id2.truncate(keep);
+          b->seq1.truncate(keep); b->qual1.truncate(keep); b->seq2.truncate(keep); b->qual2.truncate(keep);
           done_ = true;
         }
       } else {
@@ -347,7 +399,7 @@ class BatchSplitter {
 
  private:
   // copy n strict records into the structure-of-arrays strings, in parallel
-  void fill(const shk::RecordBlock &k, size_t n, Strings &id, Strings &seq, Strings &qual)
+  void fill(const shk::RecordBlock &k, size_t n, Strings &id, DevStrings &seq, DevStrings &qual)
   {
     const auto &idl = k.id_len, &sql = k.seq_len;   // measured while the block was validated
     id.off.resize(n + 1);
@@ -382,35 +434,55 @@ class BatchSplitter {
   uint64_t next_index_ = 0, n_reads_ = 0;
 };
 
-// ReadAnalyzer role (ReadAnalyzer.hpp:39-110): reads -> associations, on one GPU
+// ReadAnalyzer role (ReadAnalyzer.hpp:39-110): reads -> associations, on one GPU.  Up to SHK_PIPE_DEPTH batches are in
+// flight: the copies of the next batches overlap the kernels of the current one (shk_classify_submit / _wait).
 class ReadAnalyzer {
  public:
   ReadAnalyzer(shk_ctx *ctx, bool need_qual) : ctx_(ctx), need_qual_(need_qual) {}
-  void operator()(ReadBatch &b) const
+  // false: the batch failed at once (b.rc is set) and is not in flight
+  bool submit(std::unique_ptr<ReadBatch> b)
   {
     shk_batch in{};
-    in.n = b.seq1.size();
-    in.seq1 = b.seq1.bytes.data();
-    in.off1 = b.seq1.off.data();
-    if (b.seq2.size() == in.n && b.id2.size() == in.n && in.n) {
-      in.seq2 = b.seq2.bytes.data();
-      in.off2 = b.seq2.off.data();
+    in.n = b->seq1.size();
+    in.seq1 = b->seq1.bytes.data();
+    in.off1 = b->seq1.off.data();
+    if (b->seq2.size() == in.n && b->id2.size() == in.n && in.n) {
+      in.seq2 = b->seq2.bytes.data();
+      in.off2 = b->seq2.off.data();
     }
     if (need_qual_) {
-      // quality strings share the sequence offsets (kseq.h:216 guarantees equal lengths)
-      in.qual1 = b.qual1.bytes.data();
-      if (in.seq2) in.qual2 = b.qual2.bytes.data();
+      // quality strings share the sequence offsets (kseq.h:216 guarantees equal lengths; the serial reader pads the rest)
+      in.qual1 = b->qual1.bytes.data();
+      if (in.seq2) in.qual2 = b->qual2.bytes.data();
     }
+    uint64_t ticket = 0;
+    b->rc = shk_classify_submit(ctx_, &in, &ticket);
+    const bool ok = b->rc == SHK_OK;
+    if (ok) flying_.emplace_back(ticket, std::move(b)); else failed_ = std::move(b);
+    return ok;
+  }
+  size_t in_flight() const { return flying_.size(); }
+  std::unique_ptr<ReadBatch> take_failed() { return std::move(failed_); }
+  // the oldest batch in flight, classified
+  std::unique_ptr<ReadBatch> wait()
+  {
+    std::unique_ptr<ReadBatch> b = std::move(flying_.front().second);
+    const uint64_t ticket = flying_.front().first;
+    flying_.pop_front();
     shk_result out{};
-    b.rc = shk_classify(ctx_, &in, &out);
-    if (b.rc != SHK_OK) return;
-    b.gene_off.assign(out.gene_off, out.gene_off + in.n + 1);
-    b.gene_ids.assign(out.gene_ids, out.gene_ids + out.n_assoc);
+    b->rc = shk_classify_wait(ctx_, ticket, &out);
+    if (b->rc == SHK_OK) {
+      b->gene_off.assign(out.gene_off, out.gene_off + out.n + 1);
+      b->gene_ids.assign(out.gene_ids, out.gene_ids + out.n_assoc);
+    }
+    return b;
   }
 
  private:
   shk_ctx *ctx_;
   bool need_qual_;
+  std::deque<std::pair<uint64_t, std::unique_ptr<ReadBatch>>> flying_;
+  std::unique_ptr<ReadBatch> failed_;
 };
 
 // ReadOutput role (ReadOutput.hpp:37-50).  The reference starts a new output
@@ -470,7 +542,7 @@ class ReadOutput {
   }
 
  private:
-  static void record(std::string &f, const Strings &id, const Strings &seq, const Strings &qual, size_t i)
+  static void record(std::string &f, const Strings &id, const DevStrings &seq, const DevStrings &qual, size_t i)
   {
     f.push_back('@');
     if (i < id.size()) f.append(id.at(i), id.len(i));
@@ -506,6 +578,16 @@ class BoundedQueue {
     q_.pop_front();
     cv_space_.notify_one();
     return true;
+  }
+  // 1 = got an item, 0 = nothing there right now, -1 = closed and drained
+  int try_pop(T &v)
+  {
+    std::lock_guard<std::mutex> l(m_);
+    if (q_.empty()) return closed_ ? -1 : 0;
+    v = std::move(q_.front());
+    q_.pop_front();
+    cv_space_.notify_one();
+    return 1;
   }
   void close()
   {
@@ -588,14 +670,18 @@ int main(int argc, char *argv[])
   pelapsed("Second switch performed");
 
   // ---- 3. sample ---------------------------------------------------------------
+  // Three roles, as in main.cpp:66-77 (split / analyze / output), decoupled by queues:
+  //   readers   plain four-line FASTQ: a parallel newline count gives the byte range of every batch of each mate file
+  //             (fastq_partition.hpp), and `readers` threads parse whole batches independently into pinned
+  //             structure-of-arrays batches -- the feed scales with host cores instead of one splitter mutex
+  //             (FastqSplitter.hpp:48).  gzip'd or irregular input: the serial kseq-rule reader, from the first batch
+  //             that is not strict on.
+  //   analyzers one thread per GPU, batch i -> GPU i mod N, SHK_PIPE_DEPTH batches in flight per GPU
+  //   output    this thread, batches in input order (ReadOutput.hpp:37-50)
   {
-    unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, hw);
     BatchPool pool;
-    BatchSplitter fs(opt, io_threads, pool);
-    if (!fs.ok()) {
-      std::cerr << "shark: cannot open the sample" << std::endl;
-      return EXIT_FAILURE;
-    }
     FILE *out1 = fopen(opt.out1_path.c_str(), "w");
     FILE *out2 = (opt.paired_flag && opt.out2_path != "") ? fopen(opt.out2_path.c_str(), "w") : nullptr;
     ReadOutput ro(out1, out2, legend_ID, io_threads);
@@ -603,41 +689,158 @@ int main(int argc, char *argv[])
     if (out2) setvbuf(out2, nullptr, _IOFBF, 1 << 22);
     setvbuf(stdout, nullptr, _IOFBF, 1 << 22);
 
-    BoundedQueue<std::unique_ptr<ReadBatch>> todo((size_t)n_gpus * 2);
+    // per-GPU input queues; batch i goes to GPU i mod N
+    std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<ReadBatch>>>> todo;
+    for (int g = 0; g < n_gpus; ++g) todo.emplace_back(new BoundedQueue<std::unique_ptr<ReadBatch>>(SHK_PIPE_DEPTH + 1));
     std::mutex done_m;
     std::condition_variable done_cv;
     std::map<uint64_t, std::unique_ptr<ReadBatch>> done;
-    uint64_t n_batches = 0;
+    uint64_t n_batches = 0;          // batches handed to the GPUs so far (guarded by done_m)
     bool split_finished = false;
-
-    std::vector<double> t_gpu((size_t)n_gpus, 0.0);
-    std::thread splitter([&] {
-      for (;;) {
-        auto b = fs();
-        if (!b) break;
-        {
-          std::lock_guard<std::mutex> l(done_m);
-          n_batches = b->index + 1;
-        }
-        todo.push(std::move(b));
+    auto dispatch = [&](std::unique_ptr<ReadBatch> b) {
+      {
+        std::lock_guard<std::mutex> l(done_m);
+        n_batches = std::max(n_batches, b->index + 1);
       }
-      todo.close();
+      todo[(size_t)(b->index % (uint64_t)n_gpus)]->push(std::move(b));
+    };
+
+    // ---- the parallel feed -------------------------------------------------------
+    shk::BatchTable tab1, tab2;
+    bool parallel_feed = !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");
+    uint64_t n_par_records = 0;       // records both mate files certainly have: the pair stream of the strict part
+    if (parallel_feed) {
+      std::vector<uint64_t> cnt1, cnt2;
+      shk::count_file(opt.sample1_path, io_threads, tab1, cnt1);
+      parallel_feed = tab1.ok;
+      if (parallel_feed && opt.paired_flag) {
+        shk::count_file(opt.sample2_path, io_threads, tab2, cnt2);
+        parallel_feed = tab2.ok;
+      }
+      if (parallel_feed) {
+        n_par_records = opt.paired_flag ? std::min(tab1.n_records, tab2.n_records) : tab1.n_records;
+        shk::locate_batches(tab1, cnt1, opt.batch, n_par_records, io_threads);
+        if (opt.paired_flag) shk::locate_batches(tab2, cnt2, opt.batch, n_par_records, io_threads);
+        parallel_feed = tab1.ok && (!opt.paired_flag || tab2.ok);
+        if (!parallel_feed) n_par_records = 0;
+      }
+    }
+    const uint64_t n_par_batches = (n_par_records + opt.batch - 1) / opt.batch;
+    std::atomic<uint64_t> next_batch{0};
+    std::atomic<uint64_t> irregular_at{UINT64_MAX};     // first batch a reader found not to be strict four-line FASTQ
+    const unsigned n_readers = parallel_feed ? (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(io_threads, n_par_batches)) : 0;
+    std::vector<double> t_reader(n_readers, 0.0);
+    // a reader must not run ahead of the drain without bound: at most `window` batches beyond the one being written
+    const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2);
+    uint64_t drained = 0;                                // guarded by done_m
+    std::vector<std::thread> readers;
+    for (unsigned r = 0; r < n_readers; ++r) {
+      readers.emplace_back([&, r] {
+        shk::ParsedBatch p1, p2;
+        for (;;) {
+          const uint64_t i = next_batch.fetch_add(1);
+          if (i >= n_par_batches || i >= irregular_at.load()) break;
+          {
+            std::unique_lock<std::mutex> l(done_m);
+            done_cv.wait(l, [&] { return i < drained + window || i >= irregular_at.load(); });
+          }
+          if (i >= irregular_at.load()) break;
+          auto t0 = std::chrono::steady_clock::now();
+          const size_t want = (size_t)std::min<uint64_t>(opt.batch, n_par_records - i * opt.batch);
+          size_t ok1 = shk::parse_strict_batch(tab1.fd, tab1.off[i], tab1.off[i + 1], want, p1);
+          size_t ok2 = want;
+          if (opt.paired_flag) ok2 = shk::parse_strict_batch(tab2.fd, tab2.off[i], tab2.off[i + 1], want, p2);
+          if (ok1 < want || ok2 < want) {
+            // not strict here: this batch and everything behind it belongs to the serial reader
+            uint64_t cur = irregular_at.load();
+            while (i < cur && !irregular_at.compare_exchange_weak(cur, i)) {}
+            done_cv.notify_all();
+            break;
+          }
+          std::unique_ptr<ReadBatch> b = pool.acquire();
+          b->index = i;
+          b->first_read = i * opt.batch;
+          auto fill1 = [want](const shk::ParsedBatch &pb, Strings &id, DevStrings &seq, DevStrings &qual) {
+            id.off.resize(want + 1); seq.off.resize(want + 1); qual.off.resize(want + 1);
+            uint64_t ai = 0, as = 0;
+            for (size_t k = 0; k < want; ++k) {
+              id.off[k] = ai; seq.off[k] = as; qual.off[k] = as;
+              ai += pb.id_len[k]; as += pb.seq_len[k];
+            }
+            id.off[want] = ai; seq.off[want] = as; qual.off[want] = as;
+            id.bytes.resize(ai); seq.bytes.resize(as); qual.bytes.resize(as);
+            const char *base = pb.buf.data();
+            for (size_t k = 0; k < want; ++k) {
+              memcpy(id.bytes.data() + id.off[k], base + pb.begin(4 * k) + 1, pb.id_len[k]);
+              memcpy(seq.bytes.data() + seq.off[k], base + pb.nl[4 * k] + 1, pb.seq_len[k]);
+              memcpy(qual.bytes.data() + qual.off[k], base + pb.nl[4 * k + 2] + 1, pb.seq_len[k]);
+            }
+          };
+          fill1(p1, b->id1, b->seq1, b->qual1);
+          if (opt.paired_flag) fill1(p2, b->id2, b->seq2, b->qual2);
+          t_reader[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          if (i >= irregular_at.load()) { pool.release(std::move(b)); break; }
+          dispatch(std::move(b));
+        }
+      });
+    }
+
+    // ---- the serial feed: everything the parallel readers did not (or could not) deliver ---------
+    std::unique_ptr<BatchSplitter> fs;
+    std::thread splitter([&] {
+      for (auto &t : readers) t.join();
+      const uint64_t stop = std::min<uint64_t>(irregular_at.load(), n_par_batches);   // batches [0, stop) came from the readers
+      fs.reset(new BatchSplitter(opt, io_threads, pool));
+      bool serial_ok = fs->ok();
+      if (serial_ok && parallel_feed) {
+        const uint64_t o1 = tab1.off[stop];
+        const uint64_t o2 = opt.paired_flag ? tab2.off[stop] : 0;
+        fs->resume_serial(o1, o2, stop, std::min<uint64_t>(stop * opt.batch, n_par_records));
+      }
+      if (serial_ok) {
+        for (;;) {
+          auto b = (*fs)();
+          if (!b) break;
+          dispatch(std::move(b));
+        }
+      }
+      for (auto &q : todo) q->close();
       std::lock_guard<std::mutex> l(done_m);
       split_finished = true;
+      if (!serial_ok) n_batches = UINT64_MAX;   // reported below
       done_cv.notify_all();
     });
+
+    std::vector<double> t_gpu((size_t)n_gpus, 0.0);
     std::vector<std::thread> analyzers;
     for (int g = 0; g < n_gpus; ++g) {
       analyzers.emplace_back([&, g] {
         ReadAnalyzer ra(ctxs[(size_t)g], static_cast<char>(opt.min_quality) != 0);
-        std::unique_ptr<ReadBatch> b;
-        while (todo.pop(b)) {
-          auto t0 = std::chrono::steady_clock::now();
-          ra(*b);
-          t_gpu[(size_t)g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        auto hand_over = [&](std::unique_ptr<ReadBatch> b) {
           std::lock_guard<std::mutex> l(done_m);
           done[b->index] = std::move(b);
           done_cv.notify_all();
+        };
+        bool open = true;
+        while (open || ra.in_flight()) {
+          // keep the pipeline full; block for input only when nothing is in flight
+          while (open && ra.in_flight() < SHK_PIPE_DEPTH) {
+            std::unique_ptr<ReadBatch> b;
+            int got;
+            if (ra.in_flight() == 0) got = todo[(size_t)g]->pop(b) ? 1 : -1;
+            else got = todo[(size_t)g]->try_pop(b);
+            if (got < 0) { open = false; break; }
+            if (got == 0) break;
+            auto t0 = std::chrono::steady_clock::now();
+            if (!ra.submit(std::move(b))) hand_over(ra.take_failed());
+            t_gpu[(size_t)g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          }
+          if (ra.in_flight()) {
+            auto t0 = std::chrono::steady_clock::now();
+            std::unique_ptr<ReadBatch> b = ra.wait();
+            t_gpu[(size_t)g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            hand_over(std::move(b));
+          }
         }
       });
     }
@@ -663,13 +866,25 @@ int main(int argc, char *argv[])
       }
       pool.release(std::move(b));
       ++next;
+      {
+        std::lock_guard<std::mutex> l(done_m);
+        drained = next;
+      }
+      done_cv.notify_all();
     }
     splitter.join();
     for (auto &t : analyzers) t.join();
     fflush(stdout);
+    if (!fs || !fs->ok()) {
+      std::cerr << "shark: cannot open the sample" << std::endl;
+      return EXIT_FAILURE;
+    }
     if (opt.verbose) {
-      std::cerr << "[shark/io] threads " << io_threads << (fs.t_serial > 0 ? " serial-reader " : " block-reader ") << "index " << fs.t_index
-                << " s (" << fs.stage_report() << "), fill " << fs.t_fill << " s, serial " << fs.t_serial << " s, classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
+      double tr = 0;
+      for (double x : t_reader) tr += x;
+      std::cerr << "[shark/io] threads " << io_threads << ", parallel readers " << n_readers << " (" << std::min<uint64_t>(irregular_at.load(), n_par_batches)
+                << " batches, " << tr << " thread-seconds), serial reader: index " << fs->t_index << " s (" << fs->stage_report() << "), fill "
+                << fs->t_fill << " s, serial " << fs->t_serial << " s; classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
     }
     if (out1) fclose(out1);
     if (out2) fclose(out2);

@@ -19,15 +19,19 @@ def _free_port():
     return p
 
 
-def _run(world, out):
+def _launch(world, args):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), out], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py")] + args, env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
+
+
+def _run(world, out):
+    _launch(world, ["batches", out])
     return json.load(open(out))
 
 
@@ -49,3 +53,33 @@ def test_batch_ownership_is_a_partition():
         for r in range(world):
             seen += sdist.shard_batches(1003, 100, r, world)
         assert sorted(seen) == [(i, min(1003, i + 100)) for i in range(0, 1003, 100)]
+
+
+@pytest.mark.timeout(600)
+def test_byte_range_partition_reproduces_the_single_process_ssv(oracle, tmp_path):
+    """the sharded run over FILES: the CLI's own record-aligned byte ranges (fastq_partition.hpp), batch i -> rank i mod N,
+    ordered merge on rank 0; world sizes 1, 2 and 3 must all give the oracle CLI's ssv byte for byte"""
+    import numpy as np
+    from tests import synth
+    rng = np.random.default_rng(77)
+    genes = synth.make_genes(rng, 12, 300, 1200, share_every=4)
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">gene%d some description\n%s\n" % (i, bytes(g).decode()) for i, g in enumerate(genes)))
+    b = synth.make_reads(rng, genes, 1700, read_len=100, paired=True, on_target=0.7, var_len=True)
+    f1, f2 = tmp_path / "s_1.fq", tmp_path / "s_2.fq"
+    for f, seq, off, tag in ((f1, b["seq1"], b["off1"], 1), (f2, b["seq2"], b["off2"], 2)):
+        with open(f, "wb") as fh:
+            for i in range(len(off) - 1):
+                s_ = bytes(seq[int(off[i]):int(off[i + 1])])
+                fh.write(b"@pair%d/%d len=%d\n%s\n+\n%s\n" % (i, tag, len(s_), s_, b"I" * len(s_)))
+    want = tmp_path / "want.ssv"
+    oracle.run_cli(["-r", str(fa), "-1", str(f1), "-2", str(f2), "-k", "15", "-c", "0.5", "-o", str(tmp_path / "o1"), "-p", str(tmp_path / "o2")],
+                   str(want))
+    assert want.stat().st_size > 10000
+    for world, batch in ((1, 400), (2, 256), (3, 100)):
+        out = tmp_path / ("w%d.ssv" % world)
+        _launch(world, ["files", str(out), str(fa), str(f1), str(f2), str(batch)])
+        assert out.read_bytes() == want.read_bytes(), world
+        meta = json.load(open(str(out) + ".json"))
+        assert meta["batches"] == (1700 + batch - 1) // batch
+        assert sum(meta["counts"]) == want.read_bytes().count(b"\n")

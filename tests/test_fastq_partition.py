@@ -1,0 +1,106 @@
+"""CPU tests of the record-aligned byte-range partition behind the `shark` CLI's parallel readers
+(shark_amd/csrc/fastq_partition.hpp, through the host-only tool shark_amd/bin/shark-fastq-parts)."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "shark_amd", "bin", "shark-fastq-parts")
+
+
+@pytest.fixture(scope="module")
+def tool():
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "shark_amd", "csrc"), "../bin/shark-fastq-parts"], check=True, stdout=subprocess.DEVNULL)
+    return TOOL
+
+
+def parts(tool, batch, threads, *files):
+    r = subprocess.run([tool, str(batch), str(threads)] + [str(f) for f in files], capture_output=True, text=True, check=True)
+    return json.loads(r.stdout)
+
+
+def write_fastq(path, n, rng, tag, min_len=30, max_len=160, id_extra=True):
+    recs = []
+    with open(path, "wb") as f:
+        for i in range(n):
+            L = int(rng.integers(min_len, max_len + 1))
+            seq = bytes(rng.choice(list(b"ACGTN"), size=L).astype(np.uint8))
+            qual = bytes(rng.integers(33, 74, size=L).astype(np.uint8))
+            rid = b"read%d/%d" % (i, tag)
+            hdr = rid + (b" extra words" if id_extra and i % 3 == 0 else b"")
+            f.write(b"@" + hdr + b"\n" + seq + b"\n+\n" + qual + b"\n")
+            recs.append((rid, seq, qual))
+    return recs
+
+
+def parse_range(path, b, e):
+    """independent parse of a strict four-line byte range"""
+    data = open(path, "rb").read()[b:e]
+    lines = data.split(b"\n")
+    assert lines[-1] == b""
+    lines = lines[:-1]
+    assert len(lines) % 4 == 0
+    return [(lines[i][1:].split()[0], lines[i + 1], lines[i + 3]) for i in range(0, len(lines), 4)]
+
+
+@pytest.mark.parametrize("batch,threads", [(1, 1), (7, 3), (64, 8), (1000, 4), (5000, 2)])
+def test_partition_tiles_the_pair_stream(tool, tmp_path, batch, threads):
+    rng = np.random.default_rng(batch)
+    r1 = write_fastq(tmp_path / "a_1.fq", 1234, rng, 1)
+    r2 = write_fastq(tmp_path / "a_2.fq", 1234, rng, 2, min_len=20, max_len=90)   # mates of other lengths: other byte offsets
+    t = parts(tool, batch, threads, tmp_path / "a_1.fq", tmp_path / "a_2.fq")
+    assert t["ok"] and t["n_records"] == 1234
+    got1, got2, pos1, pos2 = [], [], 0, 0
+    for b1, e1, b2, e2, n, regular in t["batches"]:
+        assert regular and b1 == pos1 and b2 == pos2
+        p1, p2 = parse_range(tmp_path / "a_1.fq", b1, e1), parse_range(tmp_path / "a_2.fq", b2, e2)
+        assert len(p1) == len(p2) == n
+        got1 += p1
+        got2 += p2
+        pos1, pos2 = e1, e2
+    assert got1 == r1 and got2 == r2
+    assert pos1 == os.path.getsize(tmp_path / "a_1.fq") and pos2 == os.path.getsize(tmp_path / "a_2.fq")
+    assert [x[4] for x in t["batches"]] == [min(batch, 1234 - i) for i in range(0, 1234, batch)]
+
+
+def test_pair_stream_ends_with_the_shorter_file(tool, tmp_path):
+    rng = np.random.default_rng(5)
+    write_fastq(tmp_path / "a_1.fq", 500, rng, 1)
+    write_fastq(tmp_path / "a_2.fq", 333, rng, 2)
+    t = parts(tool, 100, 4, tmp_path / "a_1.fq", tmp_path / "a_2.fq")
+    assert t["ok"] and t["n_records"] == 333 and t["records_1"] == 500 and t["records_2"] == 333
+    assert [x[4] for x in t["batches"]] == [100, 100, 100, 33]
+    b1, e1 = t["batches"][-1][0], t["batches"][-1][1]
+    assert len(parse_range(tmp_path / "a_1.fq", b1, e1)) == 33          # exactly the 33 records the last pairs need
+
+
+def test_irregular_records_are_noticed_by_the_batch_that_owns_them(tool, tmp_path):
+    rng = np.random.default_rng(9)
+    write_fastq(tmp_path / "a.fq", 400, rng, 1)
+    lines = open(tmp_path / "a.fq", "rb").read().split(b"\n")
+    # record 250: sequence and quality wrapped over two lines each (legal FASTQ, not four-line)
+    i = 250 * 4
+    s, q = lines[i + 1], lines[i + 3]
+    lines[i:i + 4] = [lines[i], s[:10], s[10:], b"+", q[:10], q[10:]]
+    open(tmp_path / "b.fq", "wb").write(b"\n".join(lines))
+    t = parts(tool, 100, 4, tmp_path / "b.fq")
+    flags = [x[5] for x in t["batches"]]
+    assert flags[0] and flags[1] and not flags[2]                      # batches 0,1 are strict; batch 2 holds the wrapped record
+    # (what lies behind the first irregular batch is never used: the serial reader takes over there)
+    # CR/LF line ends, a missing final newline, gzip: not for the parallel readers
+    open(tmp_path / "c.fq", "wb").write(open(tmp_path / "a.fq", "rb").read().replace(b"\n", b"\r\n"))
+    assert not any(x[5] for x in parts(tool, 100, 2, tmp_path / "c.fq")["batches"])
+    open(tmp_path / "d.fq", "wb").write(open(tmp_path / "a.fq", "rb").read()[:-1])
+    t = parts(tool, 100, 2, tmp_path / "d.fq")
+    assert t["n_records"] == 399 and all(x[5] for x in t["batches"])   # the unterminated last record is left to the serial reader
+    with gzip.open(tmp_path / "e.fq.gz", "wb") as f:
+        f.write(open(tmp_path / "a.fq", "rb").read())
+    assert parts(tool, 100, 2, tmp_path / "e.fq.gz") == {"ok": False}
+    open(tmp_path / "empty.fq", "wb").close()
+    t = parts(tool, 100, 2, tmp_path / "empty.fq")
+    assert t["ok"] and t["n_records"] == 0 and t["batches"] == []

@@ -1,33 +1,44 @@
 #!/usr/bin/env python3
-"""End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs."""
+"""End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs.
+usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128")"""
 import json, os, subprocess, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from shark_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-on_target = float(os.environ.get('ON_TARGET', '0.5'))
+on_target = float(os.environ.get('ON_TARGET', '0.02'))
 extra = sys.argv[2:]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rng = np.random.default_rng(5)
 gene = synth.make_reference(1, 20000)[0]
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 L = 150
-td = tempfile.mkdtemp(dir="/tmp")
+td = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
 open(os.path.join(td, "g.fa"), "wb").write(b">gene0\n" + gene.tobytes() + b"\n")
 
 
 def write_fastq(path, mate):
-    # vectorised record assembly: "@r<id>/m\n" + seq + "\n+\n" + qual + "\n"
-    on = rng.random(n) < on_target
-    st = rng.integers(0, len(gene) - 400, size=n)
-    idx = st[:, None] + np.arange(L)[None, :]
-    seqs = np.where(on[:, None], gene[idx], acgt[rng.integers(0, 4, size=(n, L))])
-    ids = np.char.add(np.char.add("@r", np.arange(n).astype(str)), "/%d" % mate)
+    # whole file as one (n, record) byte matrix: "@r<9 digits>/m\n" + seq + "\n+\n" + qual + "\n"
+    W = 13 + 1 + L + 3 + L + 1
+    chunk = 1_000_000
     with open(path, "wb") as f:
-        q = b"I" * L
-        for i in range(n):
-            f.write(ids[i].encode()); f.write(b"\n"); f.write(seqs[i].tobytes()); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
+        for b0 in range(0, n, chunk):
+            m = min(chunk, n - b0)
+            rec = np.empty((m, W), dtype=np.uint8)
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            idx = np.arange(b0, b0 + m, dtype=np.int64)
+            for d in range(9):
+                rec[:, 2 + d] = ord("0") + (idx // 10 ** (8 - d)) % 10
+            rec[:, 11] = ord("/"); rec[:, 12] = ord("0") + mate; rec[:, 13] = 10
+            on = rng.random(m) < on_target
+            st = rng.integers(0, len(gene) - 400, size=m)
+            seqs = np.where(on[:, None], gene[st[:, None] + np.arange(L)[None, :]], acgt[rng.integers(0, 4, size=(m, L))])
+            rec[:, 14:14 + L] = seqs
+            rec[:, 14 + L] = 10; rec[:, 15 + L] = ord("+"); rec[:, 16 + L] = 10
+            rec[:, 17 + L:17 + 2 * L] = ord("I")
+            rec[:, 17 + 2 * L] = 10
+            rec.tofile(f)
 
 
 t0 = time.time()
@@ -40,10 +51,10 @@ for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
     t0 = time.time()
     with open(os.path.join(td, "out.ssv"), "wb") as so:
         r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"),
-                            "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq")] + args,
+                            "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-v"] + args,
                            stdout=so, stderr=subprocess.PIPE)
     dt = time.time() - t0
     print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
                       "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args,
-                      "stderr_tail": r.stderr.decode()[-400:]}), flush=True)
+                      "stderr_tail": r.stderr.decode()[-500:]}), flush=True)
 subprocess.run(["rm", "-rf", td])

@@ -1,14 +1,35 @@
 #!/usr/bin/env python3
-"""Copy the record run (tools/gpu_final_r1.sh -> gpurun_out/final/) into profiles/.
+"""Copy what tools/gpu_profiles.sh measured (gpurun_out/profiles/) into profiles/ (tracked).
 
-Usage: python tools/collect_profiles.py [tag]        (tag defaults to r01_final)
-Takes the newest rocprofv3 output directory of each pass, keeps the kernel-stats CSV, and writes
-pmc_traffic.json (per launch of the classify kernel; FETCH_SIZE correction as in profiles/README.md).
+Usage: python tools/collect_profiles.py [tag]        (tag defaults to r02)
+Writes
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+  profiles/<tag>_bench_profiled.json the bench line printed by that profiled run
+  profiles/pmc_counters.json        per-launch counters of the classify kernels, stamped with the commit and with
+                                    the hash of the kernel sources they were taken on; bench.py uses the file only
+                                    when that hash equals the hash of the sources it runs (no stale traffic figures)
 """
-import csv, glob, json, os, shutil, sys
+import csv
+import glob
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
-src = "gpurun_out/final"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", "profiles")
+KERNEL_SOURCES = ["classify.hip", "kmer_device.hpp", "shark_internal.hpp"]    # same list as bench.py
+
+
+def kernel_src_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "shark_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def newest(pattern):
     fs = glob.glob(pattern)
@@ -16,40 +37,44 @@ def newest(pattern):
         raise SystemExit("missing " + pattern)
     return max(fs, key=os.path.getmtime)
 
-def counters(path):
-    acc, name = {}, ""
-    for r in csv.DictReader(open(path)):
-        if "classify_fast" in r["Kernel_Name"]:
-            name = r["Kernel_Name"]
-            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, name
 
-bench = json.loads(open(src + "/bench.json").read().strip().splitlines()[-1])
-json.dump(bench, open("profiles/%s_bench.json" % tag, "w"), indent=1)
-shutil.copy(newest(src + "/kt/*/*_kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
-host = [json.loads(l) for l in open(src + "/host_path.json") if l.strip().startswith("{")]
-json.dump(host, open("profiles/%s_host_path.json" % tag, "w"), indent=1)
+raw = json.load(open(os.path.join(src, "counters_raw.json")))
+stats = newest(src + "/kt/*/*_kernel_stats.csv")
+shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
+bench = json.loads([l for l in open(os.path.join(src, "kt.json")) if l.startswith("{")][-1])
+json.dump(bench, open(os.path.join(ROOT, "profiles", "%s_bench_profiled.json" % tag), "w"), indent=1)
+avg_ms = {}
+for r in csv.DictReader(open(stats)):
+    if "classify" in r["Name"]:
+        avg_ms[r["Name"].split("(")[0].replace("void shk::", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
 
-f, kname = counters(newest(src + "/pmc_fetch/*/*_counter_collection.csv"))
-w, _ = counters(newest(src + "/pmc_write/*/*_counter_collection.csv"))
-cfg = bench["config"]
-pairs = cfg["pairs_per_step_per_gpu"]
-known_in = 2 * 150 * pairs + 2 * 8 * (pairs + 1)          # bases of both mates + both offset arrays
-fetch_kb, write_kb = f["FETCH_SIZE"], w["WRITE_SIZE"]
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "shark_amd/csrc"], capture_output=True, text=True).stdout.strip()
 out = {
-    "pairs": pairs, "k": 17, "bf_log2": 33, "on_target": cfg["on_target"],
-    "kernel": kname.split("(")[0].replace("void shk::", "") + " (" + cfg["probe_mode"] + ")",
-    "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-    "TCC_HIT_sum": w.get("TCC_HIT_sum"), "TCC_MISS_sum": w.get("TCC_MISS_sum"),
-    "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests of coalesced streams at 64 B; "
-                  "the fetched bytes here are the coalesced input stream); WRITE_SIZE exact",
-    "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
-    "hbm_bytes_per_launch_uncorrected": int(fetch_kb * 1024 + write_kb * 1024),
-    "known_input_bytes": known_in,
+    "commit": commit + ("+dirty" if dirty else ""), "kernel_src_sha": kernel_src_sha(), "k": 17, "bf_log2": 33,
+    "how": "tools/gpu_profiles.sh: rocprofv3 --pmc <one counter set per run> --kernel-trace; per launch of the kernel that does the "
+           "work (10 M pairs 2x150 bp); FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (uncorrected)",
+    "kernel_stats": {k: {"calls": c, "avg_ms": round(ms, 4)} for k, (c, ms) in avg_ms.items()},
+    "workloads": {},
 }
-json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
-for r in csv.DictReader(open("profiles/%s_kernel_stats.csv" % tag)):
-    if "classify_fast" in r["Name"]:
-        print("kernel stats:", r["Name"][:60], "calls", r["Calls"], "avg_ms %.3f" % (float(r["AverageNs"]) / 1e6))
-print("bench kernel_ms", bench["roofline"]["kernel_ms"], "kt run kernel_ms", json.loads(open(src + "/kt.json").read().strip().splitlines()[-1])["roofline"]["kernel_ms"])
+for wl, kernels in raw.items():
+    # the kernel that did the work = the one with the most VALU instructions
+    kn = max(kernels, key=lambda k: kernels[k].get("SQ_INSTS_VALU", 0))
+    c = kernels[kn]
+    name = wl if wl == "configs2" else "configs1_ot%.2f" % float(wl.split("ot")[1])
+    e = {"kernel": kn.replace("void shk::", ""), "pairs": 10_000_000}
+    for key in ("FETCH_SIZE", "WRITE_SIZE"):
+        if key in c:
+            e[key + "_KB"] = c[key]
+    for key in ("TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_THREAD_CYCLES_VALU"):
+        if key in c:
+            e[key] = c[key]
+    if "SQ_INSTS_VALU" in e:
+        e["valu_per_pair"] = round(e["SQ_INSTS_VALU"] / e["pairs"], 1)
+        e["salu_per_pair"] = round(e.get("SQ_INSTS_SALU", 0) / e["pairs"], 1)
+        if "SQ_THREAD_CYCLES_VALU" in e:
+            e["active_lanes_per_valu"] = round(e["SQ_THREAD_CYCLES_VALU"] / e["SQ_INSTS_VALU"], 1)
+    out["workloads"][name] = e
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_counters.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:2500])
