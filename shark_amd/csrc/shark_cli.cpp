@@ -12,6 +12,7 @@
 // per GPU calls shk_classify (ReadAnalyzer role), and the main thread writes
 // batches in input order (ReadOutput role).  Extra flags: --gpus N, --batch N.
 #include <getopt.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <chrono>
@@ -204,6 +205,11 @@ struct default_init_allocator : std::allocator<T> {
 // the same, in page-locked host memory (shk_alloc_pinned): what the GPU reads -- sequences, qualities, offsets -- is
 // copied by the DMA engine straight from here, which is what lets shk_classify_submit return before the copy is done.
 // Batches are recycled, so these allocations happen once per pipeline slot.  Falls back to malloc when pinning fails.
+// Page-locking costs about as much per byte as parsing does (measured: 21 batches of 160 MB took 12 thread-seconds to
+// pin), and the copies from ordinary memory run at 300 M reads/s -- several times what the parsers deliver -- so batches
+// are pinned only for samples large enough to pay that back (or when SHARK_PINNED=1 / 0 says so).
+std::atomic<bool> g_pin_batches{false};
+
 template <typename T>
 struct pinned_allocator {
   using value_type = T;
@@ -214,7 +220,7 @@ struct pinned_allocator {
   {
     // header word in front of the block: 1 = pinned, 0 = malloc
     const size_t bytes = n * sizeof(T) + 64;
-    char *raw = static_cast<char *>(shk_alloc_pinned(bytes));
+    char *raw = g_pin_batches.load(std::memory_order_relaxed) ? static_cast<char *>(shk_alloc_pinned(bytes)) : nullptr;
     bool pinned = raw != nullptr;
     if (!raw) raw = static_cast<char *>(malloc(bytes));
     if (!raw) throw std::bad_alloc();
@@ -705,6 +711,13 @@ int main(int argc, char *argv[])
       todo[(size_t)(b->index % (uint64_t)n_gpus)]->push(std::move(b));
     };
 
+    {
+      // pinned batches for samples of 8 GiB and more (the pinning is then a few percent of the run)
+      struct stat st1;
+      const bool big = stat(opt.sample1_path.c_str(), &st1) == 0 && (uint64_t)st1.st_size >= (8ull << 30);
+      const char *pe = getenv("SHARK_PINNED");
+      g_pin_batches = pe ? pe[0] == '1' : big;
+    }
     // ---- the parallel feed -------------------------------------------------------
     shk::BatchTable tab1, tab2;
     bool parallel_feed = !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");

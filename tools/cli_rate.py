@@ -31,8 +31,9 @@ def write_fastq(path, mate):
             for d in range(9):
                 rec[:, 2 + d] = ord("0") + (idx // 10 ** (8 - d)) % 10
             rec[:, 11] = ord("/"); rec[:, 12] = ord("0") + mate; rec[:, 13] = 10
-            on = rng.random(m) < on_target
-            st = rng.integers(0, len(gene) - 400, size=m)
+            prng = np.random.default_rng(1000 + b0)          # the same pairs are on-target in both mate files
+            on = prng.random(m) < on_target
+            st = prng.integers(0, len(gene) - 400, size=m)
             seqs = np.where(on[:, None], gene[st[:, None] + np.arange(L)[None, :]], acgt[rng.integers(0, 4, size=(m, L))])
             rec[:, 14:14 + L] = seqs
             rec[:, 14 + L] = 10; rec[:, 15 + L] = ord("+"); rec[:, 16 + L] = 10
