@@ -89,6 +89,49 @@ inline void count_file(const std::string &path, unsigned threads, BatchTable &t,
   t.ok = true;
 }
 
+// Shortcut for files whose records all have ONE byte length (fixed-width names and reads, e.g. simulators and SRA dumps):
+// record i then starts at i * rec_len and no counting pass is needed.  The guess is cheap to refute -- the length of the
+// first record, file size a multiple of it, and a sample of record starts that must read "\n@" -- and costs nothing if
+// wrong elsewhere: every reader still validates every record of its batch, and a batch that is not strict four-line
+// FASTQ hands over to the serial reader as always.  Returns false when the file does not look fixed-width.
+inline bool fixed_record_file(const std::string &path, BatchTable &t, uint64_t &rec_len)
+{
+  t.ok = false;
+  t.fd = ::open(path.c_str(), O_RDONLY);
+  if (t.fd < 0) return false;
+  struct stat st;
+  if (fstat(t.fd, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+  t.file_size = (uint64_t)st.st_size;
+  std::vector<char> head((size_t)std::min<uint64_t>(t.file_size, 1u << 16));
+  if (head.empty() || !pread_all(t.fd, head.data(), 0, head.size())) return false;
+  if ((unsigned char)head[0] == 0x1f) return false;   // gzip
+  const char *p = head.data(), *pe = p + head.size();
+  for (int l = 0; l < 4; ++l) {
+    p = (const char *)memchr(p, '\n', (size_t)(pe - p));
+    if (!p) return false;
+    ++p;
+  }
+  rec_len = (uint64_t)(p - head.data());
+  if (rec_len < 8 || t.file_size % rec_len) return false;
+  t.n_records = t.file_size / rec_len;
+  // 4096 record starts spread over the file
+  char two[2];
+  const uint64_t step = std::max<uint64_t>(1, t.n_records / 4096);
+  for (uint64_t r = step; r < t.n_records; r += step) {
+    if (pread(t.fd, two, 2, (off_t)(r * rec_len - 1)) != 2 || two[0] != '\n' || two[1] != '@') return false;
+  }
+  t.ok = true;
+  return true;
+}
+
+inline void fixed_record_batches(BatchTable &t, uint64_t rec_len, uint64_t batch, uint64_t limit)
+{
+  t.batch = batch;
+  const uint64_t n_b = (limit + batch - 1) / batch;
+  t.off.assign(n_b + 1, 0);
+  for (uint64_t i = 0; i <= n_b; ++i) t.off[i] = std::min<uint64_t>(i * batch, limit) * rec_len;
+}
+
 // Phase 2: off[i] = byte offset of record min(i * batch, limit) for i = 0 .. ceil(limit / batch); `limit` <= n_records is
 // the number of records the pair stream has (it ends with the shorter mate file, FastqSplitter.hpp:60).
 inline void locate_batches(BatchTable &t, const std::vector<uint64_t> &cnt, uint64_t batch, uint64_t limit, unsigned threads)
@@ -169,6 +212,31 @@ inline size_t parse_strict_batch(int fd, uint64_t b, uint64_t e, size_t want, Pa
   }
   pb.n = r;
   return r;
+}
+
+// copy the first `want` records of a parsed batch into structure-of-arrays strings (names up to the first whitespace,
+// sequences, qualities sharing the sequence offsets)
+template <typename Ids, typename Seqs>
+inline void fill_soa(const ParsedBatch &pb, size_t want, Ids &id, Seqs &seq, Seqs &qual)
+{
+  id.off.resize(want + 1);
+  seq.off.resize(want + 1);
+  qual.off.resize(want + 1);
+  uint64_t ai = 0, as = 0;
+  for (size_t k = 0; k < want; ++k) {
+    id.off[k] = ai; seq.off[k] = as; qual.off[k] = as;
+    ai += pb.id_len[k]; as += pb.seq_len[k];
+  }
+  id.off[want] = ai; seq.off[want] = as; qual.off[want] = as;
+  id.bytes.resize(ai);
+  seq.bytes.resize(as);
+  qual.bytes.resize(as);
+  const char *base = pb.buf.data();
+  for (size_t k = 0; k < want; ++k) {
+    memcpy(id.bytes.data() + id.off[k], base + pb.begin(4 * k) + 1, pb.id_len[k]);
+    memcpy(seq.bytes.data() + seq.off[k], base + pb.nl[4 * k] + 1, pb.seq_len[k]);
+    memcpy(qual.bytes.data() + qual.off[k], base + pb.nl[4 * k + 2] + 1, pb.seq_len[k]);
+  }
 }
 
 }  // namespace shk

@@ -63,7 +63,7 @@ const char *USAGE_MESSAGE =
     "\n"
     "MI355X build only:\n"
     "          --gpus N                      number of GPUs to shard the reads over (default:1)\n"
-    "          --batch N                     reads per device batch (default:262144)\n"
+    "          --batch N                     reads per device batch (default:65536)\n"
     "          --gene-counts FILE            write <gene> <assigned reads> per gene (summed over the GPUs with RCCL)\n"
     "      -t N also sets the number of host threads that parse FASTQ / format output (default: up to 16)\n";
 
@@ -77,7 +77,7 @@ struct Options {
   bool single = false, verbose = false;
   int nThreads = 1;
   int gpus = 1;
-  uint64_t batch = 1u << 18;
+  uint64_t batch = 1u << 16;
   std::string gene_counts_path;
 };
 
@@ -722,20 +722,32 @@ int main(int argc, char *argv[])
     shk::BatchTable tab1, tab2;
     bool parallel_feed = !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");
     uint64_t n_par_records = 0;       // records both mate files certainly have: the pair stream of the strict part
+    bool fixed_width = false;
     if (parallel_feed) {
-      std::vector<uint64_t> cnt1, cnt2;
-      shk::count_file(opt.sample1_path, io_threads, tab1, cnt1);
-      parallel_feed = tab1.ok;
-      if (parallel_feed && opt.paired_flag) {
-        shk::count_file(opt.sample2_path, io_threads, tab2, cnt2);
-        parallel_feed = tab2.ok;
-      }
-      if (parallel_feed) {
+      // fixed-width records: batch offsets are arithmetic; otherwise a parallel newline count of both files
+      uint64_t rl1 = 0, rl2 = 0;
+      fixed_width = shk::fixed_record_file(opt.sample1_path, tab1, rl1) && (!opt.paired_flag || shk::fixed_record_file(opt.sample2_path, tab2, rl2));
+      if (fixed_width) {
         n_par_records = opt.paired_flag ? std::min(tab1.n_records, tab2.n_records) : tab1.n_records;
-        shk::locate_batches(tab1, cnt1, opt.batch, n_par_records, io_threads);
-        if (opt.paired_flag) shk::locate_batches(tab2, cnt2, opt.batch, n_par_records, io_threads);
-        parallel_feed = tab1.ok && (!opt.paired_flag || tab2.ok);
-        if (!parallel_feed) n_par_records = 0;
+        shk::fixed_record_batches(tab1, rl1, opt.batch, n_par_records);
+        if (opt.paired_flag) shk::fixed_record_batches(tab2, rl2, opt.batch, n_par_records);
+      } else {
+        if (tab1.fd >= 0) { ::close(tab1.fd); tab1.fd = -1; }
+        if (tab2.fd >= 0) { ::close(tab2.fd); tab2.fd = -1; }
+        std::vector<uint64_t> cnt1, cnt2;
+        shk::count_file(opt.sample1_path, io_threads, tab1, cnt1);
+        parallel_feed = tab1.ok;
+        if (parallel_feed && opt.paired_flag) {
+          shk::count_file(opt.sample2_path, io_threads, tab2, cnt2);
+          parallel_feed = tab2.ok;
+        }
+        if (parallel_feed) {
+          n_par_records = opt.paired_flag ? std::min(tab1.n_records, tab2.n_records) : tab1.n_records;
+          shk::locate_batches(tab1, cnt1, opt.batch, n_par_records, io_threads);
+          if (opt.paired_flag) shk::locate_batches(tab2, cnt2, opt.batch, n_par_records, io_threads);
+          parallel_feed = tab1.ok && (!opt.paired_flag || tab2.ok);
+          if (!parallel_feed) n_par_records = 0;
+        }
       }
     }
     const uint64_t n_par_batches = (n_par_records + opt.batch - 1) / opt.batch;
@@ -773,24 +785,8 @@ int main(int argc, char *argv[])
           std::unique_ptr<ReadBatch> b = pool.acquire();
           b->index = i;
           b->first_read = i * opt.batch;
-          auto fill1 = [want](const shk::ParsedBatch &pb, Strings &id, DevStrings &seq, DevStrings &qual) {
-            id.off.resize(want + 1); seq.off.resize(want + 1); qual.off.resize(want + 1);
-            uint64_t ai = 0, as = 0;
-            for (size_t k = 0; k < want; ++k) {
-              id.off[k] = ai; seq.off[k] = as; qual.off[k] = as;
-              ai += pb.id_len[k]; as += pb.seq_len[k];
-            }
-            id.off[want] = ai; seq.off[want] = as; qual.off[want] = as;
-            id.bytes.resize(ai); seq.bytes.resize(as); qual.bytes.resize(as);
-            const char *base = pb.buf.data();
-            for (size_t k = 0; k < want; ++k) {
-              memcpy(id.bytes.data() + id.off[k], base + pb.begin(4 * k) + 1, pb.id_len[k]);
-              memcpy(seq.bytes.data() + seq.off[k], base + pb.nl[4 * k] + 1, pb.seq_len[k]);
-              memcpy(qual.bytes.data() + qual.off[k], base + pb.nl[4 * k + 2] + 1, pb.seq_len[k]);
-            }
-          };
-          fill1(p1, b->id1, b->seq1, b->qual1);
-          if (opt.paired_flag) fill1(p2, b->id2, b->seq2, b->qual2);
+          shk::fill_soa(p1, want, b->id1, b->seq1, b->qual1);
+          if (opt.paired_flag) shk::fill_soa(p2, want, b->id2, b->seq2, b->qual2);
           t_reader[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           if (i >= irregular_at.load()) { pool.release(std::move(b)); break; }
           dispatch(std::move(b));
@@ -895,7 +891,7 @@ int main(int argc, char *argv[])
     if (opt.verbose) {
       double tr = 0;
       for (double x : t_reader) tr += x;
-      std::cerr << "[shark/io] threads " << io_threads << ", parallel readers " << n_readers << " (" << std::min<uint64_t>(irregular_at.load(), n_par_batches)
+      std::cerr << "[shark/io] threads " << io_threads << ", parallel readers " << n_readers << (fixed_width ? " fixed-width records (" : " (") << std::min<uint64_t>(irregular_at.load(), n_par_batches)
                 << " batches, " << tr << " thread-seconds), serial reader: index " << fs->t_index << " s (" << fs->stage_report() << "), fill "
                 << fs->t_fill << " s, serial " << fs->t_serial << " s; classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
     }
