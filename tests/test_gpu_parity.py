@@ -713,3 +713,27 @@ def test_handworked_cases(case, probe, tmp_path):
     r = _run_shark(args, str(tmp_path))
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert r.stdout.decode() == case["ssv"]
+
+
+def test_dist_allreduce_one_process_per_gpu_form(oracle):
+    """shk_dist_unique_id / shk_dist_init / shk_dist_gene_counts_allreduce: the one-process-per-GPU form of the exchange step,
+    here as a world of one rank (a real RCCL communicator and a real ncclAllReduce on this GPU).  The totals land in a
+    separate buffer: the local counters are unchanged, and reducing twice gives the same totals."""
+    import ctypes as C
+    from shark_amd.capi import SHK_DIST_ID_BYTES
+    rng = np.random.default_rng(47)
+    genes = synth.make_genes(rng, 9, 400, 1200)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 22)
+    b = synth.make_reads(rng, genes, 2000, read_len=100, paired=True, on_target=0.8)
+    h.gene_counts_reset()
+    goff, gids = _compare_classify(o, h, b)
+    want = np.bincount(gids, minlength=16)[:16].astype(np.uint64)
+    ident = (C.c_uint8 * SHK_DIST_ID_BYTES)()
+    assert h.L.shk_dist_unique_id(ident) == 0
+    assert h.L.shk_dist_init(h.h, ident, 0, 1) == 0
+    assert h.L.shk_dist_init(h.h, ident, 1, 1) != 0                      # rank outside the world
+    for _ in range(2):
+        assert np.array_equal(h.dist_gene_counts_allreduce(16), want)
+        assert np.array_equal(h.gene_counts(16), want)
+    _compare_classify(o, h, b)                                             # more reads, then reduce again: twice the counts, not four times
+    assert np.array_equal(h.dist_gene_counts_allreduce(16), 2 * want)
