@@ -35,7 +35,8 @@ extern "C" {
 #define SHK_ERR_STATE            -2  /* call not allowed in the current mode */
 #define SHK_ERR_HIP              -3  /* HIP runtime error; text via shk_last_error */
 #define SHK_ERR_NOMEM            -4
-#define SHK_ERR_TOO_MANY_GENES   -5  /* > 65536 FASTA records: gene ids are uint16_t (small_vector.hpp:46) */
+#define SHK_ERR_TOO_MANY_GENES   -5  /* >= 2^31 FASTA records (more than 65 536 genes are handled as the reference handles them:
+                                        ids wrap to uint16_t, small_vector.hpp:46, and are not de-duplicated, bloomfilter.h:72) */
 #define SHK_ERR_INDEX_TOO_LARGE  -6  /* >= 2^31 set bits or list entries (int in bloomfilter.h:70,:130) */
 #define SHK_ERR_NO_DEVICE        -7
 

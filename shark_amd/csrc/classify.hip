@@ -243,7 +243,13 @@ __device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadM
   }
 }
 
-template <int U, int MODE, bool HASQ, bool FAST, bool EMIT>
+// WRAP (general kernel only): the index has more than 65 536 genes, so a list may hold an id several times
+// (index_build.hip).  The reference's accumulation then sees that id several times for one k-mer (ReadAnalyzer.hpp:56-62,
+// :79-86): behind the FIRST valid k-mer of the read, a repeated id adds min(k, pos - last) = min(k, 0) = 0 to the coverage
+// and 1 to the k-mer count; at the first k-mer itself (handled separately at :56-62, `nk = 1`, last = pos - 1) every
+// repetition adds min(k, 1) = 1 to the coverage and leaves the count at 1.  So with m_j = multiplicity of gene g in the
+// list of hit j:  nk = sum m_j - (m_first - 1),  cov = (union of the k-mer intervals) + (m_first - 1).
+template <int U, int MODE, bool HASQ, bool FAST, bool EMIT, bool WRAP = false>
 __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint64_t read, const int lane, const WaveStore st,
                                              const uint32_t slot_cap, const uint32_t tie_cov, const uint32_t tie_nk,
                                              const uint32_t *lsum, const ReadMeta meta, const bool pre, const Raw8 pre_w, const Raw8 pre_q)
@@ -262,7 +268,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   const uint32_t P2 = (L1 + 7u) & ~7u;            // packed position of mate 2's first base
   const uint32_t ns = nk2 ? P2 + nk2 : nk1;       // slots are the packed positions [0, ns)
 
-  if (FAST) {
+  if (FAST || (!EMIT && P.work == nullptr)) {   // (general kernel over ALL reads, wrap mode: same queue for what does not fit its scratch)
     if (ns > slot_cap) {  // does not fit the LDS specialisation: general kernel
       if (lane == 0) {
         const ClassifyOut *O = out_ptrs(P);
@@ -333,6 +339,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     return act & ((win & kmask) == kmask);
   };
   bool any_hit = false;
+  uint32_t my_first = GENE_INF;   // WRAP: smallest valid slot of this lane
   unsigned long long wk_kmers = 0, wk_hits = 0, wk_ids = 0;
   // slot records of the (single) round of the fast kernel live in registers
   uint32_t cur[U], rs[U], re[U];
@@ -366,6 +373,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       const uint64_t hsh = xxh64_u64(canon);
       pos[j] = POW2 ? (LAZY ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
       ok[j] = LAZY ? true : ((FAST || t < ns) && slot_ok(pp));
+      if (WRAP && ok[j] && t < my_first) my_first = t;
     }
     if (!FAST && P.work_counters) {
 #pragma unroll
@@ -594,6 +602,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
   uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
   uint32_t n_emit = 0;
   uint32_t len = 0;
+  const uint32_t first_valid = WRAP ? wave_min_u32(my_first) : 0u;   // the read's first valid k-mer (ReadAnalyzer.hpp:51-62)
   if (any_hit && !SHK_ABL(P, 2u)) {   // ablation 2: skip the vote
     // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49);
     // only needed for the threshold, i.e. when something hit
@@ -666,10 +675,25 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
           const uint64_t Hc = __ballot(h);
           nk += (uint32_t)__builtin_popcountll(Hc);
           cov += cover(Hc, Hprev);
+          uint32_t mult = 0;
           if (h) {
-            const uint32_t c_rs = st.rec_start[t] + 1u;
+            uint32_t c_rs = st.rec_start[t] + 1u;
+            mult = 1;
+            if (WRAP) {
+              const uint32_t c_end = st.rec_end[t];
+              while (c_rs < c_end && (uint32_t)P.ids[c_rs] == g) { ++c_rs; ++mult; }   // the id again: same gene, same k-mer
+            }
             st.rec_start[t] = c_rs;
             st.cur[t] = c_rs < st.rec_end[t] ? (uint32_t)P.ids[c_rs] : GENE_INF;
+          }
+          if (WRAP) {
+            nk += wave_sum_u32(h ? mult - 1u : 0u);
+            const uint32_t fl = first_valid - tb;            // wave-uniform
+            if (fl < 64u && ((Hc >> fl) & 1ull)) {
+              const uint32_t extra = (uint32_t)__builtin_amdgcn_readlane((int)mult, (int)fl) - 1u;
+              cov += extra;
+              nk -= extra;
+            }
           }
           Hprev = Hc;
         }
@@ -1195,7 +1219,7 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
 // fast kernel's capacity (MAIN) and to write out tie lists longer than
 // SHK_INLINE_IDS (EMIT).  Work items come from a queue.
 // ---------------------------------------------------------------------------
-template <bool POW2, bool HASQ, bool EMIT>
+template <bool POW2, bool HASQ, bool EMIT, bool WRAP>
 __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const ClassifyParams P)
 {
   constexpr int U = 4;
@@ -1226,7 +1250,7 @@ __global__ __launch_bounds__(CF_THREADS) void classify_general_kernel(const Clas
     } else if (P.work) {
       read = P.work[w];
     }
-    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT>(P, read, lane, st, S, tc, tn, nullptr, fetch_meta(P, read), false, Raw8{0u, 0u, 0u, 0u}, Raw8{0u, 0u, 0u, 0u});
+    process_read<U, POW2 ? PM_BV : PM_BV_MOD, HASQ, false, EMIT, WRAP>(P, read, lane, st, S, tc, tn, nullptr, fetch_meta(P, read), false, Raw8{0u, 0u, 0u, 0u}, Raw8{0u, 0u, 0u, 0u});
   }
 }
 
@@ -1411,7 +1435,7 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   return SHK_OK;
 }
 
-bool uni_kernel_available(const Ctx *ctx) { return pm_lds(probe_mode(ctx->idx)); }
+bool uni_kernel_available(const Ctx *ctx) { return pm_lds(probe_mode(ctx->idx)) && !ctx->idx.wrap; }
 
 template <int U>
 static void launch_uni_u(const ClassifyParams &p, bool pow2, bool hasq, unsigned grid, hipStream_t s)
@@ -1453,9 +1477,11 @@ int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *f
 int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsigned n_waves, hipStream_t stream)
 {
   if (p.n_work == 0 && !p.work_count) return SHK_OK;
-  const bool pow2 = ctx->idx.pow2, hasq = p.hasq != 0;
+  const bool pow2 = ctx->idx.pow2, hasq = p.hasq != 0, wrap = ctx->idx.wrap;
   const unsigned grid = (n_waves + CF_WAVES - 1) / CF_WAVES;
-#define LG(P2_, HQ_, EM_) hipLaunchKernelGGL((classify_general_kernel<P2_, HQ_, EM_>), dim3(grid), dim3(CF_THREADS), 0, stream, p)
+#define LG3(P2_, HQ_, EM_) do { if (wrap) hipLaunchKernelGGL((classify_general_kernel<P2_, HQ_, EM_, true>), dim3(grid), dim3(CF_THREADS), 0, stream, p); \
+                                else hipLaunchKernelGGL((classify_general_kernel<P2_, HQ_, EM_, false>), dim3(grid), dim3(CF_THREADS), 0, stream, p); } while (0)
+#define LG(P2_, HQ_, EM_) LG3(P2_, HQ_, EM_)
   if (emit) {
     if (pow2) { if (hasq) LG(true, true, true); else LG(true, false, true); }
     else { if (hasq) LG(false, true, true); else LG(false, false, true); }
@@ -1463,6 +1489,7 @@ int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsign
     if (pow2) { if (hasq) LG(true, true, false); else LG(true, false, false); }
     else { if (hasq) LG(false, true, false); else LG(false, false, false); }
   }
+#undef LG3
 #undef LG
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;

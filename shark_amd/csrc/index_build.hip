@@ -46,7 +46,7 @@ __global__ __launch_bounds__(RK_THREADS) void ref_kmer_kernel(const uint8_t *__r
                                                               uint64_t *__restrict__ bf64, uint64_t bf_bits, uint64_t bf_mask, int pow2,
                                                               uint8_t *__restrict__ rec_has, unsigned long long *__restrict__ n_valid,
                                                               const uint32_t *__restrict__ rank_w, const uint32_t *__restrict__ rec_nidx,
-                                                              uint64_t *__restrict__ keys, uint64_t sentinel)
+                                                              uint64_t *__restrict__ keys, uint64_t sentinel, int wrap)
 {
   __shared__ uint8_t codes[RK_THREADS + 32];
   const uint64_t b0 = (uint64_t)blockIdx.x * RK_THREADS;
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(RK_THREADS) void ref_kmer_kernel(const uint8_t *__r
   } else {
     // bloomfilter.h:70: kmer_rank = _brank(bf_idx); the list entry is (rank, gene)
     const uint32_t rk = bf_rank(rank_w, bf64[pos >> 6], pos);
-    keys[i] = ((uint64_t)rk << 16) | (uint64_t)rec_nidx[r];
+    const uint32_t g = rec_nidx[r];
+    // normal: (rank, gene).  More than 65 536 genes (wrap): (rank, gene & 0xFFFF, came-from-a-gene-above-65535) -- see build_index
+    keys[i] = wrap ? (((uint64_t)rk << 17) | ((uint64_t)(g & 0xFFFFu) << 1) | (g > 0xFFFFu ? 1u : 0u)) : (((uint64_t)rk << 16) | (uint64_t)g);
   }
 }
 
@@ -122,28 +124,30 @@ __global__ __launch_bounds__(256) void bf_summary_kernel(const uint64_t *__restr
 }
 
 // sorted keys -> head flags (first occurrence of each distinct (rank, gene))
-__global__ __launch_bounds__(256) void unique_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t sentinel, uint32_t *__restrict__ flags)
+// (wrap: an entry of a gene above 65535 is never dropped -- bloomfilter.h:72 compares the uint16_t last() with the int index)
+__global__ __launch_bounds__(256) void unique_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t sentinel, int wrap, uint32_t *__restrict__ flags)
 {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t key = keys[i];
-  flags[i] = (key < sentinel && (i == 0 || keys[i - 1] != key)) ? 1u : 0u;
+  flags[i] = (key < sentinel && (i == 0 || keys[i - 1] != key || (wrap && (key & 1ull)))) ? 1u : 0u;
 }
 
-// write the CSR: ids[o] for every distinct key, offsets[r] at the first key of rank r
+// write the CSR: ids[o] for every kept key, offsets[r] at the first key of rank r
 __global__ __launch_bounds__(256) void csr_write_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx, uint64_t n, uint64_t sentinel,
-                                                        uint32_t *__restrict__ csr_off, uint16_t *__restrict__ csr_ids)
+                                                        int wrap, uint32_t *__restrict__ csr_off, uint16_t *__restrict__ csr_ids)
 {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t key = keys[i];
   if (key >= sentinel) return;
-  const bool head = i == 0 || keys[i - 1] != key;
+  const bool head = i == 0 || keys[i - 1] != key || (wrap && (key & 1ull));
   if (!head) return;
   const uint32_t o = idx[i];
-  csr_ids[o] = (uint16_t)(key & 0xFFFFu);
-  const uint64_t r = key >> 16;
-  if (i == 0 || (keys[i - 1] >> 16) != r) csr_off[r] = o;
+  const uint32_t sh = wrap ? 17u : 16u;
+  csr_ids[o] = (uint16_t)((key >> (wrap ? 1 : 0)) & 0xFFFFu);
+  const uint64_t r = key >> sh;
+  if (i == 0 || (keys[i - 1] >> sh) != r) csr_off[r] = o;
 }
 
 // list entries: {start, len (clipped), first gene} per set bit
@@ -247,7 +251,7 @@ int build_index(Ctx *ctx)
     // ---- pass 1: set bits ---------------------------------------------------
     hipLaunchKernelGGL(ref_kmer_kernel<MODE_SET>, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st,
                        d_bytes, total, d_rec_off, n_rec, k, ix.bf64, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
-                       d_rec_has, d_n_valid, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0ull);
+                       d_rec_has, d_n_valid, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0ull, 0);
     BI_HIP(hipGetLastError());
     BI_HIP(hipMemcpyAsync(h_has.data(), d_rec_has, n_rec, hipMemcpyDeviceToHost, st));
   }
@@ -282,27 +286,34 @@ int build_index(Ctx *ctx)
     ++nidx;
   }
   ctx->nidx = nidx;
-  // gene ids are stored as uint16_t (small_vector.hpp:46); beyond 65536 the
-  // reference wraps and duplicates -- refused here instead of reproduced.
+  // Gene ids are stored as uint16_t (small_vector.hpp:46).  With more than 65 536 genes the reference keeps going: the
+  // index wraps (gene 65536+x is stored as x and reported under x's name), and because bloomfilter.h:72 compares the
+  // uint16_t last() with the int gene index -- never equal above 65535 -- such a gene is appended once per k-mer
+  // OCCURRENCE, duplicates included.  A set bit's list is then [ascending unique ids of the genes below 65536] followed by
+  // one entry per occurrence from the genes above, in gene order.  ReadAnalyzer only ever accumulates over a list, so the
+  // order inside it does not matter, the multiplicities do: the lists are stored sorted by id with their duplicates
+  // (`wrap` mode), and the classify kernels count multiplicities (classify.hip, WRAP).
+  bool wrap = false;
   for (uint32_t r = 0; r < n_rec; ++r)
-    if (h_has[r] && h_nidx[r] > 0xFFFFu) { cleanup(); ctx->last_error = "more than 65536 genes"; return SHK_ERR_TOO_MANY_GENES; }
+    if (h_has[r] && h_nidx[r] > 0xFFFFu) wrap = true;
+  ix.wrap = wrap;
 
   // ---- pass 2 + switch_mode(2): (rank, gene) keys -> sort -> unique -> CSR ----
   BI_HIP(hipMalloc((void **)&d_csr_off, (n_set + 2) * sizeof(uint32_t)));
   uint64_t tot_idx = 0;
   if (n_valid > 0) {
-    const uint64_t sentinel = n_set << 16;
+    const uint64_t sentinel = n_set << (wrap ? 17 : 16);
     BI_HIP(hipMalloc((void **)&d_rec_nidx, n_rec * sizeof(uint32_t)));
     BI_HIP(hipMemcpyAsync(d_rec_nidx, h_nidx.data(), n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     BI_HIP(hipMalloc((void **)&d_keys, total * sizeof(uint64_t)));
     BI_HIP(hipMalloc((void **)&d_keys_alt, total * sizeof(uint64_t)));
     hipLaunchKernelGGL(ref_kmer_kernel<MODE_KEYS>, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st,
                        d_bytes, total, d_rec_off, n_rec, k, ix.bf64, ix.bf_bits, ix.bf_bits - 1, ix.pow2 ? 1 : 0,
-                       (uint8_t *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)ix.rank_w, (const uint32_t *)d_rec_nidx, d_keys, sentinel);
+                       (uint8_t *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)ix.rank_w, (const uint32_t *)d_rec_nidx, d_keys, sentinel, wrap ? 1 : 0);
     BI_HIP(hipGetLastError());
 
     // bits needed to order keys up to and including the sentinel
-    unsigned end_bit = 17;
+    unsigned end_bit = wrap ? 18 : 17;
     while (end_bit < 64 && (sentinel >> end_bit) != 0) ++end_bit;
     if (total >= (1ull << 32)) { cleanup(); ctx->last_error = "reference has >= 2^32 bases"; return SHK_ERR_INDEX_TOO_LARGE; }
     uint32_t *d_hist = nullptr;
@@ -316,14 +327,14 @@ int build_index(Ctx *ctx)
     if (!sorted) { cleanup(); ctx->last_error = "radix sort launch failed"; return SHK_ERR_HIP; }
 
     BI_HIP(hipMalloc((void **)&d_flags, total * sizeof(uint32_t)));
-    hipLaunchKernelGGL(unique_flags_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, total, sentinel, d_flags);
+    hipLaunchKernelGGL(unique_flags_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, total, sentinel, wrap ? 1 : 0, d_flags);
     BI_HIP(hipGetLastError());
     const uint64_t *d_tot = exclusive_scan_u32(d_flags, d_flags, total, d_scan_tmp, st);
     BI_HIP(hipMemcpyAsync(&tot_idx, d_tot, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     BI_HIP(hipStreamSynchronize(st));
     if (tot_idx >= (1ull << 31)) { cleanup(); ctx->last_error = "index has >= 2^31 list entries (int tot_idx, bloomfilter.h:130)"; return SHK_ERR_INDEX_TOO_LARGE; }
     BI_HIP(hipMalloc((void **)&ix.ids, (tot_idx + 8) * sizeof(uint16_t)));
-    hipLaunchKernelGGL(csr_write_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, (const uint32_t *)d_flags, total, sentinel, d_csr_off, ix.ids);
+    hipLaunchKernelGGL(csr_write_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, sorted, (const uint32_t *)d_flags, total, sentinel, wrap ? 1 : 0, d_csr_off, ix.ids);
     BI_HIP(hipGetLastError());
   } else {
     BI_HIP(hipMalloc((void **)&ix.ids, 8 * sizeof(uint16_t)));

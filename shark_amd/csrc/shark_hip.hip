@@ -270,8 +270,19 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   }
   // the timed launch is the one that does the work: the uniform kernel when the host knows it applies (or has to ask
   // the device: then the generic kernel is launched behind it and returns at once for a uniform batch)
-  if (uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, st))) return rc;
-  if (uni_mode == UNI_NO && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
+  if (ctx->idx.wrap) {
+    // more than 65 536 genes: lists carry multiplicities, which only the general kernel counts (classify.hip, WRAP); it
+    // runs over all reads with the fast kernel's slot capacity and queues what does not fit, as the fast kernel would
+    ClassifyParams p = s.p;
+    unsigned n_waves = 0;
+    if ((rc = size_scratch(ctx, p, s.fast_cap, n, &n_waves))) return rc;
+    p.work = nullptr;
+    p.n_work = n;
+    p.work_count = nullptr;
+    if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
+  }
+  if (!ctx->idx.wrap && uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, st))) return rc;
+  if (!ctx->idx.wrap && uni_mode == UNI_NO && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
   if (uni_mode == UNI_ASK_DEVICE && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
   if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
 

@@ -66,6 +66,7 @@ struct DeviceIndex {
   bool tab_with_summary = false;
   uint64_t n_set = 0;
   uint64_t tot_idx = 0;
+  bool wrap = false;         // more than 65 536 genes: lists sorted by 16-bit id WITH duplicates (index_build.hip), WRAP kernels
 };
 
 // per-wave staging area of a read for a slot capacity S (layout: classify.hip)

@@ -737,3 +737,62 @@ def test_dist_allreduce_one_process_per_gpu_form(oracle):
         assert np.array_equal(h.gene_counts(16), want)
     _compare_classify(o, h, b)                                             # more reads, then reduce again: twice the counts, not four times
     assert np.array_equal(h.dist_gene_counts_allreduce(16), 2 * want)
+
+
+def test_more_than_65536_genes_wrap_like_the_reference(oracle):
+    """small_vector.hpp:46 stores gene ids as uint16_t and bloomfilter.h:72 compares the stored id with the int index: with
+    more than 65 536 genes the ids wrap (gene 65536+x is reported under x's name) and a gene above 65535 is appended once
+    per k-mer occurrence, duplicates included -- which changes (cov, nk) through ReadAnalyzer.hpp:56-62,:79-86.  Well
+    defined in the reference, hence reproduced: index totals, every list as a multiset, and the associations."""
+    rng = np.random.default_rng(65536)
+    n_genes = 70000
+    genes = [synth.random_seq(rng, int(rng.integers(40, 70))) for _ in range(n_genes)]
+    rep = synth.random_seq(rng, 30)
+    genes[65540] = np.concatenate([rep, synth.random_seq(rng, 5), rep, synth.random_seq(rng, 20)])   # k-mers twice inside a wrapped gene
+    genes[65550] = np.concatenate([rep[:25], synth.random_seq(rng, 30)])                             # ... and shared with another one
+    genes[66000] = genes[464].copy()                         # 66000 & 0xFFFF == 464: two genes behind one id
+    genes[69999] = np.concatenate([genes[3][:35], genes[65539][:30]])
+    k = 17
+    o, h, info = _build_both(oracle, genes, k=k, bf_bits=1 << 30)
+    assert info["nidx"] == n_genes
+    assert info["n_set_bits"] == o.num_kmer()
+    off, ids = h.copy_lists()
+    oi = o.index_kmer()
+    assert info["tot_idx"] == len(oi) == len(ids)
+    # same lists as multisets: the oracle keeps insertion order (genes below 65536 ascending, then the wrapped ones in gene
+    # order), the device sorts by id
+    # (list r of the oracle is the r-th run of index_kmer; equal lengths are implied by the multiset comparison below)
+    assert np.array_equal(np.sort(ids), np.sort(oi))
+    starts = off.astype(np.int64)
+    a = np.split(ids, starts[1:-1])
+    b = np.split(oi, starts[1:-1])
+    assert all(np.array_equal(np.sort(x), np.sort(y)) for x, y in zip(a[:20000], b[:20000]))
+    assert all(np.all(np.diff(x.astype(np.int64)) >= 0) for x in a[:20000])
+    assert any(len(x) != len(np.unique(x)) for x in a), "expected duplicate ids in some list"
+    # reads from wrapped genes, from genes below, from the colliding pair, and random ones
+    picks = [65540, 65550, 66000, 464, 69999, 3, 65539, 12, 65536, 65535, 70000 - 1, 1000, 68000]
+    m1, m2 = [], []
+    for g in picks * 40:
+        s_ = genes[g]
+        L = int(rng.integers(20, len(s_) + 1))
+        st = int(rng.integers(0, len(s_) - L + 1))
+        a_ = s_[st:st + L].copy()
+        if rng.random() < 0.2:
+            a_[int(rng.integers(0, L))] = ord("N")
+        m1.append(a_.tobytes())
+        m2.append(synth.revcomp(s_)[:int(rng.integers(17, len(s_) + 1))].tobytes())
+    for _ in range(200):
+        m1.append(synth.random_seq(rng, 60).tobytes())
+        m2.append(synth.random_seq(rng, 60).tobytes())
+    # and a read far beyond the fast kernels' capacity, so that the queue of long reads is exercised in wrap mode too
+    m1.append(np.concatenate([genes[65540], genes[66000], synth.random_seq(rng, 700), genes[69999]]).tobytes())
+    m2.append(synth.revcomp(np.concatenate([genes[65550], genes[464]])).tobytes())
+    batch = synth.batch_from_lists(m1, m2)
+    for c in (0.3, 0.0):
+        o2, h2, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=c)
+        goff, gids = _compare_classify(o2, h2, batch)
+        assert goff[-1] > 300
+        assert h2.timing()["last_n_long"] >= 1
+    # single-end, --single
+    o3, h3, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=0.2, single=True)
+    _compare_classify(o3, h3, synth.batch_from_lists(m1))
