@@ -767,7 +767,7 @@ __global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::M
   __shared__ uint64_t lds[G::SUM_WORDS64 + G::WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (pm_lds(MODE) && P.uni_flag && P.uni_flag[0] == 1u) return;   // a uniform batch: classify_uni_kernel has it
+  if (pm_tab(MODE) && P.uni_flag && P.uni_flag[0] == 1u) return;   // a uniform batch: classify_uni_kernel has it
   const uint32_t *lsum = nullptr;
   if (pm_lds(MODE)) {
     // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
@@ -860,13 +860,26 @@ __device__ __forceinline__ KernargParams kernarg_params()
 #ifndef SHK_UNI_WAVES
 #define SHK_UNI_WAVES 6   // 75 VGPRs, nothing spilled; at 8 waves per SIMD (64 VGPRs) the loop reloads spilled lane constants from scratch and measures 1-6 % slower
 #endif
-template <int U, bool HASQ, bool POW2>
-__global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_uni_kernel(const ClassifyParams P)
+// MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
+// probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
+// only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
+template <int U, int MODE>
+struct UniGeom {
+  // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes are latency bound: 8 waves per SIMD
+  static constexpr int MIN_WAVES = U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : 8);
+  static constexpr uint32_t SUM_WORDS64 = pm_lds(MODE) ? LDS_SUM_BITS / 64 : 0;
+};
+
+template <int U, int MODE, bool HASQ>
+__global__ __launch_bounds__(512, (UniGeom<U, MODE>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
+  constexpr bool POW2 = pm_pow2(MODE);
+  constexpr bool LSUM = pm_lds(MODE);
+  constexpr bool SUM = MODE == PM_TAB_SUM;
   constexpr int WAVES = 8;
   constexpr uint32_t S = 64 * U;
   constexpr uint32_t WORDS = stage_words_for(S);
-  __shared__ uint64_t lds[LDS_SUM_BITS / 64 + WAVES * WORDS];
+  __shared__ uint64_t lds[UniGeom<U, MODE>::SUM_WORDS64 + WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
@@ -877,7 +890,7 @@ __global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_un
   }
   L1 = __builtin_amdgcn_readfirstlane(L1);
   L2 = __builtin_amdgcn_readfirstlane(L2);
-  {
+  if (LSUM) {
     // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -885,7 +898,7 @@ __global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_un
     __syncthreads();
   }
   const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
-  uint64_t *wbase = lds + LDS_SUM_BITS / 64 + wave * WORDS;
+  uint64_t *wbase = lds + UniGeom<U, MODE>::SUM_WORDS64 + wave * WORDS;
   uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
   uint32_t *const rv = fw + code_dwords_for(S);
   uint64_t *const vbits = wbase + code_dwords_for(S);
@@ -985,12 +998,37 @@ __global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_un
         const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
         const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
         const uint64_t hsh = xxh64_u64(canon);
-        pos[j] = POW2 ? hsh : bf_pos_np(hsh, P);            // (power-of-two sizes: every use below masks the bits it needs)
+        // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+        pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
       }
     }
-    uint32_t okm[U];   // all ones where the summary bit is set, else 0
+    uint32_t okm[U];   // all ones where the slot's probe has to be made, else 0
     bool something = false;
-    {
+    if (!LSUM) {
+      // slot pp exists and all its k characters are valid (process_read, slot_ok); then the L2-resident summary
+      const uint64_t kmask0 = (1ull << k) - 1ull;
+      bool ok[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t pp = (uint32_t)lane + 64u * j;
+        const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+        const uint32_t V = pp >> 6, vs = pp & 63u;
+        const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
+        const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+        ok[j] = exists & ((win & kmask0) == kmask0);
+      }
+      if (SUM) {
+        uint32_t sw[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
+#pragma unroll
+        for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
+      }
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < U; ++j) { okm[j] = ok[j] ? 0xFFFFFFFFu : 0u; any |= ok[j]; }
+      something = __ballot(any) != 0ull;
+    } else {
       uint32_t si[U], sw[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
@@ -1019,7 +1057,13 @@ __global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_un
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const uint32_t bb = (uint32_t)pos[j] & bmask;
-        bk[j] = tab16[(bb & okm[j]) | (spare & ~okm[j])];
+        const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
+        if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
+          bk[j] = make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+          bk[j] = tab16[bi];
+        }
       }
       bool lane_any = false, lane_more = false;
       bool more[U];
@@ -1071,7 +1115,7 @@ __global__ __launch_bounds__(512, (U <= 5 ? SHK_UNI_WAVES : 6)) void classify_un
           const uint32_t V = pp >> 6, vs = pp & 63u;
           const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
           const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
-          hit[j] = (m0 | m1) & exists & ((win & kmask) == kmask);
+          hit[j] = LSUM ? ((m0 | m1) & exists & ((win & kmask) == kmask)) : (m0 | m1);   // (table modes settled that before the probe)
           any2 |= hit[j];
           const uint32_t lo = m0 ? bk[j].x : bk[j].z;
           payload[j] = lo & 0x7FFFFFFFu;
@@ -1435,33 +1479,40 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   return SHK_OK;
 }
 
-bool uni_kernel_available(const Ctx *ctx) { return pm_lds(probe_mode(ctx->idx)) && !ctx->idx.wrap; }
+bool uni_kernel_available(const Ctx *ctx) { return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap; }
 
 template <int U>
-static void launch_uni_u(const ClassifyParams &p, bool pow2, bool hasq, unsigned grid, hipStream_t s)
+static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, unsigned grid, hipStream_t s)
 {
-#define LU(HQ_, P2_) hipLaunchKernelGGL((classify_uni_kernel<U, HQ_, P2_>), dim3(grid), dim3(512), 0, s, p)
-  if (pow2) { if (hasq) LU(true, true); else LU(false, true); }
-  else { if (hasq) LU(true, false); else LU(false, false); }
+#define LU(M_) do { if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, M_, true>), dim3(grid), dim3(512), 0, s, p); \
+                    else hipLaunchKernelGGL((classify_uni_kernel<U, M_, false>), dim3(grid), dim3(512), 0, s, p); } while (0)
+  switch (mode) {
+  case PM_LDS_TAB: LU(PM_LDS_TAB); break;
+  case PM_LDS_TAB_MOD: LU(PM_LDS_TAB_MOD); break;
+  case PM_TAB: LU(PM_TAB); break;
+  case PM_TAB_MOD: LU(PM_TAB_MOD); break;
+  default: LU(PM_TAB_SUM); break;
+  }
 #undef LU
 }
 
-// the uniform-length kernel (index in LDS-summary mode only); with p.uni_flag set it decides on the device whether it runs
+// the uniform-length kernel (every index with a position table); with p.uni_flag set it decides on the device whether it runs
 int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
 {
   if (p.n == 0) return SHK_OK;
   const bool hasq = p.hasq != 0;
+  const int mode = probe_mode(ctx->idx);
   const uint32_t u = fast_kernel_unroll(max_slots);
-  const uint64_t cap = (u <= 5 && SHK_UNI_WAVES >= 8) ? 1024 : 768;   // exactly the resident workgroups
+  const int min_waves = u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : 8);
+  const uint64_t cap = 256ull * (uint64_t)(min_waves / 2);   // exactly the resident 512-thread workgroups
   const uint64_t want = (p.n + 7) / 8;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  const bool pow2 = ctx->idx.pow2;
-  if (u == 2) launch_uni_u<2>(p, pow2, hasq, grid, stream);
-  else if (u == 3) launch_uni_u<3>(p, pow2, hasq, grid, stream);
-  else if (u == 4) launch_uni_u<4>(p, pow2, hasq, grid, stream);
-  else if (u == 5) launch_uni_u<5>(p, pow2, hasq, grid, stream);
-  else if (u == 6) launch_uni_u<6>(p, pow2, hasq, grid, stream);
-  else launch_uni_u<8>(p, pow2, hasq, grid, stream);
+  if (u == 2) launch_uni_u<2>(p, mode, hasq, grid, stream);
+  else if (u == 3) launch_uni_u<3>(p, mode, hasq, grid, stream);
+  else if (u == 4) launch_uni_u<4>(p, mode, hasq, grid, stream);
+  else if (u == 5) launch_uni_u<5>(p, mode, hasq, grid, stream);
+  else if (u == 6) launch_uni_u<6>(p, mode, hasq, grid, stream);
+  else launch_uni_u<8>(p, mode, hasq, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }
