@@ -1,15 +1,33 @@
 // shark-fastq-parts -- prints the record-aligned byte ranges the `shark` CLI's parallel readers use (fastq_partition.hpp).
 // Host-only (no GPU): lets the CPU tests check the partition against an independent parse, and shows a user how a
-// sample would be split.   usage: shark-fastq-parts BATCH THREADS file_1.fq [file_2.fq]
+// sample would be split.   usage: shark-fastq-parts BATCH THREADS file_1.fq [file_2.fq]   |   shark-fastq-parts --records file
 // Output: one JSON object: n_records (pairs in the strict part), batches = [[begin1, end1, begin2, end2, records, regular], ...]
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 
 #include "fastq_partition.hpp"
+#include "fastx_reader.hpp"
 
 int main(int argc, char **argv)
 {
+  if (argc == 3 && std::string(argv[1]) == "--records") {
+    // what the serial kseq-rule reader delivers (plain, gzip or BGZF input): record count, bases, FNV-1a of every field
+    shk::FastxReader r(argv[2]);
+    if (!r.ok()) { printf("{\"ok\": false}\n"); return 0; }
+    shk::FastxRecord rec;
+    unsigned long long n = 0, bases = 0, h = 1469598103934665603ull;
+    while (r.read(rec) >= 0) {
+      ++n;
+      bases += rec.seq.size();
+      for (const std::string *f : {&rec.name, &rec.seq, &rec.qual}) {
+        for (char c : *f) h = (h ^ (unsigned char)c) * 1099511628211ull;
+        h = (h ^ 0xFFu) * 1099511628211ull;
+      }
+    }
+    printf("{\"ok\": true, \"records\": %llu, \"bases\": %llu, \"fnv\": \"%llx\", \"bgzf\": %s}\n", n, bases, h, r.parallel_inflate() ? "true" : "false");
+    return 0;
+  }
   if (argc < 4) {
     fprintf(stderr, "usage: %s BATCH THREADS file_1.fq [file_2.fq]\n", argv[0]);
     return 2;

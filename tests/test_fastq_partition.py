@@ -104,3 +104,46 @@ def test_irregular_records_are_noticed_by_the_batch_that_owns_them(tool, tmp_pat
     open(tmp_path / "empty.fq", "wb").close()
     t = parts(tool, 100, 2, tmp_path / "empty.fq")
     assert t["ok"] and t["n_records"] == 0 and t["batches"] == []
+
+
+def test_reader_delivers_the_same_records_from_plain_gzip_and_bgzf(tool, tmp_path):
+    """the serial kseq-rule reader behind a read-ahead thread: plain file, ordinary gzip (inflated ahead of the parser) and
+    BGZF (blocks inflated in parallel) must deliver identical records; a gzip member behind BGZF blocks is read too"""
+    import struct
+    import zlib
+    rng = np.random.default_rng(3)
+    write_fastq(tmp_path / "t.fq", 30000, rng, 1)
+    data = open(tmp_path / "t.fq", "rb").read()
+    with gzip.open(tmp_path / "t.fq.gz", "wb", compresslevel=4) as f:
+        f.write(data)
+
+    def bgzf(payload, path, blk=60000, eof=True):
+        with open(path, "wb") as f:
+            for o in list(range(0, len(payload), blk)) + ([None] if eof else []):
+                chunk = b"" if o is None else payload[o:o + blk]
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                d = c.compress(chunk) + c.flush()
+                f.write(struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, ord("B"), ord("C"), 2, len(d) + 25))
+                f.write(d)
+                f.write(struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    bgzf(data, tmp_path / "t.bgzf.gz")
+    assert gzip.open(tmp_path / "t.bgzf.gz").read() == data                     # a valid gzip file for everybody else
+    bgzf(data, tmp_path / "t.noeof.gz", eof=False)
+    with open(tmp_path / "t.mixed.gz", "wb") as f:
+        f.write(open(tmp_path / "t.noeof.gz", "rb").read())
+        f.write(gzip.compress(b"@tail\nACGT\n+\nIIII\n"))
+
+    def rec(path):
+        return json.loads(subprocess.run([tool, "--records", str(path)], capture_output=True, text=True, check=True).stdout)
+    want = rec(tmp_path / "t.fq")
+    assert want["ok"] and want["records"] == 30000 and not want["bgzf"]
+    for name, is_bgzf in (("t.fq.gz", False), ("t.bgzf.gz", True), ("t.noeof.gz", True)):
+        got = rec(tmp_path / name)
+        assert (got["records"], got["bases"], got["fnv"], got["bgzf"]) == (want["records"], want["bases"], want["fnv"], is_bgzf), name
+    mixed = rec(tmp_path / "t.mixed.gz")
+    assert mixed["records"] == 30001 and mixed["bases"] == want["bases"] + 4
+    # a corrupted block ends the stream instead of delivering garbage
+    raw = bytearray(open(tmp_path / "t.bgzf.gz", "rb").read())
+    raw[len(raw) // 2] ^= 0xFF
+    open(tmp_path / "t.bad.gz", "wb").write(bytes(raw))
+    assert rec(tmp_path / "t.bad.gz")["records"] < 30000
