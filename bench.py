@@ -50,6 +50,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD = 256 * 4            # 256 CUs x 4 SIMD-32
 CLK_GHZ = 2.4               # max clock; a wave64 VALU instruction issues over 2 cycles
 LAUNCH_PAIRS = 10_000_000
+RANDOM_LOOKUP_CEILING_G = 54.6   # G independent 16-B lookups/s in an 8 GiB table, streaming loads (tools/gather_bench on MI355X)
 KERNEL_SOURCES = ["classify.hip", "kmer_device.hpp", "shark_internal.hpp"]
 
 
@@ -198,12 +199,20 @@ def main():
         steps2 = max(2, min(args.steps, 10))
         dt2, tm2, _, n_assoc2, _ = timed(h2, p2, lp, steps2, 1, False)
         k2 = tm2["total_ms"] / max(tm2["n_launches"], 1)
+        w2 = h2.count_work(lp, p2[0]["seq1"], p2[0]["off1"], p2[0]["seq2"], p2[0]["off2"]) if rank == 0 else None
         cfg2 = {"workload": "configs[2] index: 60000 genes (1.78e8 bases, lognormal lengths, every 10th gene shares half of its predecessor), "
                             "%d pairs 2x150 bp per GPU per step, k=17 c=0.6 bf=2^36 bits" % lp,
                 "value": round(2 * lp * world * steps2 / dt2, 1), "unit": "reads/s", "n_gpus": world, "steps": steps2,
                 "ms_per_step": round(dt2 / steps2 * 1e3, 3), "kernel_ms": round(k2, 4), "probe_mode": h2.probe_mode(),
                 "index_build_s": round(t_build2, 3), "n_set_bits": int(info2["n_set_bits"]), "tot_idx": int(info2["tot_idx"]),
                 "assoc_per_step": n_assoc2 // steps2, "tie_reads": int(tm2["last_n_tie"])}
+        if w2:
+            # this index is bound by the RATE of random lookups behind the caches: one 16-byte bucket per valid k-mer (plus list
+            # entries for multi-gene hits); ceiling measured with tools/gather_bench on an 8 GiB table (profiles/r02_gather_ceiling.jsonl)
+            cfg2["roofline"] = {"bound": "random 16-B lookups behind L2 (request rate, not bytes)", "kmers_probed": int(w2["n_kmers"]),
+                                "G_lookups_per_s": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1), "ceiling_G_lookups_per_s": RANDOM_LOOKUP_CEILING_G,
+                                "frac": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9 / RANDOM_LOOKUP_CEILING_G, 3),
+                                "sector_GBps": round(64 * w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1)}
         h2.close()
         del b2
         # the headline context again for the roofline counters / cpu sample below
@@ -250,13 +259,11 @@ def main():
                               "load_width": "input bases are fetched as aligned dwords (4 B per lane, 3 per lane per read), offsets as 8-B loads; "
                                             "the guide calibrates the x2 only for 16 B-per-lane streams, so both figures are given"}
                 iv = e["SQ_INSTS_VALU"]
-                prof_ms = e.get("kernel_ms_profiled", kern_ms)
                 valu = {"insts_per_pair": round(iv / n, 1), "salu_per_pair": round(e.get("SQ_INSTS_SALU", 0) / n, 1),
                         "lds_per_pair": round(e.get("SQ_INSTS_LDS", 0) / n, 1),
                         "cycles_per_valu_inst": round(kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / iv, 2),
                         "frac_of_issue_ceiling": round(iv * 2.0 / (kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD), 4),
-                        "ceiling": "1024 SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction" % CLK_GHZ,
-                        "kernel_ms_profiled": prof_ms}
+                        "ceiling": "1024 SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction" % CLK_GHZ}
         except Exception as ex:   # a broken profile file must not break the bench line
             prof_note = "profiles/pmc_counters.json unreadable: %r" % (ex,)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

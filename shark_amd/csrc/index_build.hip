@@ -356,11 +356,10 @@ int build_index(Ctx *ctx)
     uint32_t lgB = 0;
     while ((1ull << lgB) < ix.bf_bits) ++lgB;
     uint32_t lg = 9;                                        // >= 512 buckets
-    while ((2ull << lg) < 4ull * n_set) ++lg;               // load factor <= 1/4
-    // ... except where half the size makes the table fit an XCD's 4 MiB L2 (gene panels of 100-250 genes): random
-    // lookups run at 266 G/s from L2 against 55-80 G/s behind it (tools/gather_bench), which outweighs the longer probe
-    // paths of a table at load <= 1/2 (about 5 % of the hits and 26 % of the misses look at a second bucket)
-    if (lg > 9 && (16ull << lg) > (4ull << 20) && (16ull << (lg - 1)) <= (4ull << 20) && !getenv("SHK_TABLE_QUARTER")) --lg;
+    // smallest power of two with a load factor <= 0.30: short probe paths (an empty slot ends a search), and panel-sized
+    // indices keep their table inside an XCD's L2 one size longer (60 genes: 4 MiB instead of 8, 23.2 -> 19.9 ms per
+    // 10 M pairs; random lookups run at 266 G/s from L2 against 55-80 G/s behind it, tools/gather_bench)
+    while ((2ull << lg) * 3ull < 10ull * n_set) ++lg;
     if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
     if (lg < lgB && lg <= 31) {                             // (bucket indices are 32-bit in the kernel)
       const uint64_t slots = 2ull << lg;
