@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <cctype>
 #include <chrono>
 #include <cstdint>
@@ -138,12 +139,48 @@ inline void parallel_for(unsigned n_threads, size_t n, F f)
   });
 }
 
-// allocator that leaves chars uninitialised on resize (every byte is overwritten)
+// Large host buffers on transparent huge pages.  The readers' buffers are written once per batch by many threads at
+// once; with 4 KiB pages every first touch is a page fault that takes the process's address-space lock, which is what made
+// 32-128 reader threads slower than 16 (profiles/README.md).  Blocks of 2 MiB and more come from mmap + MADV_HUGEPAGE
+// (512 times fewer faults where the kernel grants huge pages; ordinary pages otherwise), smaller ones from malloc.
+inline void *big_alloc(size_t bytes)
+{
+  constexpr size_t HUGE = 2u << 20;
+  if (bytes < HUGE) return malloc(bytes ? bytes : 1);
+  const size_t len = (bytes + HUGE - 1) & ~(HUGE - 1);
+  void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) return nullptr;
+#ifdef MADV_HUGEPAGE
+  (void)madvise(p, len, MADV_HUGEPAGE);
+#endif
+  return p;
+}
+inline void big_free(void *p, size_t bytes)
+{
+  constexpr size_t HUGE = 2u << 20;
+  if (!p) return;
+  if (bytes < HUGE) free(p);
+  else munmap(p, (bytes + HUGE - 1) & ~(HUGE - 1));
+}
+
+// allocator that leaves chars uninitialised on resize (every byte is overwritten) and puts large blocks on huge pages
 template <typename T>
-struct NoInitAlloc : std::allocator<T> {
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
   template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+  T *allocate(size_t n)
+  {
+    void *p = big_alloc(n * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t n) { big_free(p, n * sizeof(T)); }
   template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
   template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+  template <typename U> bool operator==(const NoInitAlloc<U> &) const { return true; }
+  template <typename U> bool operator!=(const NoInitAlloc<U> &) const { return false; }
 };
 
 // a view of the next `n` strict records of one file

@@ -194,17 +194,10 @@ class Progress {
 const Progress pelapsed;
 
 // ---- one batch of reads, structure of arrays ---------------------------------
-// allocator that leaves chars uninitialised on resize (the parallel filler overwrites every byte)
+// allocator that leaves chars uninitialised on resize (the fillers overwrite every byte); large blocks on huge pages
 template <typename T>
-struct default_init_allocator : std::allocator<T> {
-  template <typename U> struct rebind { using other = default_init_allocator<U>; };
-  template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
-  template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
-};
+using default_init_allocator = shk::NoInitAlloc<T>;
 
-// the same, in page-locked host memory (shk_alloc_pinned): what the GPU reads -- sequences, qualities, offsets -- is
-// copied by the DMA engine straight from here, which is what lets shk_classify_submit return before the copy is done.
-// Batches are recycled, so these allocations happen once per pipeline slot.  Falls back to malloc when pinning fails.
 // Page-locking costs about as much per byte as parsing does (measured: 21 batches of 160 MB took 12 thread-seconds to
 // pin), and the copies from ordinary memory run at 300 M reads/s -- several times what the parsers deliver -- so batches
 // are pinned only for samples large enough to pay that back (or when SHARK_PINNED=1 / 0 says so).
@@ -222,15 +215,15 @@ struct pinned_allocator {
     const size_t bytes = n * sizeof(T) + 64;
     char *raw = g_pin_batches.load(std::memory_order_relaxed) ? static_cast<char *>(shk_alloc_pinned(bytes)) : nullptr;
     bool pinned = raw != nullptr;
-    if (!raw) raw = static_cast<char *>(malloc(bytes));
+    if (!raw) raw = static_cast<char *>(shk::big_alloc(bytes));
     if (!raw) throw std::bad_alloc();
     *reinterpret_cast<uint64_t *>(raw) = pinned ? 1 : 0;
     return reinterpret_cast<T *>(raw + 64);
   }
-  void deallocate(T *p, size_t)
+  void deallocate(T *p, size_t n)
   {
     char *raw = reinterpret_cast<char *>(p) - 64;
-    if (*reinterpret_cast<uint64_t *>(raw)) shk_free_pinned(raw); else free(raw);
+    if (*reinterpret_cast<uint64_t *>(raw)) shk_free_pinned(raw); else shk::big_free(raw, n * sizeof(T) + 64);
   }
   template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
   template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
