@@ -33,53 +33,23 @@ __host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r)
 #endif
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SHK_XXH_MAD)
-// 64 x 64 -> 64 multiply by a constant as three v_mad_u64_u32 and one add.  hipcc's own lowering is one v_mad_u64_u32
-// (lo x lo) plus two v_mul_lo_u32 for the cross terms plus a v_add3; v_mul_lo_u32 is the slowest of them (tools/alu_bench:
-// 2.6 ns per wave-instruction per SIMD against 2.07 for v_mad_u64_u32), and only the LOW word of a cross product is needed,
-// which v_mad_u64_u32 delivers as well -- with the other cross product already added in.
-__device__ __forceinline__ uint64_t mad_u64_u32_c0(uint32_t a, uint32_t b)
-{
-  uint64_t d;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b) : "vcc");
-  return d;
-}
-__device__ __forceinline__ uint64_t mad_u64_u32(uint32_t a, uint32_t b, uint64_t c)
-{
-  uint64_t d;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
-  return d;
-}
-__device__ __forceinline__ uint64_t mul64_const(uint64_t a, uint64_t c)
-{
-  const uint32_t a_lo = (uint32_t)a, a_hi = (uint32_t)(a >> 32), c_lo = (uint32_t)c, c_hi = (uint32_t)(c >> 32);
-  const uint64_t x = mad_u64_u32_c0(a_lo, c_lo);          // full lo x lo
-  const uint64_t u = mad_u64_u32_c0(a_hi, c_lo);          // low word: a_hi * c_lo
-  const uint64_t w = mad_u64_u32(a_lo, c_hi, u);          // low word: a_lo * c_hi + a_hi * c_lo
-  return ((uint64_t)((uint32_t)(x >> 32) + (uint32_t)w) << 32) | (uint32_t)x;
-}
-#define SHK_MUL64(a_, c_) mul64_const((a_), (c_))
-#else
-#define SHK_MUL64(a_, c_) ((a_) * (c_))
-#endif
-
 __host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t v)
 {
   uint64_t h = XP5 + 8ull;          // seed(0) + PRIME5 + len
-  uint64_t k1 = SHK_MUL64(v, XP2);  // round(0, v)
+  uint64_t k1 = v * XP2;            // round(0, v)
 #if defined(__HIP_DEVICE_COMPILE__)
   // keep the product as a value: hipcc otherwise rewrites rotl(v*P2, 31) as two more multiplies by
   // shifted constants (17 multiply instructions per hash instead of 15)
   asm("" : "+v"(k1));
 #endif
   k1 = rotl64(k1, 31);
-  k1 = SHK_MUL64(k1, XP1);
+  k1 *= XP1;
   h ^= k1;
-  h = SHK_MUL64(rotl64(h, 27), XP1) + XP4;
+  h = rotl64(h, 27) * XP1 + XP4;
   h ^= h >> 33;
-  h = SHK_MUL64(h, XP2);
+  h *= XP2;
   h ^= h >> 29;
-  h = SHK_MUL64(h, XP3);
+  h *= XP3;
   h ^= h >> 32;
   return h;
 }
