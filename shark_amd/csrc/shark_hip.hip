@@ -31,6 +31,39 @@ static void free_index(DeviceIndex &ix)
   ix = DeviceIndex{};
 }
 
+// ---- tracing hook: roctx ranges around the library's phases, so that a rocprofv3 --marker-trace /
+// --sys-trace timeline shows index build, submit and wait next to the kernels.  Off unless SHK_ROCTX=1; libroctx64 is
+// loaded on first use, nothing is linked.
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+};
+Roctx &roctx()
+{
+  static Roctx r;
+  if (!r.tried) {
+    r.tried = true;
+    const char *e = getenv("SHK_ROCTX");
+    if (e && e[0] == '1') {
+      void *lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_LOCAL);
+      if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+      if (lib) {
+        r.push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+        r.pop = (int (*)())dlsym(lib, "roctxRangePop");
+      }
+    }
+  }
+  return r;
+}
+}  // namespace
+struct TraceRange {
+  explicit TraceRange(const char *name) { if (roctx().push) { (void)roctx().push(name); on = true; } }
+  ~TraceRange() { if (on && roctx().pop) (void)roctx().pop(); }
+  bool on = false;
+};
+
 // slot positions of a read (pair) whose mates are `len` long: classify.hip packs mate 2 at the next
 // multiple of 8 after mate 1 and uses packed positions as k-mer slots
 static uint32_t slots_for_len(uint32_t len, uint32_t k, bool paired)
@@ -539,6 +572,7 @@ int shk_ref_finalize(shk_ctx *ctx)
   if (!ctx) return SHK_ERR_ARG;
   if (ctx->mode != 0) return SHK_ERR_STATE;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  TraceRange tr("shk_ref_finalize: index build");
   const int rc = build_index(ctx);
   if (rc != SHK_OK) return rc;
   ctx->mode = 2;
@@ -608,6 +642,7 @@ int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_
   int rc = check_batch(ctx, batch);
   if (rc) return rc;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  TraceRange tr("shk_classify_device");
   return classify_resident(ctx, batch, max_read_len, result);
 }
 
@@ -623,6 +658,7 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   int rc = check_batch(ctx, b);
   if (rc) return rc;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  TraceRange tr("shk_classify_submit");
   Slot &s = ctx->slots[(ctx->next_ticket - 1) % PIPE_DEPTH];
   if (s.ticket != 0 && !s.waited) {
     ctx->last_error = "pipeline full: shk_classify_wait the oldest ticket before submitting another batch";
@@ -716,6 +752,7 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
 {
   if (!ctx || !result || ticket == 0) return SHK_ERR_ARG;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  TraceRange tr("shk_classify_wait");
   Slot &s = ctx->slots[(ticket - 1) % PIPE_DEPTH];
   if (s.ticket != ticket || s.waited) { ctx->last_error = "unknown or already waited ticket"; return SHK_ERR_STATE; }
   SHK_HIP(ctx, hipEventSynchronize(s.ev_done));
