@@ -863,23 +863,31 @@ __device__ __forceinline__ KernargParams kernarg_params()
 // MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
 // probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
 // only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
-template <int U, int MODE>
+// LSL: log2 of the LDS summary's bits.  18 = 32 KiB, several 512-thread workgroups per CU (the sparse indices of a few
+// genes); 20 = 128 KiB shared by ONE 1024-thread workgroup per CU -- four times the reach (pass rate <= 30 % up to ~3x10^5
+// set bits, i.e. panels of a hundred genes) at 4 waves per SIMD, for indices that would otherwise probe an L2-resident
+// summary through the vector L1 (one cache line per clock per CU) for every k-mer.
+template <int U, int MODE, int LSL>
 struct UniGeom {
+  static constexpr int WAVES = (pm_lds(MODE) && LSL == 20) ? 16 : 8;
+  static constexpr int THREADS = WAVES * 64;
   // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes are latency bound: 8 waves per SIMD
-  static constexpr int MIN_WAVES = U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : 8);
-  static constexpr uint32_t SUM_WORDS64 = pm_lds(MODE) ? LDS_SUM_BITS / 64 : 0;
+  static constexpr int MIN_WAVES = WAVES == 16 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : 8));
+  static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (1u << LSL) : 0u;
+  static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };
 
-template <int U, int MODE, bool HASQ>
-__global__ __launch_bounds__(512, (UniGeom<U, MODE>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
+template <int U, int MODE, bool HASQ, int LSL>
+__global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
-  constexpr int WAVES = 8;
+  using UG = UniGeom<U, MODE, LSL>;
+  constexpr int WAVES = UG::WAVES;
   constexpr uint32_t S = 64 * U;
   constexpr uint32_t WORDS = stage_words_for(S);
-  __shared__ uint64_t lds[UniGeom<U, MODE>::SUM_WORDS64 + WAVES * WORDS];
+  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
@@ -891,14 +899,14 @@ __global__ __launch_bounds__(512, (UniGeom<U, MODE>::MIN_WAVES)) void classify_u
   L1 = __builtin_amdgcn_readfirstlane(L1);
   L2 = __builtin_amdgcn_readfirstlane(L2);
   if (LSUM) {
-    // stage the summary: 32 KiB, 16 bytes per thread per pass, once per (persistent) workgroup
+    // stage the summary: 16 bytes per thread per pass, once per (persistent) workgroup
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t i = threadIdx.x; i < LDS_SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
     __syncthreads();
   }
   const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
-  uint64_t *wbase = lds + UniGeom<U, MODE>::SUM_WORDS64 + wave * WORDS;
+  uint64_t *wbase = lds + UG::SUM_WORDS64 + wave * WORDS;
   uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
   uint32_t *const rv = fw + code_dwords_for(S);
   uint64_t *const vbits = wbase + code_dwords_for(S);
@@ -1032,8 +1040,8 @@ __global__ __launch_bounds__(512, (UniGeom<U, MODE>::MIN_WAVES)) void classify_u
       uint32_t si[U], sw[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low 18 bits = summary index
-        sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (LDS_SUM_BITS / 8 - 4)));
+        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
+        sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
       }
       uint32_t any = 0;
 #pragma unroll
@@ -1482,37 +1490,47 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
 bool uni_kernel_available(const Ctx *ctx) { return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap; }
 
 template <int U>
-static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, unsigned grid, hipStream_t s)
+static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, unsigned grid, hipStream_t s)
 {
-#define LU(M_) do { if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, M_, true>), dim3(grid), dim3(512), 0, s, p); \
-                    else hipLaunchKernelGGL((classify_uni_kernel<U, M_, false>), dim3(grid), dim3(512), 0, s, p); } while (0)
+#define LU(M_, L_) do { if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, M_, true, L_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p); \
+                        else hipLaunchKernelGGL((classify_uni_kernel<U, M_, false, L_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p); } while (0)
   switch (mode) {
-  case PM_LDS_TAB: LU(PM_LDS_TAB); break;
-  case PM_LDS_TAB_MOD: LU(PM_LDS_TAB_MOD); break;
-  case PM_TAB: LU(PM_TAB); break;
-  case PM_TAB_MOD: LU(PM_TAB_MOD); break;
-  default: LU(PM_TAB_SUM); break;
+  case PM_LDS_TAB: if (big) LU(PM_LDS_TAB, 20); else LU(PM_LDS_TAB, 18); break;
+  case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
+  case PM_TAB: LU(PM_TAB, 18); break;
+  case PM_TAB_MOD: LU(PM_TAB_MOD, 18); break;
+  default: LU(PM_TAB_SUM, 18); break;
   }
 #undef LU
 }
 
 // the uniform-length kernel (every index with a position table); with p.uni_flag set it decides on the device whether it runs
-int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream)
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots, hipStream_t stream)
 {
-  if (p.n == 0) return SHK_OK;
+  if (p_in.n == 0) return SHK_OK;
+  ClassifyParams p = p_in;
   const bool hasq = p.hasq != 0;
-  const int mode = probe_mode(ctx->idx);
+  int mode = probe_mode(ctx->idx);
   const uint32_t u = fast_kernel_unroll(max_slots);
-  const int min_waves = u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : 8);
-  const uint64_t cap = 256ull * (uint64_t)(min_waves / 2);   // exactly the resident 512-thread workgroups
-  const uint64_t want = (p.n + 7) / 8;
+  // indices too dense for the 32 KiB LDS summary may still have the 128 KiB one (index_build.hip): uniform batches then
+  // run in LDS-summary mode with it, whatever chain ragged batches use on this index
+  const bool big = !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
+  if (big) {
+    mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
+    p.lsum32 = ctx->idx.lbig32;
+    p.lsum_shift = ctx->idx.lbig_shift;
+  }
+  const int min_waves = big ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : 8));
+  const uint64_t wpb = big ? 16 : 8;
+  const uint64_t cap = big ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
+  const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  if (u == 2) launch_uni_u<2>(p, mode, hasq, grid, stream);
-  else if (u == 3) launch_uni_u<3>(p, mode, hasq, grid, stream);
-  else if (u == 4) launch_uni_u<4>(p, mode, hasq, grid, stream);
-  else if (u == 5) launch_uni_u<5>(p, mode, hasq, grid, stream);
-  else if (u == 6) launch_uni_u<6>(p, mode, hasq, grid, stream);
-  else launch_uni_u<8>(p, mode, hasq, grid, stream);
+  if (u == 2) launch_uni_u<2>(p, mode, hasq, big, grid, stream);
+  else if (u == 3) launch_uni_u<3>(p, mode, hasq, big, grid, stream);
+  else if (u == 4) launch_uni_u<4>(p, mode, hasq, big, grid, stream);
+  else if (u == 5) launch_uni_u<5>(p, mode, hasq, big, grid, stream);
+  else if (u == 6) launch_uni_u<6>(p, mode, hasq, false, grid, stream);
+  else launch_uni_u<8>(p, mode, hasq, false, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }

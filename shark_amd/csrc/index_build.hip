@@ -393,6 +393,20 @@ int build_index(Ctx *ctx)
             ix.lsum_shift = sh;
           }
         }
+        // too dense for 2^18 bits: a 2^20-bit summary for the uniform-length kernel (128 KiB of LDS, classify.hip LSL = 20)
+        ix.lbig_shift = 0;
+        if (!ix.lsum_shift && lgB > 20 && !getenv("SHK_NO_LDS_SUMMARY") && !getenv("SHK_NO_BIG_LDS_SUMMARY")) {
+          const uint32_t sh = lgB - 20;
+          const double pass = 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits);
+          if (sh >= 6 && sh < 32 && pass <= 0.30) {
+            BI_HIP(hipMalloc((void **)&ix.lbig32, ((1u << 20) / 32 + 2) * sizeof(uint32_t)));
+            BI_HIP(hipMemsetAsync(ix.lbig32, 0, ((1u << 20) / 32 + 2) * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(bf_summary_kernel, dim3(grid_for(n_words, 256)), dim3(256), 0, st, (const uint64_t *)ix.bf64, n_words, sh, ix.lbig32);
+            BI_HIP(hipGetLastError());
+            BI_HIP(hipStreamSynchronize(st));
+            ix.lbig_shift = sh;
+          }
+        }
         table_bytes = slots * sizeof(uint64_t);
       } else {
         (void)hipFree(ix.tab);   // displacement overflow: keep the bit-vector path

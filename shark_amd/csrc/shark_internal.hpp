@@ -61,6 +61,8 @@ struct DeviceIndex {
   uint64_t sum_bits = 0;
   uint32_t *lsum32 = nullptr; // 2^18-bit summary staged into LDS by the table kernel (small indices only)
   uint32_t lsum_shift = 0;    // 0 = not used
+  uint32_t *lbig32 = nullptr; // 2^20-bit summary (128 KiB of LDS, one 1024-thread workgroup per CU): classify_uni_kernel on
+  uint32_t lbig_shift = 0;    //   indices too dense for the 2^18-bit one; 0 = not built
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
   bool tab_with_summary = false;

@@ -796,3 +796,24 @@ def test_more_than_65536_genes_wrap_like_the_reference(oracle):
     # single-end, --single
     o3, h3, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=0.2, single=True)
     _compare_classify(o3, h3, synth.batch_from_lists(m1))
+
+
+@pytest.mark.parametrize("bf_bits", [1 << 30, 5 << 32])
+def test_panel_sized_index_uses_the_big_lds_summary(oracle, bf_bits, monkeypatch):
+    """~2.4e5 set bits: too dense for the 2^18-bit LDS summary, sparse enough for the 2^20-bit one (classify_uni_kernel with a
+    1024-thread workgroup per CU).  Uniform batches take it, ragged ones the index's ordinary chain; both must equal the oracle,
+    and so must the same index without it."""
+    rng = np.random.default_rng(2020)
+    genes = synth.make_genes(rng, 100, 2000, 3000, share_every=5)
+    o, h, info = _build_both(oracle, genes, k=17, bf_bits=bf_bits)
+    assert 150_000 < info["n_set_bits"] < 330_000 and "lds" not in h.probe_mode()
+    uni = synth.make_reads(rng, genes, 3000, read_len=150, paired=True, on_target=0.6)
+    rag = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.6, var_len=True)
+    se = synth.make_reads(rng, genes, 1500, read_len=100, paired=False, on_target=0.6)
+    want = [_compare_classify(o, h, b) for b in (uni, rag, se)]
+    monkeypatch.setenv("SHK_NO_BIG_LDS_SUMMARY", "1")
+    h2 = _hip(k=17, bf_bits=bf_bits)
+    h2.build([bytes(g) for g in genes])
+    for b, (wg, wi) in zip((uni, rag, se), want):
+        g2, i2 = h2.classify(b["seq1"], b["off1"], b["seq2"], b["off2"])
+        assert np.array_equal(g2, wg) and np.array_equal(i2, wi)
