@@ -395,7 +395,9 @@ int build_index(Ctx *ctx)
         }
         // too dense for 2^18 bits: a 2^20-bit summary for the uniform-length kernel (128 KiB of LDS, classify.hip LSL = 20)
         ix.lbig_shift = 0;
-        if (!ix.lsum_shift && lgB > 20 && !getenv("SHK_NO_LDS_SUMMARY") && !getenv("SHK_NO_BIG_LDS_SUMMARY")) {
+        // (only where the table has outgrown an XCD's L2: 100 genes 24.4 -> 20.2 ms, 150 genes 26.3 -> 24.5 ms per 10 M pairs;
+        //  with a 4 MiB table probing it directly is as fast, 60 genes 19.7 ms)
+        if (!ix.lsum_shift && lgB > 20 && slots * sizeof(uint64_t) > (4ull << 20) && !getenv("SHK_NO_LDS_SUMMARY") && !getenv("SHK_NO_BIG_LDS_SUMMARY")) {
           const uint32_t sh = lgB - 20;
           const double pass = 1.0 - std::exp(-(double)n_set * (double)(1ull << sh) / (double)ix.bf_bits);
           if (sh >= 6 && sh < 32 && pass <= 0.30) {
