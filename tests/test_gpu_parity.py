@@ -817,3 +817,69 @@ def test_panel_sized_index_uses_the_big_lds_summary(oracle, bf_bits, monkeypatch
     for b, (wg, wi) in zip((uni, rag, se), want):
         g2, i2 = h2.classify(b["seq1"], b["off1"], b["seq2"], b["off2"])
         assert np.array_equal(g2, wg) and np.array_equal(i2, wi)
+
+
+@pytest.mark.parametrize("shape", ["fixed_width", "ragged", "second_file_shorter", "first_file_shorter_no_final_newline", "bgzf", "single_end_gz"])
+def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
+    """every way the CLI gets its reads -- arithmetic offsets of fixed-width records, the parallel newline count, the pair
+    stream ending with the shorter mate file, a last record without newline (serial reader takes over), BGZF blocks inflated
+    in parallel, gzip inflated ahead of the parser -- with several GPUs' worth of queues, thread counts and batch sizes:
+    ssv and both FASTQ outputs byte for byte the oracle CLI's"""
+    import gzip
+    import struct
+    import subprocess
+    import zlib
+    rng = np.random.default_rng(len(shape))
+    genes = synth.make_genes(rng, 6, 500, 1500, share_every=3)
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">g%d\n%s\n" % (i, bytes(g).decode()) for i, g in enumerate(genes)))
+    n = 2300
+
+    def fastq(tag, count, fixed):
+        out = []
+        for i in range(count):
+            g = genes[i % 6]
+            L = 100 if fixed else int(rng.integers(40, 120))
+            st = int(rng.integers(0, len(g) - L))
+            s_ = bytes(g[st:st + L]) if i % 4 else bytes(synth.random_seq(rng, L))
+            q = bytes(rng.integers(35, 74, size=L).astype(np.uint8))
+            rid = (b"r%06d/%d" % (i, tag)) if fixed else (b"read%d/%d some text" % (i, tag))
+            out.append(b"@" + rid + b"\n" + s_ + b"\n+\n" + q + b"\n")
+        return b"".join(out)
+
+    fixed = shape == "fixed_width"
+    t1, t2 = fastq(1, n, fixed), fastq(2, n - 700 if shape == "second_file_shorter" else n, fixed)
+    if shape == "first_file_shorter_no_final_newline":
+        t1 = fastq(1, n - 450, False)[:-1]
+    f1, f2 = tmp_path / "a_1.fq", tmp_path / "a_2.fq"
+    f1.write_bytes(t1)
+    f2.write_bytes(t2)
+    paired = shape != "single_end_gz"
+    if shape == "bgzf":
+        for f, data in ((f1, t1), (f2, t2)):
+            with open(str(f) + ".gz", "wb") as fh:
+                for o_ in list(range(0, len(data), 50000)) + [None]:
+                    chunk = b"" if o_ is None else data[o_:o_ + 50000]
+                    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                    d = c.compress(chunk) + c.flush()
+                    fh.write(struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, ord("B"), ord("C"), 2, len(d) + 25))
+                    fh.write(d)
+                    fh.write(struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        f1, f2 = tmp_path / "a_1.fq.gz", tmp_path / "a_2.fq.gz"
+    if shape == "single_end_gz":
+        with gzip.open(str(f1) + ".gz", "wb") as fh:
+            fh.write(t1)
+        f1 = tmp_path / "a_1.fq.gz"
+    args = ["-r", str(fa), "-1", str(f1), "-k", "15", "-q", "10"] + (["-2", str(f2)] if paired else [])
+    ossv = tmp_path / "o.ssv"
+    oracle.run_cli(args + ["-o", str(tmp_path / "o1.fq")] + (["-p", str(tmp_path / "o2.fq")] if paired else []), str(ossv))
+    assert ossv.read_bytes().count(b"\n") > 500
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
+    for extra in (["--batch", "97", "-t", "5"], ["--batch", "1000", "-t", "3"], []):
+        r = subprocess.run([exe] + args + ["-o", str(tmp_path / "h1.fq")] + (["-p", str(tmp_path / "h2.fq")] if paired else []) + extra,
+                           capture_output=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        assert r.stdout == ossv.read_bytes(), (shape, extra)
+        assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
+        if paired:
+            assert (tmp_path / "h2.fq").read_bytes() == (tmp_path / "o2.fq").read_bytes()
