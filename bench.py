@@ -30,7 +30,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying
                  only used when it was taken on the same kernel sources
   cpu_baseline   the CPU oracle (a port of the reference path) on this host
   configs        the same measurement on BASELINE configs[2]'s index
-                 (60 000 genes, 2^36-bit filter), 10 M-pair steps
+                 (60 000 genes, 2^36-bit filter) and on configs[4]'s shape
+                 (k=31, -q 20, --single, 2^37 bits), 10 M-pair steps
   batch_boundary PCIe-inclusive rate of the host-buffer entry points (never
                  `value`)
 """
@@ -183,7 +184,7 @@ def main():
     value = reads_per_step * args.steps / dt
 
     # ---- BASELINE configs[2] index (60 000 genes, 2^36 bits): every rank, 10 M-pair steps -----
-    cfg2 = None
+    cfg2 = cfg4 = None
     if not args.no_configs:
         h.close()
         for b in batches[1:]:
@@ -215,6 +216,23 @@ def main():
                                 "sector_GBps": round(64 * w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1)}
         h2.close()
         del b2
+        # BASELINE configs[4] shape on this GPU's shard: k=31, -q 20, --single, 2^37-bit filter (the quality-mask path at max k)
+        t0 = time.time()
+        h4 = SharkHip(k=31, c=0.6, bf_bits=1 << 37, min_quality=20, single=True, device=local_rank)
+        info4 = h4.build([g.tobytes() for g in g2])
+        t_build4 = time.time() - t0
+        b4 = synth.make_pairs_device(lp, g2, dev, seed=synth.SEED + 7 + rank, read_len=L, on_target=0.5, with_qual=True)
+        torch.cuda.synchronize()
+        p4 = [{kk: (v.data_ptr() if v is not None else 0) for kk, v in b4.items()}]
+        dt4, tm4, _, n_assoc4, _ = timed(h4, p4, lp, steps2, 1, False)
+        k4 = tm4["total_ms"] / max(tm4["n_launches"], 1)
+        cfg4 = {"workload": "configs[4] shape: the same 60000 genes, %d pairs 2x150 bp with qualities (90 %% >= Q30) per GPU per step, "
+                            "k=31 c=0.6 -q 20 --single bf=2^37 bits" % lp,
+                "value": round(2 * lp * world * steps2 / dt4, 1), "unit": "reads/s", "n_gpus": world, "steps": steps2,
+                "ms_per_step": round(dt4 / steps2 * 1e3, 3), "kernel_ms": round(k4, 4), "probe_mode": h4.probe_mode(),
+                "index_build_s": round(t_build4, 3), "n_set_bits": int(info4["n_set_bits"]), "assoc_per_step": n_assoc4 // steps2}
+        h4.close()
+        del b4
         # the headline context again for the roofline counters / cpu sample below
         h = SharkHip(k=k, c=c, bf_bits=bf_bits, device=local_rank)
         h.build([g.tobytes() for g in genes])
@@ -375,7 +393,7 @@ def main():
                    "long_reads": int(tm["last_n_long"]), "tie_reads": int(tm["last_n_tie"]), "probe_mode": h.probe_mode()},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "configs": [cfg2] if cfg2 else [],
+        "configs": [cfg2, cfg4] if cfg2 else [],
         "batch_boundary": boundary,
     }
     print(json.dumps(out), flush=True)

@@ -108,13 +108,16 @@ int main()
     CK(hipFree(tab));
   }
   // a table that fits the Infinity Cache / the L2s
-  for (uint64_t mib : {128ull, 16ull, 2ull}) {
+  for (uint64_t mib : {128ull, 16ull, 8ull, 4ull, 2ull, 1ull}) {
     const uint64_t bytes = mib << 20;
     uint8_t *tab;
     CK(hipMalloc((void **)&tab, bytes));
     CK(hipMemset(tab, 1, bytes));
     run<5, 0, 16>(tab, bytes, 8, out, "plain");
     run<10, 0, 16>(tab, bytes, 8, out, "plain");
+    run<5, 0, 8>(tab, bytes, 8, out, "plain");
+    run<5, 0, 4>(tab, bytes, 8, out, "plain");
+    run<10, 0, 4>(tab, bytes, 6, out, "plain");
     CK(hipFree(tab));
   }
   return 0;
