@@ -359,6 +359,8 @@ int build_index(Ctx *ctx)
     // smallest power of two with a load factor <= 0.30: short probe paths (an empty slot ends a search), and panel-sized
     // indices keep their table inside an XCD's L2 one size longer (60 genes: 4 MiB instead of 8, 23.2 -> 19.9 ms per
     // 10 M pairs; random lookups run at 266 G/s from L2 against 55-80 G/s behind it, tools/gather_bench)
+    // (denser is worse even where it would bring the table back into L2: at load 0.46-0.6 the probe paths behind full home
+    //  buckets diverge, 100 genes 19.4 -> 25-34 ms, 130 genes 22.7 -> 31-51 ms)
     while ((2ull << lg) * 3ull < 10ull * n_set) ++lg;
     if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
     if (lg < lgB && lg <= 31) {                             // (bucket indices are 32-bit in the kernel)
