@@ -36,6 +36,8 @@
 // what bounds the kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kmer_device.hpp"
 #include "shark_internal.hpp"
 
@@ -877,7 +879,11 @@ struct UniGeom {
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };
 
-template <int U, int MODE, bool HASQ, int LSL>
+// UNI = false: the same kernel for batches of mixed read lengths (trimmed reads).  The geometry is then per read --
+// offsets prefetched two reads ahead, bases one read ahead, as classify_fast_kernel does it -- but the structure is this
+// kernel's: straight-line miss path, the hit path behind one branch with its own parameter loads, count[] pre-zeroed.  A
+// read with more than 64 U slots or more than 64 staging groups goes to the general kernel's queue.
+template <int U, int MODE, bool HASQ, int LSL, bool UNI>
 __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
   constexpr bool POW2 = pm_pow2(MODE);
@@ -892,7 +898,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
   if (P.uni_flag) {
-    if (P.uni_flag[0] != 1u) return;   // not a uniform batch (or it does not fit): classify_fast_kernel handles it
+    // both launches are made when only the device knows whether the batch is uniform: exactly one of them works
+    if ((P.uni_flag[0] == 1u) != UNI) return;
     L1 = P.uni_flag[1];
     L2 = P.uni_flag[2];
   }
@@ -912,28 +919,35 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   uint64_t *const vbits = wbase + code_dwords_for(S);
   constexpr uint32_t rcap = stage_cap_bases(S);
 
-  // ---- geometry of every read of the batch ------------------------------------
+  // ---- geometry: of every read of the batch (UNI) or of the current read ----------
   const uint32_t k = P.k;
-  const uint32_t nk1 = L1 >= k ? L1 - k + 1 : 0;
-  const uint32_t nk2 = L2 >= k ? L2 - k + 1 : 0;
-  const uint32_t P2 = (L1 + 7u) & ~7u;
-  const uint32_t g2 = P2 >> 3;
-  const uint32_t n_groups = g2 + ((L2 + 7u) >> 3);     // <= 64 (checked before this kernel is chosen)
-  // lane -> the 8 bases it stages
-  const bool act = (uint32_t)lane < n_groups;
-  const bool m2 = (uint32_t)lane >= g2;
-  const uint32_t b = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
-  const uint32_t Lm = m2 ? L2 : L1;
-  const uint32_t rem = act ? Lm - b : 8u;
-  const uint32_t nbytes = rem < 8u ? rem : 8u;
-  const uint32_t tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
-  const uint8_t *const sbase = (m2 ? P.seq2 : P.seq1) + b;
-  const uint8_t *const qbase = HASQ ? (m2 ? P.qual2 : P.qual1) + b : nullptr;
+  uint32_t nk1, nk2, P2, g2, n_groups, tail_inv, Lm, rem, nbytes;
+  bool act, m2;
+  auto set_geometry = [&](const uint32_t l1, const uint32_t l2) {
+    nk1 = l1 >= k ? l1 - k + 1 : 0;
+    nk2 = l2 >= k ? l2 - k + 1 : 0;
+    P2 = (l1 + 7u) & ~7u;
+    g2 = P2 >> 3;
+    n_groups = g2 + ((l2 + 7u) >> 3);                 // <= 64 (UNI: checked before this kernel is chosen; else: per read below)
+    // lane -> the 8 bases it stages
+    act = (uint32_t)lane < n_groups;
+    m2 = (uint32_t)lane >= g2;
+    const uint32_t b = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
+    Lm = m2 ? l2 : l1;
+    rem = act ? Lm - b : 8u;
+    nbytes = rem < 8u ? rem : 8u;
+    tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
+  };
+  set_geometry(L1, L2);
+  const uint32_t b_uni = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
+  const uint8_t *const sbase = (m2 ? P.seq2 : P.seq1) + b_uni;
+  const uint8_t *const qbase = HASQ ? (m2 ? P.qual2 : P.qual1) + b_uni : nullptr;
   // the unguarded loads read up to 11 bytes behind a group's first byte: fine while that stays inside the mate's buffer
   const uint32_t n32 = (uint32_t)P.n, stride = gridDim.x * WAVES;
   const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
   const uint32_t guard_reads = Lmin >= 12u ? 1u : (Lmin ? (12u + Lmin - 1u) / Lmin : n32);   // trailing reads with guarded loads
 
+  // UNI: read r of a mate is at r * L
   auto issue = [&](const uint32_t r, Raw8 &w, Raw8 &q) {
     w = Raw8{0u, 0u, 0u, 0u};
     q = Raw8{0u, 0u, 0u, 0u};
@@ -952,7 +966,15 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   uint32_t read = blockIdx.x * WAVES + wave;
   if (read >= n32) return;
   Raw8 w_cur, q_cur;
-  issue(read, w_cur, q_cur);
+  ReadMeta m_cur{}, m_nxt{};
+  if (UNI) {
+    issue(read, w_cur, q_cur);
+  } else {
+    m_cur = fetch_meta(P, read);
+    fetch_group<HASQ>(P, m_cur, (uint32_t)lane, w_cur, q_cur);
+    const uint32_t n1 = n32 - read > stride ? read + stride : n32;
+    m_nxt = fetch_meta(P, n1 < n32 ? n1 : read);
+  }
   retire_loads(w_cur);
   retire_loads(q_cur);
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
@@ -960,7 +982,30 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     const uint32_t nxt = n32 - read > stride ? read + stride : n32;   // saturates at n32
     const bool have_nxt = nxt < n32;
     Raw8 w_nxt = Raw8{0u, 0u, 0u, 0u}, q_nxt = Raw8{0u, 0u, 0u, 0u};
-    if (have_nxt) issue(nxt, w_nxt, q_nxt);
+    ReadMetaRaw r_nn{};
+    uint32_t nn = n32;
+    if (UNI) {
+      if (have_nxt) issue(nxt, w_nxt, q_nxt);
+    } else {
+      if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
+      nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
+      r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
+      set_geometry(m_cur.L1, m_cur.L2);
+    }
+    bool skip = false;
+    if (!UNI) {
+      const uint32_t ns = nk2 ? P2 + nk2 : nk1;
+      if (ns > S || n_groups > 64u) {   // does not fit this specialisation: the general kernel's queue (as process_read does)
+        if (lane == 0) {
+          const ClassifyOut *O = out_ptrs(P);
+          const uint32_t qi = atomicAdd(&O->counters[CTR_LONG], 1u);
+          O->long_queue[qi] = read;
+          atomicMax(&O->counters[CTR_MAX_SLOTS], ns);
+        }
+        skip = true;
+      }
+    }
+    if (!skip) {
 
     // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
     if (act) {
@@ -1221,9 +1266,15 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         }
       }
     }
+    }   // !skip
     if (!have_nxt) break;
     retire_loads(w_nxt);
     retire_loads(q_nxt);
+    if (!UNI) {
+      retire_meta(r_nn);
+      m_cur = m_nxt;
+      m_nxt = meta_finish(r_nn);
+    }
     read = nxt; w_cur = w_nxt; q_cur = q_nxt;
   }
 }
@@ -1487,13 +1538,19 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   return SHK_OK;
 }
 
-bool uni_kernel_available(const Ctx *ctx) { return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap; }
+// (SHK_FORCE_GENERIC=1: every batch through classify_fast_kernel / process_read -- the tests run both code paths)
+bool uni_kernel_available(const Ctx *ctx)
+{
+  const char *e = getenv("SHK_FORCE_GENERIC");
+  return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap && !(e && e[0] == '1');
+}
 
 template <int U>
-static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, unsigned grid, hipStream_t s)
+static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool uni, unsigned grid, hipStream_t s)
 {
-#define LU(M_, L_) do { if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, M_, true, L_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p); \
-                        else hipLaunchKernelGGL((classify_uni_kernel<U, M_, false, L_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p); } while (0)
+#define LU4(M_, L_, HQ_, UN_) hipLaunchKernelGGL((classify_uni_kernel<U, M_, HQ_, L_, UN_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p)
+#define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
+                        else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
   switch (mode) {
   case PM_LDS_TAB: if (big) LU(PM_LDS_TAB, 20); else LU(PM_LDS_TAB, 18); break;
   case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
@@ -1502,10 +1559,12 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
   default: LU(PM_TAB_SUM, 18); break;
   }
 #undef LU
+#undef LU4
 }
 
-// the uniform-length kernel (every index with a position table); with p.uni_flag set it decides on the device whether it runs
-int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots, hipStream_t stream)
+// the table kernel (every index with a position table), for uniform batches (`uni`) or ragged ones; with p.uni_flag set each
+// of the two launches decides on the device whether it is the one that runs
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots, bool uni, hipStream_t stream)
 {
   if (p_in.n == 0) return SHK_OK;
   ClassifyParams p = p_in;
@@ -1514,7 +1573,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint32_t u = fast_kernel_unroll(max_slots);
   // indices too dense for the 32 KiB LDS summary may still have the 128 KiB one (index_build.hip): uniform batches then
   // run in LDS-summary mode with it, whatever chain ragged batches use on this index
-  const bool big = !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
+  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
     p.lsum32 = ctx->idx.lbig32;
@@ -1525,12 +1584,12 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint64_t cap = big ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  if (u == 2) launch_uni_u<2>(p, mode, hasq, big, grid, stream);
-  else if (u == 3) launch_uni_u<3>(p, mode, hasq, big, grid, stream);
-  else if (u == 4) launch_uni_u<4>(p, mode, hasq, big, grid, stream);
-  else if (u == 5) launch_uni_u<5>(p, mode, hasq, big, grid, stream);
-  else if (u == 6) launch_uni_u<6>(p, mode, hasq, false, grid, stream);
-  else launch_uni_u<8>(p, mode, hasq, false, grid, stream);
+  if (u == 2) launch_uni_u<2>(p, mode, hasq, big, uni, grid, stream);
+  else if (u == 3) launch_uni_u<3>(p, mode, hasq, big, uni, grid, stream);
+  else if (u == 4) launch_uni_u<4>(p, mode, hasq, big, uni, grid, stream);
+  else if (u == 5) launch_uni_u<5>(p, mode, hasq, big, uni, grid, stream);
+  else if (u == 6) launch_uni_u<6>(p, mode, hasq, false, uni, grid, stream);
+  else launch_uni_u<8>(p, mode, hasq, false, uni, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }

@@ -272,8 +272,9 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
   s.fast_cap = 64 * fast_kernel_unroll(max_slots);
   s.gen_slots = s.fast_cap;
-  if (!uni_kernel_available(ctx) || n == 0) uni_mode = UNI_NO;
-  if (uni_mode == UNI_NO) {
+  const bool table_kernel = uni_kernel_available(ctx) && n != 0;   // an index with a position table: classify_uni_kernel, uniform or not
+  if (!table_kernel) {
+    uni_mode = UNI_NO;
     SHK_HIP(ctx, hipMemsetAsync(s.d_count + n, 0, sizeof(uint32_t), st));
   } else {
     // classify_uni_kernel writes count[] only for reads with associations
@@ -281,7 +282,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     if (uni_mode == UNI_ASK_DEVICE) {
       if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
       s.p.uni_flag = s.d_uni_flag;
-    } else {
+    } else if (uni_mode == UNI_YES) {
       s.p.uni_L1 = uni_L1;
       s.p.uni_L2 = uni_L2;
     }
@@ -314,9 +315,15 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     p.work_count = nullptr;
     if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
   }
-  if (!ctx->idx.wrap && uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, st))) return rc;
-  if (!ctx->idx.wrap && uni_mode == UNI_NO && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
-  if (uni_mode == UNI_ASK_DEVICE && (rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;
+  if (!ctx->idx.wrap) {
+    if (!table_kernel) {
+      if ((rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;           // bit-vector probe chains
+    } else {
+      // what the host knows decides the launch; when only the device knows, both are made and one returns at once
+      if (uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, true, st))) return rc;
+      if (uni_mode != UNI_YES && (rc = launch_classify_uni(ctx, s.p, max_slots, false, st))) return rc;
+    }
+  }
   if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
 
   uint32_t n_long = 0;

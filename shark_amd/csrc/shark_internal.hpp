@@ -209,7 +209,7 @@ int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool sk
 int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
 int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
                            const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, hipStream_t stream);
-int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, hipStream_t stream);
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, bool uni, hipStream_t stream);
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);
 bool uni_kernel_available(const Ctx *ctx);
 uint32_t fast_kernel_max_slots();
