@@ -702,14 +702,23 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   // slot count of the longest read decides the specialisation; only when even the largest one is too small do reads
   // go to the general kernel, and then the host counts them here (so the device never has to be asked)
   uint32_t max_slots = slots_of_read(max1, max2, k);   // an upper bound for every read: the slot count is monotone in both lengths
+  // Reads the table kernel cannot take -- more slots than its largest specialisation, or more than 64 staging groups of 8
+  // bases -- go to the general kernel; the host counts them here with the kernel's own criterion (classify.hip), so the
+  // device never has to be asked.  Only when the bounds say such reads are possible at all.
   uint32_t n_long = 0, long_slots = 0;
-  if (max_slots > fast_kernel_max_slots()) {
+  const bool group_limit = uni_kernel_available(ctx);   // (classify_fast_kernel, used on indices without a table, stages any number of groups)
+  const uint64_t groups_bound = ((max1 + 7) >> 3) + ((max2 + 7) >> 3);
+  if (max_slots > fast_kernel_max_slots() || (group_limit && groups_bound > 64)) {
+    const uint32_t cap = 64 * fast_kernel_unroll(std::min(max_slots, fast_kernel_max_slots()));
     for (uint64_t i = 0; i < n; ++i) {
-      const uint32_t ns = slots_of_read(b->off1[i + 1] - b->off1[i], paired ? b->off2[i + 1] - b->off2[i] : 0, k);
-      long_slots = std::max(long_slots, ns);
-      n_long += ns > fast_kernel_max_slots();
+      const uint64_t l1 = b->off1[i + 1] - b->off1[i], l2 = paired ? b->off2[i + 1] - b->off2[i] : 0;
+      const uint32_t ns = slots_of_read(l1, l2, k);
+      if (ns > cap || (group_limit && ((l1 + 7) >> 3) + ((l2 + 7) >> 3) > 64)) {
+        long_slots = std::max(long_slots, ns);
+        ++n_long;
+      }
     }
-    max_slots = fast_kernel_max_slots();
+    if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
   }
 
   hipStream_t up = ctx->h2d_stream, st = ctx->stream;
@@ -747,7 +756,7 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   if (paired) { d.seq2 = (const char *)s.d_seq2; d.off2 = s.d_off2; }
   if (hasq) { d.qual1 = (const char *)s.d_qual1; if (paired) d.qual2 = (const char *)s.d_qual2; }
   s.host_batch = true;
-  const bool uni_fits = uniform && n_long == 0 && ((max1 + 7) >> 3) + ((max2 + 7) >> 3) <= 64;
+  const bool uni_fits = uniform && n_long == 0 && groups_bound <= 64;
   if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true, uni_fits ? UNI_YES : UNI_NO, (uint32_t)max1, (uint32_t)max2))) return rc;
   s.ticket = ctx->next_ticket++;
   s.waited = false;
