@@ -260,7 +260,8 @@ enum UniMode {
 };
 
 static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_slots, int long_mode, uint32_t n_long_host,
-                            uint32_t long_slots_host, bool count_genes, int uni_mode = UNI_ASK_DEVICE, uint32_t uni_L1 = 0, uint32_t uni_L2 = 0)
+                            uint32_t long_slots_host, bool count_genes, int uni_mode = UNI_ASK_DEVICE, uint32_t uni_L1 = 0, uint32_t uni_L2 = 0,
+                            bool groups_fit = true)
 {
   hipStream_t st = ctx->stream;
   const uint64_t n = b->n;
@@ -272,7 +273,9 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
   s.fast_cap = 64 * fast_kernel_unroll(max_slots);
   s.gen_slots = s.fast_cap;
-  const bool table_kernel = uni_kernel_available(ctx) && n != 0;   // an index with a position table: classify_uni_kernel, uniform or not
+  // an index with a position table: classify_uni_kernel, uniform or not -- unless the batch is known to hold reads of more
+  // than 64 staging groups (> 512 bases per pair), which only classify_fast_kernel stages without the general kernel's help
+  const bool table_kernel = uni_kernel_available(ctx) && n != 0 && groups_fit;
   if (!table_kernel) {
     uni_mode = UNI_NO;
     SHK_HIP(ctx, hipMemsetAsync(s.d_count + n, 0, sizeof(uint32_t), st));
@@ -379,7 +382,8 @@ static int classify_resident(Ctx *ctx, const shk_batch *b, uint32_t max_read_len
   const uint32_t max_slots = max_read_len ? slots_for_len(max_read_len, ctx->prm.k, paired) : 0;
   const int long_mode = (max_read_len && max_slots <= fast_kernel_max_slots()) ? LONG_NONE_EXPECTED : LONG_UNKNOWN;
   int rc;
-  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr))) return rc;
+  const uint64_t hint_groups = (((uint64_t)max_read_len + 7) >> 3) * (paired ? 2 : 1);   // (no bound given: the table kernel queues what it cannot stage)
+  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr, UNI_ASK_DEVICE, 0, 0, hint_groups <= 64))) return rc;
   SHK_HIP(ctx, hipStreamSynchronize(st));
   bool redone = false;
   if ((rc = finish_classify(ctx, s, long_mode == LONG_NONE_EXPECTED, wc == nullptr, &redone))) return rc;
@@ -702,18 +706,17 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   // slot count of the longest read decides the specialisation; only when even the largest one is too small do reads
   // go to the general kernel, and then the host counts them here (so the device never has to be asked)
   uint32_t max_slots = slots_of_read(max1, max2, k);   // an upper bound for every read: the slot count is monotone in both lengths
-  // Reads the table kernel cannot take -- more slots than its largest specialisation, or more than 64 staging groups of 8
-  // bases -- go to the general kernel; the host counts them here with the kernel's own criterion (classify.hip), so the
-  // device never has to be asked.  Only when the bounds say such reads are possible at all.
+  // Reads with more slots than the largest specialisation go to the general kernel; the host counts them here with the
+  // kernels' own criterion (classify.hip), so the device never has to be asked.  Only when the bound says there are any.
   uint32_t n_long = 0, long_slots = 0;
-  const bool group_limit = uni_kernel_available(ctx);   // (classify_fast_kernel, used on indices without a table, stages any number of groups)
   const uint64_t groups_bound = ((max1 + 7) >> 3) + ((max2 + 7) >> 3);
-  if (max_slots > fast_kernel_max_slots() || (group_limit && groups_bound > 64)) {
+  const bool groups_fit = groups_bound <= 64;   // else the batch runs on classify_fast_kernel, which stages any number of groups
+  if (max_slots > fast_kernel_max_slots()) {
     const uint32_t cap = 64 * fast_kernel_unroll(std::min(max_slots, fast_kernel_max_slots()));
     for (uint64_t i = 0; i < n; ++i) {
       const uint64_t l1 = b->off1[i + 1] - b->off1[i], l2 = paired ? b->off2[i + 1] - b->off2[i] : 0;
       const uint32_t ns = slots_of_read(l1, l2, k);
-      if (ns > cap || (group_limit && ((l1 + 7) >> 3) + ((l2 + 7) >> 3) > 64)) {
+      if (ns > cap) {
         long_slots = std::max(long_slots, ns);
         ++n_long;
       }
@@ -756,8 +759,10 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   if (paired) { d.seq2 = (const char *)s.d_seq2; d.off2 = s.d_off2; }
   if (hasq) { d.qual1 = (const char *)s.d_qual1; if (paired) d.qual2 = (const char *)s.d_qual2; }
   s.host_batch = true;
-  const bool uni_fits = uniform && n_long == 0 && groups_bound <= 64;
-  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true, uni_fits ? UNI_YES : UNI_NO, (uint32_t)max1, (uint32_t)max2))) return rc;
+  const bool uni_fits = uniform && n_long == 0 && groups_fit;
+  if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true, uni_fits ? UNI_YES : UNI_NO, (uint32_t)max1, (uint32_t)max2,
+                             groups_fit)))
+    return rc;
   s.ticket = ctx->next_ticket++;
   s.waited = false;
   *ticket = s.ticket;
