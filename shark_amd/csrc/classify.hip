@@ -64,10 +64,11 @@ enum ProbeMode {
   PM_TAB_SUM = 4,  // summary level, then position table
   PM_LDS_TAB = 5,  // 2^18-bit summary held in LDS, then position table (small indices)
   PM_TAB_MOD = 6,      // PM_TAB for a filter size that is not a power of two (position = hash % size)
-  PM_LDS_TAB_MOD = 7   // PM_LDS_TAB, likewise
+  PM_LDS_TAB_MOD = 7,  // PM_LDS_TAB, likewise
+  PM_KLDS = 8          // classify_uni_kernel only: LDS summary + table keyed by the K-MER itself (k <= 18; no XXH64 per read k-mer)
 };
 __host__ __device__ constexpr bool pm_pow2(int m) { return m != PM_BV_MOD && m != PM_TAB_MOD && m != PM_LDS_TAB_MOD; }
-__host__ __device__ constexpr bool pm_lds(int m) { return m == PM_LDS_TAB || m == PM_LDS_TAB_MOD; }
+__host__ __device__ constexpr bool pm_lds(int m) { return m == PM_LDS_TAB || m == PM_LDS_TAB_MOD || m == PM_KLDS; }
 __host__ __device__ constexpr bool pm_tab(int m) { return m == PM_TAB || m == PM_TAB_SUM || m == PM_TAB_MOD || pm_lds(m); }
 
 // position of a hash in a filter whose size is not a power of two: hash % _size (bloomfilter.h:58,:66,:88)
@@ -889,6 +890,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
+  // KM: the index knows EVERY canonical k-mer whose filter bit is set (index_build.hip, kmer_enum_kernel): summary and
+  // table are keyed by the k-mer's value, `pos[j]` holds the k-mer and `hx[j]` its cheap mix; no XXH64, no position
+  constexpr bool KM = MODE == PM_KLDS;
   using UG = UniGeom<U, MODE, LSL>;
   constexpr int WAVES = UG::WAVES;
   constexpr uint32_t S = 64 * U;
@@ -1037,6 +1041,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
     // ---- U canonical k-mers, U hashes, U summary probes --------------------------
     uint64_t pos[U];
+    uint32_t hx[U];
     {
       const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
       const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
@@ -1050,9 +1055,15 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
         const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
         const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
-        const uint64_t hsh = xxh64_u64(canon);
-        // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
-        pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
+        if (KM) {
+          pos[j] = canon;
+          hx[j] = kmer_mix(canon);
+        } else {
+          const uint64_t hsh = xxh64_u64(canon);
+          // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+          pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
+          hx[j] = 0;
+        }
       }
     }
     uint32_t okm[U];   // all ones where the slot's probe has to be made, else 0
@@ -1085,7 +1096,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       uint32_t si[U], sw[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
+        si[j] = KM ? (hx[j] >> (32 - LSL))
+                   : __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
         sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
       }
       uint32_t any = 0;
@@ -1099,17 +1111,25 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (something) {
       // ---- position table: the probes that passed read their home bucket, the others the spare empty bucket ----
       const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
-      const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
+      const uint32_t bmask = KM ? (uint32_t)((1ull << P.tab_lg) - 1ull) : ((uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask);
       const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
       const uint32_t spare = 1u << P.tab_lg;
+      // the word(s) a slot is compared with.  Position table: high word = tag | valid | displacement.  K-mer table: high word
+      // = k-mer >> 4, and the top five bits of the low word = (k-mer & 15) << 1 | valid.
       auto want_of = [&](const int j) -> uint32_t {
+        if (KM) return (uint32_t)(pos[j] >> 4);
         const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
         return (tag << 8) | 0x80u;
       };
+      auto want_lo = [&](const int j) -> uint32_t { return (((uint32_t)pos[j] & 15u) << 1) | 1u; };
+      auto slot_is = [&](const uint32_t lo, const uint32_t hi, const uint32_t want, const uint32_t wl) -> uint32_t {
+        return KM ? (uint32_t)((hi == want) & ((lo >> 27) == wl)) : (uint32_t)(hi == want);
+      };
+      auto slot_free = [&](const uint32_t lo, const uint32_t hi) -> uint32_t { return KM ? (uint32_t)(((lo >> 27) & 1u) == 0u) : (uint32_t)(hi == 0u); };
       uint4 bk[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t bb = (uint32_t)pos[j] & bmask;
+        const uint32_t bb = KM ? kmer_bucket(hx[j], bmask) : ((uint32_t)pos[j] & bmask);
         const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
         if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
           const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
@@ -1122,9 +1142,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       bool more[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t want = want_of(j);
-        const bool match = (bk[j].y == want) | (bk[j].w == want);
-        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);
+        const uint32_t want = want_of(j), wl = want_lo(j);
+        const bool match = (slot_is(bk[j].x, bk[j].y, want, wl) | slot_is(bk[j].z, bk[j].w, want, wl)) != 0u;
+        const bool empty = (slot_free(bk[j].x, bk[j].y) | slot_free(bk[j].z, bk[j].w)) != 0u;
         lane_any |= match;
         more[j] = !match & !empty;
         lane_more |= more[j];
@@ -1133,17 +1153,18 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #pragma unroll
         for (int j = 0; j < U; ++j) {
           uint32_t d = 0;
+          const uint32_t home = KM ? kmer_bucket(hx[j], bmask) : (uint32_t)pos[j];
           while (more[j]) {
             ++d;
-            const uint4 b2 = tab16[((uint32_t)pos[j] + d) & bmask];
-            const uint32_t want = want_of(j) | d;
-            const bool n0 = b2.y == want, n1 = b2.w == want;
+            const uint4 b2 = tab16[(home + d) & bmask];
+            const uint32_t want = KM ? want_of(j) : (want_of(j) | d), wl = want_lo(j);
+            const bool n0 = slot_is(b2.x, b2.y, want, wl) != 0u, n1 = slot_is(b2.z, b2.w, want, wl) != 0u;
             if (n0 | n1) {
-              bk[j].x = n0 ? b2.x : b2.z;
+              bk[j].x = n0 ? b2.x : b2.z;   // moved into slot 0 of bk[j] in home form, so that the decode needs no second case
               bk[j].y = want_of(j);
               lane_any = true;
               more[j] = false;
-            } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
+            } else if ((slot_free(b2.x, b2.y) | slot_free(b2.z, b2.w)) != 0u || d >= 63u) {
               more[j] = false;
             }
           }
@@ -1160,8 +1181,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         bool any2 = false;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-          const uint32_t want = want_of(j);
-          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+          const uint32_t want = want_of(j), wl = want_lo(j);
+          const bool m0 = slot_is(bk[j].x, bk[j].y, want, wl) != 0u, m1 = slot_is(bk[j].z, bk[j].w, want, wl) != 0u;
           // the probe was issued without looking at the slot: it has to exist and be a valid k-mer (process_read, slot_ok)
           const uint32_t pp = (uint32_t)lane + 64u * j;
           const bool exists = (pp < nk1) | ((pp - P2) < nk2);
@@ -1171,8 +1192,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           hit[j] = LSUM ? ((m0 | m1) & exists & ((win & kmask) == kmask)) : (m0 | m1);   // (table modes settled that before the probe)
           any2 |= hit[j];
           const uint32_t lo = m0 ? bk[j].x : bk[j].z;
-          payload[j] = lo & 0x7FFFFFFFu;
-          multi[j] = (lo >> 31) != 0u;
+          payload[j] = KM ? (lo & 0x3FFFFFFu) : (lo & 0x7FFFFFFFu);
+          multi[j] = KM ? (((lo >> 26) & 1u) != 0u) : ((lo >> 31) != 0u);
         }
         if (__ballot(any2)) {
           bool lane_multi = false;
@@ -1496,6 +1517,7 @@ const char *probe_mode_name(const Ctx *ctx)
 {
   static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table",
                                 "table-mod", "lds-summary+table-mod"};
+  if (ctx->idx.ktab_lg && uni_kernel_available(ctx)) return "lds-summary+kmer-table";   // (batches classify_fast_kernel takes use the chain below)
   return names[probe_mode(ctx->idx)];
 }
 
@@ -1552,6 +1574,7 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
 #define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
                         else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
   switch (mode) {
+  case PM_KLDS: if (big) LU(PM_KLDS, 20); else LU(PM_KLDS, 18); break;
   case PM_LDS_TAB: if (big) LU(PM_LDS_TAB, 20); else LU(PM_LDS_TAB, 18); break;
   case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
   case PM_TAB: LU(PM_TAB, 18); break;
@@ -1573,11 +1596,22 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint32_t u = fast_kernel_unroll(max_slots);
   // indices too dense for the 32 KiB LDS summary may still have the 128 KiB one (index_build.hip): uniform batches then
   // run in LDS-summary mode with it, whatever chain ragged batches use on this index
-  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
+  bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
     p.lsum32 = ctx->idx.lbig32;
     p.lsum_shift = ctx->idx.lbig_shift;
+  }
+  // the k-mer-keyed table (k <= 18, sparse filters): no XXH64 per read k-mer.  Its 128 KiB summary form needs the
+  // 1024-thread workgroup, which only the uniform instantiations up to U = 5 have.
+  const DeviceIndex &ix = ctx->idx;
+  if (ix.ktab_lg && (ix.klsum_log2 == 18 || (uni && u <= 5))) {
+    mode = PM_KLDS;
+    big = ix.klsum_log2 == 20;
+    p.tab = ix.ktab;
+    p.tab_lg = ix.ktab_lg;
+    p.lsum32 = ix.klsum32;
+    p.lsum_shift = 0;
   }
   const int min_waves = big ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : 8));
   const uint64_t wpb = big ? 16 : 8;

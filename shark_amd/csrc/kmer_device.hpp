@@ -55,6 +55,21 @@ __host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t v)
 }
 
 // ---------------------------------------------------------------------------
+// The k-mer-keyed table (k <= 18; index_build.hip / classify.hip): a cheap 32-bit mix of a canonical k-mer (< 2^36).
+// Summary index = top bits, bucket = the folded low bits.  One slow multiply instead of XXH64's fifteen.
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t kmer_mix(uint64_t x)
+{
+  return (uint32_t)x * 0x9E3779B1u ^ ((uint32_t)(x >> 32) & 0xFFu) * 0x85EBCAu;
+}
+__host__ __device__ __forceinline__ uint32_t kmer_bucket(uint32_t h, uint32_t bmask) { return (h ^ (h >> 16)) & bmask; }
+// slot (64 bit): [63:28] k-mer  [27] valid  [26] multi  [25:0] gene (single-gene list) or rank r (multi: ent[r])
+__host__ __device__ __forceinline__ uint64_t kmer_slot(uint64_t x, bool multi, uint32_t payload)
+{
+  return (x << 28) | (1ull << 27) | ((uint64_t)multi << 26) | (uint64_t)(payload & 0x3FFFFFFu);
+}
+
+// ---------------------------------------------------------------------------
 // Base classification, 4 ASCII bytes at a time (SWAR).
 // Result must agree with to_int (kmer_utils.hpp:29-41): A/a C/c G/g T/t are
 // valid with codes 0..3 (= to_int-1, kmer_utils.hpp:68), every other byte --
