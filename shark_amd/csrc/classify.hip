@@ -1111,25 +1111,21 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (something) {
       // ---- position table: the probes that passed read their home bucket, the others the spare empty bucket ----
       const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
-      const uint32_t bmask = KM ? (uint32_t)((1ull << P.tab_lg) - 1ull) : ((uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask);
+      const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
       const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
       const uint32_t spare = 1u << P.tab_lg;
-      // the word(s) a slot is compared with.  Position table: high word = tag | valid | displacement.  K-mer table: high word
-      // = k-mer >> 4, and the top five bits of the low word = (k-mer & 15) << 1 | valid.
+      const uint32_t knb = kmer_nb(k);
+      // the word a slot's high word is compared with (0 = empty slot in both tables).  Position table: tag | valid |
+      // displacement.  K-mer table: the k-mer's top 32 bits + 1 (kmer_device.hpp); its low bits select the sub-table.
       auto want_of = [&](const int j) -> uint32_t {
-        if (KM) return (uint32_t)(pos[j] >> 4);
+        if (KM) return kmer_want(pos[j], knb);
         const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
         return (tag << 8) | 0x80u;
       };
-      auto want_lo = [&](const int j) -> uint32_t { return (((uint32_t)pos[j] & 15u) << 1) | 1u; };
-      auto slot_is = [&](const uint32_t lo, const uint32_t hi, const uint32_t want, const uint32_t wl) -> uint32_t {
-        return KM ? (uint32_t)((hi == want) & ((lo >> 27) == wl)) : (uint32_t)(hi == want);
-      };
-      auto slot_free = [&](const uint32_t lo, const uint32_t hi) -> uint32_t { return KM ? (uint32_t)(((lo >> 27) & 1u) == 0u) : (uint32_t)(hi == 0u); };
       uint4 bk[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t bb = KM ? kmer_bucket(hx[j], bmask) : ((uint32_t)pos[j] & bmask);
+        const uint32_t bb = KM ? kmer_bucket(pos[j], hx[j], 0u, P.tab_lg, knb) : ((uint32_t)pos[j] & bmask);
         const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
         if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
           const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
@@ -1142,9 +1138,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       bool more[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t want = want_of(j), wl = want_lo(j);
-        const bool match = (slot_is(bk[j].x, bk[j].y, want, wl) | slot_is(bk[j].z, bk[j].w, want, wl)) != 0u;
-        const bool empty = (slot_free(bk[j].x, bk[j].y) | slot_free(bk[j].z, bk[j].w)) != 0u;
+        const uint32_t want = want_of(j);
+        const bool match = (bk[j].y == want) | (bk[j].w == want);
+        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);
         lane_any |= match;
         more[j] = !match & !empty;
         lane_more |= more[j];
@@ -1153,18 +1149,17 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #pragma unroll
         for (int j = 0; j < U; ++j) {
           uint32_t d = 0;
-          const uint32_t home = KM ? kmer_bucket(hx[j], bmask) : (uint32_t)pos[j];
           while (more[j]) {
             ++d;
-            const uint4 b2 = tab16[(home + d) & bmask];
-            const uint32_t want = KM ? want_of(j) : (want_of(j) | d), wl = want_lo(j);
-            const bool n0 = slot_is(b2.x, b2.y, want, wl) != 0u, n1 = slot_is(b2.z, b2.w, want, wl) != 0u;
+            const uint4 b2 = tab16[KM ? kmer_bucket(pos[j], hx[j], d, P.tab_lg, knb) : (((uint32_t)pos[j] + d) & bmask)];
+            const uint32_t want = KM ? want_of(j) : (want_of(j) | d);
+            const bool n0 = b2.y == want, n1 = b2.w == want;
             if (n0 | n1) {
               bk[j].x = n0 ? b2.x : b2.z;   // moved into slot 0 of bk[j] in home form, so that the decode needs no second case
               bk[j].y = want_of(j);
               lane_any = true;
               more[j] = false;
-            } else if ((slot_free(b2.x, b2.y) | slot_free(b2.z, b2.w)) != 0u || d >= 63u) {
+            } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
               more[j] = false;
             }
           }
@@ -1181,8 +1176,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         bool any2 = false;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-          const uint32_t want = want_of(j), wl = want_lo(j);
-          const bool m0 = slot_is(bk[j].x, bk[j].y, want, wl) != 0u, m1 = slot_is(bk[j].z, bk[j].w, want, wl) != 0u;
+          const uint32_t want = want_of(j);
+          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
           // the probe was issued without looking at the slot: it has to exist and be a valid k-mer (process_read, slot_ok)
           const uint32_t pp = (uint32_t)lane + 64u * j;
           const bool exists = (pp < nk1) | ((pp - P2) < nk2);
@@ -1192,8 +1187,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           hit[j] = LSUM ? ((m0 | m1) & exists & ((win & kmask) == kmask)) : (m0 | m1);   // (table modes settled that before the probe)
           any2 |= hit[j];
           const uint32_t lo = m0 ? bk[j].x : bk[j].z;
-          payload[j] = KM ? (lo & 0x3FFFFFFu) : (lo & 0x7FFFFFFFu);
-          multi[j] = KM ? (((lo >> 26) & 1u) != 0u) : ((lo >> 31) != 0u);
+          payload[j] = lo & 0x7FFFFFFFu;
+          multi[j] = (lo >> 31) != 0u;
         }
         if (__ballot(any2)) {
           bool lane_multi = false;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(KE_THREADS) void kmer_enum_kernel(uint32_t k, uint6
     __syncthreads();
   }
   const uint64_t stride = (uint64_t)gridDim.x * KE_THREADS;
-  const uint32_t bmask = (uint32_t)((1ull << ktab_lg) - 1ull);
+  const uint32_t nb = kmer_nb(k);
   uint32_t mine = 0;
   for (uint64_t x = (uint64_t)blockIdx.x * KE_THREADS + threadIdx.x; x < universe; x += stride) {
     const uint64_t rc = revcomp_left_aligned(x << (64 - 2 * k), k);
@@ -247,13 +247,12 @@ __global__ __launch_bounds__(KE_THREADS) void kmer_enum_kernel(uint32_t k, uint6
       const uint32_t r = rank_w[pos >> 6] + (uint32_t)__builtin_popcountll(word & ((1ull << (pos & 63)) - 1ull));
       const ListEntry le = ent[r];
       const bool multi = le.len != 1;
-      const unsigned long long e = kmer_slot(x, multi, multi ? r : (uint32_t)le.gene0);
+      const unsigned long long e = kmer_slot(x, nb, multi, multi ? r : (uint32_t)le.gene0);
       const uint32_t hx = kmer_mix(x);
-      uint32_t bkt = kmer_bucket(hx, bmask);
       bool done = false;
       for (uint32_t d = 0; d < 64 && !done; ++d) {
+        const uint32_t bkt = kmer_bucket(x, hx, d, ktab_lg, nb);
         for (int sidx = 0; sidx < 2 && !done; ++sidx) done = atomicCAS(&ktab[2 * (uint64_t)bkt + sidx], 0ull, e) == 0ull;
-        bkt = (bkt + 1) & bmask;
       }
       if (!done) atomicAdd(fail, 1u);
       const uint32_t si = hx >> (32 - klsum_log2);
@@ -520,7 +519,7 @@ int build_index(Ctx *ctx)
   // LDS summary; the universe must not dwarf the filter (else most keys would be false positives): 4^k / 2 <= 2 B
   ix.ktab_lg = 0;
   ix.klsum_log2 = 0;
-  if (k <= 18 && n_set > 0 && n_set < (1ull << 26) && ix.tab_lg && (ix.lsum_shift || ix.lbig_shift) && !getenv("SHK_NO_KMER_TABLE") &&
+  if (k <= 18 && n_set > 0 && ix.tab_lg && (ix.lsum_shift || ix.lbig_shift) && !getenv("SHK_NO_KMER_TABLE") &&
       !(force && force[0] == 'b')) {
     const uint64_t universe = 1ull << (2 * k);
     if (universe / 2 <= 2 * ix.bf_bits || universe <= (1ull << 20)) {

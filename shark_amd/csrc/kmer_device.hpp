@@ -62,11 +62,22 @@ __host__ __device__ __forceinline__ uint32_t kmer_mix(uint64_t x)
 {
   return (uint32_t)x * 0x9E3779B1u ^ ((uint32_t)(x >> 32) & 0xFFu) * 0x85EBCAu;
 }
-__host__ __device__ __forceinline__ uint32_t kmer_bucket(uint32_t h, uint32_t bmask) { return (h ^ (h >> 16)) & bmask; }
-// slot (64 bit): [63:28] k-mer  [27] valid  [26] multi  [25:0] gene (single-gene list) or rank r (multi: ent[r])
-__host__ __device__ __forceinline__ uint64_t kmer_slot(uint64_t x, bool multi, uint32_t payload)
+// A k-mer has 2k <= 36 bits.  The slot's compare word holds its top 32 bits (+1, so that 0 stays "empty": a canonical k-mer
+// never has 32 leading one bits -- it would start with 16 T, and its reverse complement, ending in 16 A, would be smaller);
+// the nb = max(0, 2k - 32) low bits are implied by WHERE the slot is: the table is 2^nb sub-tables, selected by those bits,
+// each a ring of buckets with its own linear probing.  So a slot looks exactly like the position table's -- one 32-bit
+// compare per slot, 0 = empty, low word = multi(1) | gene-or-rank(31) -- and needs no displacement field.
+__host__ __device__ __forceinline__ uint32_t kmer_nb(uint32_t k) { return 2u * k > 32u ? 2u * k - 32u : 0u; }
+__host__ __device__ __forceinline__ uint32_t kmer_want(uint64_t x, uint32_t nb) { return (uint32_t)(x >> nb) + 1u; }
+// bucket of probe step d (d = 0: home) in a table of 2^lg buckets
+__host__ __device__ __forceinline__ uint32_t kmer_bucket(uint64_t x, uint32_t h, uint32_t d, uint32_t lg, uint32_t nb)
 {
-  return (x << 28) | (1ull << 27) | ((uint64_t)multi << 26) | (uint64_t)(payload & 0x3FFFFFFu);
+  const uint32_t sub_lg = lg - nb, submask = (1u << sub_lg) - 1u;
+  return (((uint32_t)x & ((1u << nb) - 1u)) << sub_lg) | (((h ^ (h >> 16)) + d) & submask);
+}
+__host__ __device__ __forceinline__ uint64_t kmer_slot(uint64_t x, uint32_t nb, bool multi, uint32_t payload)
+{
+  return ((uint64_t)kmer_want(x, nb) << 32) | ((uint64_t)multi << 31) | (uint64_t)(payload & 0x7FFFFFFFu);
 }
 
 // ---------------------------------------------------------------------------
