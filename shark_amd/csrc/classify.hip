@@ -891,7 +891,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
   // KM: the index knows EVERY canonical k-mer whose filter bit is set (index_build.hip, kmer_enum_kernel): summary and
-  // table are keyed by the k-mer's value, `pos[j]` holds the k-mer and `hx[j]` its cheap mix; no XXH64, no position
+  // table are keyed by the k-mer's value, `pos[j]` holds the k-mer (kmer_mix of it indexes them); no XXH64, no position
   constexpr bool KM = MODE == PM_KLDS;
   using UG = UniGeom<U, MODE, LSL>;
   constexpr int WAVES = UG::WAVES;
@@ -925,7 +925,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
   // ---- geometry: of every read of the batch (UNI) or of the current read ----------
   const uint32_t k = P.k;
-  uint32_t nk1, nk2, P2, g2, n_groups, tail_inv, Lm, rem, nbytes;
+  uint32_t nk1, nk2, P2, g2, n_groups, tail_inv, Lm;
   bool act, m2;
   auto set_geometry = [&](const uint32_t l1, const uint32_t l2) {
     nk1 = l1 >= k ? l1 - k + 1 : 0;
@@ -938,8 +938,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     m2 = (uint32_t)lane >= g2;
     const uint32_t b = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
     Lm = m2 ? l2 : l1;
-    rem = act ? Lm - b : 8u;
-    nbytes = rem < 8u ? rem : 8u;
+    const uint32_t rem = act ? Lm - b : 8u;
     tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
   };
   set_geometry(L1, L2);
@@ -958,9 +957,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (act) {
       const uint64_t o = (uint64_t)r * Lm;
       if (n32 - r > guard_reads) {
-        w = load8_issue_all(sbase + o, nbytes);
-        if (HASQ) q = load8_issue_all(qbase + o, nbytes);
+        w = load8_issue_all(sbase + o, 8u);
+        if (HASQ) q = load8_issue_all(qbase + o, 8u);
       } else {
+        const uint32_t rem = Lm - b_uni;   // (the last reads of the batch: what is left of the mate decides which dwords exist)
         w = load8_issue(sbase + o, rem);
         if (HASQ) q = load8_issue(qbase + o, rem);
       }
@@ -1041,7 +1041,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
     // ---- U canonical k-mers, U hashes, U summary probes --------------------------
     uint64_t pos[U];
-    uint32_t hx[U];
     {
       const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
       const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
@@ -1056,13 +1055,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
         const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
         if (KM) {
-          pos[j] = canon;
-          hx[j] = kmer_mix(canon);
+          pos[j] = canon;   // (its cheap mix is recomputed where it is needed: three instructions against a register per slot)
         } else {
           const uint64_t hsh = xxh64_u64(canon);
           // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
           pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
-          hx[j] = 0;
         }
       }
     }
@@ -1096,7 +1093,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       uint32_t si[U], sw[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        si[j] = KM ? (hx[j] >> (32 - LSL))
+        si[j] = KM ? (kmer_mix(pos[j]) >> (32 - LSL))
                    : __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
         sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
       }
@@ -1125,7 +1122,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       uint4 bk[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        const uint32_t bb = KM ? kmer_bucket(pos[j], hx[j], 0u, P.tab_lg, knb) : ((uint32_t)pos[j] & bmask);
+        if (KM) asm("" : "+v"(pos[j]));   // (recompute the mix here instead of carrying five more registers from the summary stage)
+        const uint32_t bb = KM ? kmer_bucket(pos[j], kmer_mix(pos[j]), 0u, P.tab_lg, knb) : ((uint32_t)pos[j] & bmask);
         const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
         if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
           const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
@@ -1151,7 +1149,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           uint32_t d = 0;
           while (more[j]) {
             ++d;
-            const uint4 b2 = tab16[KM ? kmer_bucket(pos[j], hx[j], d, P.tab_lg, knb) : (((uint32_t)pos[j] + d) & bmask)];
+            const uint4 b2 = tab16[KM ? kmer_bucket(pos[j], kmer_mix(pos[j]), d, P.tab_lg, knb) : (((uint32_t)pos[j] + d) & bmask)];
             const uint32_t want = KM ? want_of(j) : (want_of(j) | d);
             const bool n0 = b2.y == want, n1 = b2.w == want;
             if (n0 | n1) {
