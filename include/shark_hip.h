@@ -89,9 +89,7 @@ typedef struct shk_index_info {
 int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
 /* How the classify kernels look a k-mer's filter position up on this index:
  * "bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table",
- * "lds-summary+table", "lds-summary+kmer-table" (k <= 18 on a sparse filter:
- * every canonical k-mer whose bit is set is a key of a table looked up by the
- * k-mer's value), and for filter sizes that are not a power of two
+ * "lds-summary+table", and for filter sizes that are not a power of two
  * "table-mod", "lds-summary+table-mod"
  * (every mode returns exactly the filter's bit).  Environment
  * SHK_PROBE=bitvector at finalize time disables the table (tests use it). */

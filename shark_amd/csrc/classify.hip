@@ -64,11 +64,10 @@ enum ProbeMode {
   PM_TAB_SUM = 4,  // summary level, then position table
   PM_LDS_TAB = 5,  // 2^18-bit summary held in LDS, then position table (small indices)
   PM_TAB_MOD = 6,      // PM_TAB for a filter size that is not a power of two (position = hash % size)
-  PM_LDS_TAB_MOD = 7,  // PM_LDS_TAB, likewise
-  PM_KLDS = 8          // classify_uni_kernel only: LDS summary + table keyed by the K-MER itself (k <= 18; no XXH64 per read k-mer)
+  PM_LDS_TAB_MOD = 7   // PM_LDS_TAB, likewise
 };
 __host__ __device__ constexpr bool pm_pow2(int m) { return m != PM_BV_MOD && m != PM_TAB_MOD && m != PM_LDS_TAB_MOD; }
-__host__ __device__ constexpr bool pm_lds(int m) { return m == PM_LDS_TAB || m == PM_LDS_TAB_MOD || m == PM_KLDS; }
+__host__ __device__ constexpr bool pm_lds(int m) { return m == PM_LDS_TAB || m == PM_LDS_TAB_MOD; }
 __host__ __device__ constexpr bool pm_tab(int m) { return m == PM_TAB || m == PM_TAB_SUM || m == PM_TAB_MOD || pm_lds(m); }
 
 // position of a hash in a filter whose size is not a power of two: hash % _size (bloomfilter.h:58,:66,:88)
@@ -246,6 +245,43 @@ __device__ __forceinline__ void fetch_group(const ClassifyParams &P, const ReadM
   }
 }
 
+// bucket `bi` of a table.  SMALL: the table is known to be below 4 GiB (every index with an LDS summary: < 2^22 buckets),
+// so the byte offset fits 32 bits and the load takes the scalar base + one VGPR of offset instead of a 64-bit VGPR address.
+template <bool SMALL>
+__device__ __forceinline__ uint4 load_bucket(const uint4 *__restrict__ tab16, const uint32_t bi)
+{
+  if (SMALL) return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(tab16) + (bi << 4));
+  return tab16[bi];
+}
+
+// The probe path behind a full home bucket, one probe after the other (process_read; classify_uni_kernel walks all its probes
+// per round).  A probe that finds its key gets it moved into (x, y) of bk[j] in home form.  POSKEY: the position table's
+// slots carry their displacement in the compared word.
+template <int U, bool POSKEY, typename WantOf, typename BucketOf>
+__device__ __forceinline__ void walk_probe_paths(const uint4 *__restrict__ tab16, uint4 (&bk)[U], bool (&more)[U], bool &lane_any,
+                                                 const WantOf want_of, const BucketOf bucket_of)
+{
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    uint32_t d = 0;
+    while (more[j]) {
+      ++d;
+      const uint4 b2 = tab16[bucket_of(j, d)];
+      const uint32_t w0 = want_of(j);
+      const uint32_t want = POSKEY ? (w0 | d) : w0;
+      const bool n0 = b2.y == want, n1 = b2.w == want;
+      if (n0 | n1) {
+        bk[j].x = n0 ? b2.x : b2.z;
+        bk[j].y = w0;
+        lane_any = true;
+        more[j] = false;
+      } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {   // a free slot ends every search
+        more[j] = false;
+      }
+    }
+  }
+}
+
 // WRAP (general kernel only): the index has more than 65 536 genes, so a list may hold an id several times
 // (index_build.hip).  The reference's accumulation then sees that id several times for one k-mer (ReadAnalyzer.hpp:56-62,
 // :79-86): behind the FIRST valid k-mer of the read, a repeated id adds min(k, pos - last) = min(k, 0) = 0 to the coverage
@@ -419,7 +455,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
     bool lane_any = false;
     if (TAB) {
       // ---- position table: one 16-byte bucket answers membership AND the list ----
-      // slot = tag(24) | valid | displacement(6) in the high word, multi(1) | payload(31) in the low
+      // slot = tag(24) | valid | displacement(6) in the high word, multi(1) | overflow(1) | payload(30) in the low
       // word, so membership is ONE compare per slot and nothing else is decoded unless it matched
       const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
       const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;   // tab_lg <= 31; bucket = pos & bmask
@@ -451,33 +487,13 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
       for (int j = 0; j < U; ++j) {
         const uint32_t want = want_of(j);
         const bool match = (bk[j].y == want) | (bk[j].w == want);
-        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);                   // a free slot ends the probe path
         lane_any |= match;
-        more[j] = !match & !empty;
+        more[j] = !match & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
         lane_more |= more[j];
       }
-      // rare: the home bucket was full of other keys -> walk the probe path; a slot found there is
-      // moved into (x, y) of bk[j] in home form, so that the decode below needs no second case
-      if (__ballot(lane_more)) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          uint32_t d = 0;
-          while (more[j]) {
-            ++d;
-            const uint4 b2 = tab16[((uint32_t)pos[j] + d) & bmask];
-            const uint32_t want = want_of(j) | d;
-            const bool n0 = b2.y == want, n1 = b2.w == want;
-            if (n0 | n1) {
-              bk[j].x = n0 ? b2.x : b2.z;
-              bk[j].y = want_of(j);
-              lane_any = true;
-              more[j] = false;
-            } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
-              more[j] = false;
-            }
-          }
-        }
-      }
+      // rare: the key may sit behind its (full) home bucket -> walk the probe path
+      if (__ballot(lane_more))
+        walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, [&](const int j, const uint32_t d) { return ((uint32_t)pos[j] + d) & bmask; });
       bool round_any = __ballot(lane_any) != 0ull;
       if (FAST && !round_any) break;
       // something matched: decode.  In LDS-summary mode the slots now have to exist and be valid
@@ -493,7 +509,7 @@ __device__ __forceinline__ void process_read(const ClassifyParams &P, const uint
         if (LAZY) hit[j] = hit[j] && slot_ok((uint32_t)lane + 64u * j);
         lane_any |= hit[j];
         const uint32_t lo = m0 ? bk[j].x : bk[j].z;
-        payload[j] = lo & 0x7FFFFFFFu;
+        payload[j] = lo & TAB_PAYLOAD;
         multi[j] = (lo >> 31) != 0u;
       }
       if (!FAST && P.work_counters) {
@@ -837,14 +853,23 @@ __global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::M
 // its parameters there, so it holds no registers while off-target reads stream through.  count[] is zeroed by the host
 // before the launch; only reads with associations write it.
 // ---------------------------------------------------------------------------
+#ifndef SHK_STREAM_READS
+#define SHK_STREAM_READS 0
+#endif
 __device__ __forceinline__ Raw8 load8_issue_all(const uint8_t *p, uint32_t nbytes)
 {
   const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
   const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
   Raw8 r;
+#if SHK_STREAM_READS
+  r.d0 = __builtin_nontemporal_load(q);
+  r.d1 = __builtin_nontemporal_load(q + 1);
+  r.d2 = __builtin_nontemporal_load(q + 2);
+#else
   r.d0 = q[0];
   r.d1 = q[1];
   r.d2 = q[2];
+#endif
   r.shn = sh | (nbytes << 4);
   return r;
 }
@@ -890,9 +915,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
-  // KM: the index knows EVERY canonical k-mer whose filter bit is set (index_build.hip, kmer_enum_kernel): summary and
-  // table are keyed by the k-mer's value, `pos[j]` holds the k-mer (kmer_mix of it indexes them); no XXH64, no position
-  constexpr bool KM = MODE == PM_KLDS;
   using UG = UniGeom<U, MODE, LSL>;
   constexpr int WAVES = UG::WAVES;
   constexpr uint32_t S = 64 * U;
@@ -1054,13 +1076,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
         const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
         const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
-        if (KM) {
-          pos[j] = canon;   // (its cheap mix is recomputed where it is needed: three instructions against a register per slot)
-        } else {
-          const uint64_t hsh = xxh64_u64(canon);
-          // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
-          pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
-        }
+        const uint64_t hsh = xxh64_u64(canon);
+        // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+        pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
       }
     }
     uint32_t okm[U];   // all ones where the slot's probe has to be made, else 0
@@ -1093,8 +1111,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       uint32_t si[U], sw[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        si[j] = KM ? (kmer_mix(pos[j]) >> (32 - LSL))
-                   : __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
+        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
         sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
       }
       uint32_t any = 0;
@@ -1111,57 +1128,61 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
       const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
       const uint32_t spare = 1u << P.tab_lg;
-      const uint32_t knb = kmer_nb(k);
-      // the word a slot's high word is compared with (0 = empty slot in both tables).  Position table: tag | valid |
-      // displacement.  K-mer table: the k-mer's top 32 bits + 1 (kmer_device.hpp); its low bits select the sub-table.
+      // the word a slot's high word is compared with (0 = empty slot): tag | valid | displacement 0
       auto want_of = [&](const int j) -> uint32_t {
-        if (KM) return kmer_want(pos[j], knb);
         const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
         return (tag << 8) | 0x80u;
       };
       uint4 bk[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
-        if (KM) asm("" : "+v"(pos[j]));   // (recompute the mix here instead of carrying five more registers from the summary stage)
-        const uint32_t bb = KM ? kmer_bucket(pos[j], kmer_mix(pos[j]), 0u, P.tab_lg, knb) : ((uint32_t)pos[j] & bmask);
+        const uint32_t bb = (uint32_t)pos[j] & bmask;
         const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
         if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
           const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
           bk[j] = make_uint4(v.x, v.y, v.z, v.w);
         } else {
-          bk[j] = tab16[bi];
+          bk[j] = load_bucket<LSUM && UNI>(tab16, bi);   // (the ragged instantiation runs out of registers with the short addresses)
         }
       }
+      // each probe keeps one word of its bucket: the low word of the slot that matched (mt[j] says whether one did)
       bool lane_any = false, lane_more = false;
-      bool more[U];
+      bool more[U], mt[U];
+      uint32_t slo[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const uint32_t want = want_of(j);
-        const bool match = (bk[j].y == want) | (bk[j].w == want);
-        const bool empty = (bk[j].y == 0u) | (bk[j].w == 0u);
-        lane_any |= match;
-        more[j] = !match & !empty;
+        const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+        mt[j] = m0 | m1;
+        slo[j] = m0 ? bk[j].x : bk[j].z;
+        lane_any |= mt[j];
+        more[j] = !mt[j] & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
         lane_more |= more[j];
       }
-      if (__ballot(lane_more)) {   // rare: a full home bucket -> walk the probe path (see process_read)
+      if (__ballot(lane_more)) {
+        // rare: the key may sit behind its (full) home bucket.  Round d looks at bucket home+d of every probe that is
+        // still searching, all U loads in flight together (the others read the spare bucket: one line for the wave) --
+        // a memory round trip per displacement, not per probe.
+        auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
+        uint32_t d = 0;
+        do {
+          ++d;
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-          uint32_t d = 0;
-          while (more[j]) {
-            ++d;
-            const uint4 b2 = tab16[KM ? kmer_bucket(pos[j], kmer_mix(pos[j]), d, P.tab_lg, knb) : (((uint32_t)pos[j] + d) & bmask)];
-            const uint32_t want = KM ? want_of(j) : (want_of(j) | d);
-            const bool n0 = b2.y == want, n1 = b2.w == want;
-            if (n0 | n1) {
-              bk[j].x = n0 ? b2.x : b2.z;   // moved into slot 0 of bk[j] in home form, so that the decode needs no second case
-              bk[j].y = want_of(j);
-              lane_any = true;
-              more[j] = false;
-            } else if ((b2.y == 0u) | (b2.w == 0u) | (d >= 63u)) {
-              more[j] = false;
-            }
+          for (int j = 0; j < U; ++j) bk[j] = load_bucket<LSUM && UNI>(tab16, more[j] ? bucket_of(j, d) : spare);
+          lane_more = false;
+#pragma unroll
+          for (int j = 0; j < U; ++j) {
+            const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
+            const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
+            const bool found = more[j] & (n0 | n1);
+            const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
+            slo[j] = found ? (n0 ? bk[j].x : bk[j].z) : slo[j];
+            mt[j] |= found;
+            lane_any |= found;
+            more[j] = more[j] & !found & !ends;
+            lane_more |= more[j];
           }
-        }
+        } while (__ballot(lane_more));
       }
       if (__ballot(lane_any)) {
         // ================= something matched in the table: the hit path =================
@@ -1174,19 +1195,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         bool any2 = false;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-          const uint32_t want = want_of(j);
-          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
           // the probe was issued without looking at the slot: it has to exist and be a valid k-mer (process_read, slot_ok)
           const uint32_t pp = (uint32_t)lane + 64u * j;
           const bool exists = (pp < nk1) | ((pp - P2) < nk2);
           const uint32_t V = pp >> 6, vs = pp & 63u;
           const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
           const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
-          hit[j] = LSUM ? ((m0 | m1) & exists & ((win & kmask) == kmask)) : (m0 | m1);   // (table modes settled that before the probe)
+          hit[j] = LSUM ? (mt[j] & exists & ((win & kmask) == kmask)) : mt[j];   // (table modes settled that before the probe)
           any2 |= hit[j];
-          const uint32_t lo = m0 ? bk[j].x : bk[j].z;
-          payload[j] = lo & 0x7FFFFFFFu;
-          multi[j] = (lo >> 31) != 0u;
+          payload[j] = slo[j] & TAB_PAYLOAD;
+          multi[j] = (slo[j] >> 31) != 0u;
         }
         if (__ballot(any2)) {
           bool lane_multi = false;
@@ -1510,7 +1528,6 @@ const char *probe_mode_name(const Ctx *ctx)
 {
   static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table",
                                 "table-mod", "lds-summary+table-mod"};
-  if (ctx->idx.ktab_lg && uni_kernel_available(ctx)) return "lds-summary+kmer-table";   // (batches classify_fast_kernel takes use the chain below)
   return names[probe_mode(ctx->idx)];
 }
 
@@ -1567,7 +1584,6 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
 #define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
                         else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
   switch (mode) {
-  case PM_KLDS: if (big) LU(PM_KLDS, 20); else LU(PM_KLDS, 18); break;
   case PM_LDS_TAB: if (big) LU(PM_LDS_TAB, 20); else LU(PM_LDS_TAB, 18); break;
   case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
   case PM_TAB: LU(PM_TAB, 18); break;
@@ -1589,22 +1605,11 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint32_t u = fast_kernel_unroll(max_slots);
   // indices too dense for the 32 KiB LDS summary may still have the 128 KiB one (index_build.hip): uniform batches then
   // run in LDS-summary mode with it, whatever chain ragged batches use on this index
-  bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
+  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
     p.lsum32 = ctx->idx.lbig32;
     p.lsum_shift = ctx->idx.lbig_shift;
-  }
-  // the k-mer-keyed table (k <= 18, sparse filters): no XXH64 per read k-mer.  Its 128 KiB summary form needs the
-  // 1024-thread workgroup, which only the uniform instantiations up to U = 5 have.
-  const DeviceIndex &ix = ctx->idx;
-  if (ix.ktab_lg && (ix.klsum_log2 == 18 || (uni && u <= 5))) {
-    mode = PM_KLDS;
-    big = ix.klsum_log2 == 20;
-    p.tab = ix.ktab;
-    p.tab_lg = ix.ktab_lg;
-    p.lsum32 = ix.klsum32;
-    p.lsum_shift = 0;
   }
   const int min_waves = big ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : 8));
   const uint64_t wpb = big ? 16 : 8;

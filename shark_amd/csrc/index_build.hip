@@ -188,78 +188,22 @@ __global__ __launch_bounds__(256) void table_build_kernel(const uint64_t *__rest
     const ListEntry le = ent[r];
     const bool multi = le.len != 1;
     // slot: tag(24) | valid (bit 39) | displacement (6) in the high word -- the word the kernel compares --
-    // and multi (bit 31) | rank or gene in the low word
+    // and multi (bit 31) | overflow (bit 30, slot 0 of a bucket, see kmer_device.hpp) | rank or gene in the low word
     const uint64_t base = ((pos >> tab_lg) << 40) | (1ull << 39) | ((uint64_t)multi << 31) | (uint64_t)(multi ? r : (uint32_t)le.gene0);
-    uint64_t bkt = pos & bmask;
+    const uint64_t home = pos & bmask;
+    uint64_t bkt = home;
     bool done = false;
     for (uint32_t d = 0; d < 64 && !done; ++d) {
       const unsigned long long e = base | ((unsigned long long)d << 32);
       for (int sidx = 0; sidx < 2 && !done; ++sidx)
         done = atomicCAS(&tab[2 * bkt + sidx], 0ull, e) == 0ull;
+      // placed behind its home bucket: mark that bucket (both its slots are taken and final, so the OR races with nothing)
+      if (done && d) atomicOr(&tab[2 * home], (unsigned long long)TAB_OVERFLOW);
       bkt = (bkt + 1) & bmask;
     }
     if (!done) atomicAdd(fail, 1u);
     ++r;
   }
-}
-
-// ---------------------------------------------------------------------------
-// The k-mer-keyed table.  For k <= 18 the universe of canonical k-mers is small enough (4^17 / 2 = 8.6e9) to ask the
-// finished filter about every one of them: X is a key iff bit (XXH64(X) mod B) is set -- whether X is a k-mer of some gene
-// or one of the filter's false positives makes no difference to BF::get_index (bloomfilter.h:78-102), and none here.  A
-// read's k-mer is then looked up by VALUE: no hash, no position, the same list.  Exact by construction; the filter stays
-// the ground truth it was derived from (and what the tests compare word for word).
-//   PASS 0 counts the keys, PASS 1 inserts them and sets the LDS summary's bits (keyed by kmer_mix).
-// ---------------------------------------------------------------------------
-constexpr int KE_THREADS = 256;
-template <int PASS>
-__global__ __launch_bounds__(KE_THREADS) void kmer_enum_kernel(uint32_t k, uint64_t universe, const uint64_t *__restrict__ bf64, uint64_t bf_bits,
-                                                               uint64_t bf_mask, int pow2, uint32_t mod_fast, uint32_t mod_shift, uint32_t mod_m,
-                                                               uint64_t mod_c, const uint32_t *__restrict__ psum32, uint32_t psum_shift,
-                                                               const uint32_t *__restrict__ rank_w, const ListEntry *__restrict__ ent,
-                                                               unsigned long long *__restrict__ ktab, uint32_t ktab_lg,
-                                                               uint32_t *__restrict__ klsum32, uint32_t klsum_log2,
-                                                               unsigned long long *__restrict__ n_keys, uint32_t *__restrict__ fail)
-{
-  // the position-keyed 2^18-bit summary (when the index has one) proves most candidates clear without touching memory
-  __shared__ uint32_t lsum[LDS_SUM_BITS / 32];
-  if (psum32) {
-    for (uint32_t i = threadIdx.x; i < LDS_SUM_BITS / 32; i += KE_THREADS) lsum[i] = psum32[i];
-    __syncthreads();
-  }
-  const uint64_t stride = (uint64_t)gridDim.x * KE_THREADS;
-  const uint32_t nb = kmer_nb(k);
-  uint32_t mine = 0;
-  for (uint64_t x = (uint64_t)blockIdx.x * KE_THREADS + threadIdx.x; x < universe; x += stride) {
-    const uint64_t rc = revcomp_left_aligned(x << (64 - 2 * k), k);
-    if (x > rc) continue;                                   // only canonical k-mers are ever looked up (KmerBuilder.hpp:49)
-    const uint64_t h = xxh64_u64(x);
-    const uint64_t pos = pow2 ? (h & bf_mask) : (mod_fast ? bf_pos_fastmod(h, mod_shift, mod_m, mod_c) : h % bf_bits);
-    if (psum32) {
-      const uint32_t si = (uint32_t)(pos >> psum_shift);
-      if (!((lsum[si >> 5] >> (si & 31)) & 1u)) continue;
-    }
-    const uint64_t word = bf64[pos >> 6];
-    if (!((word >> (pos & 63)) & 1ull)) continue;
-    if (PASS == 0) {
-      ++mine;
-    } else {
-      const uint32_t r = rank_w[pos >> 6] + (uint32_t)__builtin_popcountll(word & ((1ull << (pos & 63)) - 1ull));
-      const ListEntry le = ent[r];
-      const bool multi = le.len != 1;
-      const unsigned long long e = kmer_slot(x, nb, multi, multi ? r : (uint32_t)le.gene0);
-      const uint32_t hx = kmer_mix(x);
-      bool done = false;
-      for (uint32_t d = 0; d < 64 && !done; ++d) {
-        const uint32_t bkt = kmer_bucket(x, hx, d, ktab_lg, nb);
-        for (int sidx = 0; sidx < 2 && !done; ++sidx) done = atomicCAS(&ktab[2 * (uint64_t)bkt + sidx], 0ull, e) == 0ull;
-      }
-      if (!done) atomicAdd(fail, 1u);
-      const uint32_t si = hx >> (32 - klsum_log2);
-      atomicOr(&klsum32[si >> 5], 1u << (si & 31));
-    }
-  }
-  if (PASS == 0 && mine) atomicAdd(n_keys, (unsigned long long)mine);
 }
 
 static unsigned grid_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -411,7 +355,7 @@ int build_index(Ctx *ctx)
   ix.tab_lg = 0;
   uint64_t table_bytes = 0;
   const char *force = getenv("SHK_PROBE");   // "bitvector" disables the table (tests exercise both paths)
-  if (n_set > 0 && !(force && force[0] == 'b')) {   // (any filter size: buckets and tags are cut from the position, not from the hash)
+  if (n_set > 0 && n_set <= TAB_PAYLOAD && !(force && force[0] == 'b')) {   // (any filter size: buckets and tags are cut from the position, not from the hash)
     uint32_t lgB = 0;
     while ((1ull << lgB) < ix.bf_bits) ++lgB;
     uint32_t lg = 9;                                        // >= 512 buckets
@@ -420,7 +364,10 @@ int build_index(Ctx *ctx)
     // 10 M pairs; random lookups run at 266 G/s from L2 against 55-80 G/s behind it, tools/gather_bench)
     // (denser is worse even where it would bring the table back into L2: at load 0.46-0.6 the probe paths behind full home
     //  buckets diverge, 100 genes 19.4 -> 25-34 ms, 130 genes 22.7 -> 31-51 ms)
-    while ((2ull << lg) * 3ull < 10ull * n_set) ++lg;
+#ifndef SHK_TAB_LOAD10
+#define SHK_TAB_LOAD10 3
+#endif
+    while ((2ull << lg) * SHK_TAB_LOAD10 < 10ull * n_set) ++lg;
     if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
     if (lg < lgB && lg <= 31) {                             // (bucket indices are 32-bit in the kernel)
       const uint64_t slots = 2ull << lg;
@@ -513,70 +460,6 @@ int build_index(Ctx *ctx)
     BI_HIP(hipGetLastError());
   }
   BI_HIP(hipStreamSynchronize(st));
-
-  // ---- k-mer-keyed table (see kmer_enum_kernel) ---------------------------------
-  // worth its build time where the classify kernel is bound by instruction issue, i.e. on indices sparse enough for an
-  // LDS summary; the universe must not dwarf the filter (else most keys would be false positives): 4^k / 2 <= 2 B
-  ix.ktab_lg = 0;
-  ix.klsum_log2 = 0;
-  if (k <= 18 && n_set > 0 && ix.tab_lg && (ix.lsum_shift || ix.lbig_shift) && !getenv("SHK_NO_KMER_TABLE") &&
-      !(force && force[0] == 'b')) {
-    const uint64_t universe = 1ull << (2 * k);
-    if (universe / 2 <= 2 * ix.bf_bits || universe <= (1ull << 20)) {
-      unsigned long long *d_nk = nullptr;
-      uint32_t *d_fail = nullptr;
-      BI_HIP(hipMalloc((void **)&d_nk, sizeof(unsigned long long)));
-      BI_HIP(hipMalloc((void **)&d_fail, sizeof(uint32_t)));
-      BI_HIP(hipMemsetAsync(d_nk, 0, sizeof(unsigned long long), st));
-      BI_HIP(hipMemsetAsync(d_fail, 0, sizeof(uint32_t), st));
-      uint32_t mod_fast = 0, mod_shift = 0, mod_m = 0;
-      uint64_t mod_c = 0;
-      if (!ix.pow2) {
-        mod_shift = (uint32_t)__builtin_ctzll(ix.bf_bits);
-        const uint64_t m = ix.bf_bits >> mod_shift;
-        mod_fast = mod_shift >= 32 && m < (1ull << 32);
-        mod_m = mod_fast ? (uint32_t)m : 0;
-        mod_c = mod_fast ? 0xFFFFFFFFFFFFFFFFull / m + 1 : 0;
-      }
-      const unsigned egrid = (unsigned)std::min<uint64_t>(4096, std::max<uint64_t>(1, universe / KE_THREADS));
-      const uint32_t *psum = ix.lsum_shift ? ix.lsum32 : nullptr;
-      hipLaunchKernelGGL(kmer_enum_kernel<0>, dim3(egrid), dim3(KE_THREADS), 0, st, k, universe, (const uint64_t *)ix.bf64, ix.bf_bits, ix.bf_bits - 1,
-                         ix.pow2 ? 1 : 0, mod_fast, mod_shift, mod_m, mod_c, psum, ix.lsum_shift, (const uint32_t *)ix.rank_w, (const ListEntry *)ix.ent,
-                         (unsigned long long *)nullptr, 0u, (uint32_t *)nullptr, 18u, d_nk, d_fail);
-      BI_HIP(hipGetLastError());
-      unsigned long long n_keys = 0;
-      BI_HIP(hipMemcpyAsync(&n_keys, d_nk, sizeof(n_keys), hipMemcpyDeviceToHost, st));
-      BI_HIP(hipStreamSynchronize(st));
-      ix.n_keys = n_keys;
-      auto kpass = [&](uint32_t lg) { return 1.0 - std::exp(-(double)n_keys / (double)(1ull << lg)); };
-      const uint32_t ksl = kpass(18) <= 0.30 ? 18u : (kpass(20) <= 0.30 ? 20u : 0u);
-      if (n_keys > 0 && ksl) {
-        uint32_t lg = 9;
-        while ((2ull << lg) * 3ull < 10ull * n_keys) ++lg;   // load <= 0.30, as the position table
-        const uint64_t slots = 2ull << lg;
-        BI_HIP(hipMalloc((void **)&ix.ktab, (slots + 2) * sizeof(uint64_t)));
-        BI_HIP(hipMemsetAsync(ix.ktab, 0, (slots + 2) * sizeof(uint64_t), st));
-        BI_HIP(hipMalloc((void **)&ix.klsum32, ((1u << ksl) / 32 + 2) * sizeof(uint32_t)));
-        BI_HIP(hipMemsetAsync(ix.klsum32, 0, ((1u << ksl) / 32 + 2) * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(kmer_enum_kernel<1>, dim3(egrid), dim3(KE_THREADS), 0, st, k, universe, (const uint64_t *)ix.bf64, ix.bf_bits, ix.bf_bits - 1,
-                           ix.pow2 ? 1 : 0, mod_fast, mod_shift, mod_m, mod_c, psum, ix.lsum_shift, (const uint32_t *)ix.rank_w, (const ListEntry *)ix.ent,
-                           reinterpret_cast<unsigned long long *>(ix.ktab), lg, ix.klsum32, ksl, d_nk, d_fail);
-        BI_HIP(hipGetLastError());
-        uint32_t h_fail = 0;
-        BI_HIP(hipMemcpyAsync(&h_fail, d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        BI_HIP(hipStreamSynchronize(st));
-        if (h_fail == 0) {
-          ix.ktab_lg = lg;
-          ix.klsum_log2 = ksl;
-        } else {
-          (void)hipFree(ix.ktab); ix.ktab = nullptr;
-          (void)hipFree(ix.klsum32); ix.klsum32 = nullptr;
-        }
-      }
-      (void)hipFree(d_nk);
-      (void)hipFree(d_fail);
-    }
-  }
 
   cleanup();
 #undef BI_HIP

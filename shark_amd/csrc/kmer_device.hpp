@@ -54,31 +54,11 @@ __host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t v)
   return h;
 }
 
-// ---------------------------------------------------------------------------
-// The k-mer-keyed table (k <= 18; index_build.hip / classify.hip): a cheap 32-bit mix of a canonical k-mer (< 2^36).
-// Summary index = top bits, bucket = the folded low bits.  One slow multiply instead of XXH64's fifteen.
-// ---------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint32_t kmer_mix(uint64_t x)
-{
-  return (uint32_t)x * 0x9E3779B1u ^ ((uint32_t)(x >> 32) & 0xFFu) * 0x85EBCAu;
-}
-// A k-mer has 2k <= 36 bits.  The slot's compare word holds its top 32 bits (+1, so that 0 stays "empty": a canonical k-mer
-// never has 32 leading one bits -- it would start with 16 T, and its reverse complement, ending in 16 A, would be smaller);
-// the nb = max(0, 2k - 32) low bits are implied by WHERE the slot is: the table is 2^nb sub-tables, selected by those bits,
-// each a ring of buckets with its own linear probing.  So a slot looks exactly like the position table's -- one 32-bit
-// compare per slot, 0 = empty, low word = multi(1) | gene-or-rank(31) -- and needs no displacement field.
-__host__ __device__ __forceinline__ uint32_t kmer_nb(uint32_t k) { return 2u * k > 32u ? 2u * k - 32u : 0u; }
-__host__ __device__ __forceinline__ uint32_t kmer_want(uint64_t x, uint32_t nb) { return (uint32_t)(x >> nb) + 1u; }
-// bucket of probe step d (d = 0: home) in a table of 2^lg buckets
-__host__ __device__ __forceinline__ uint32_t kmer_bucket(uint64_t x, uint32_t h, uint32_t d, uint32_t lg, uint32_t nb)
-{
-  const uint32_t sub_lg = lg - nb, submask = (1u << sub_lg) - 1u;
-  return (((uint32_t)x & ((1u << nb) - 1u)) << sub_lg) | (((h ^ (h >> 16)) + d) & submask);
-}
-__host__ __device__ __forceinline__ uint64_t kmer_slot(uint64_t x, uint32_t nb, bool multi, uint32_t payload)
-{
-  return ((uint64_t)kmer_want(x, nb) << 32) | ((uint64_t)multi << 31) | (uint64_t)(payload & 0x7FFFFFFFu);
-}
+// Low word of a position-table slot: multi(1) | overflow(1) | gene-or-rank(30).  TAB_OVERFLOW is kept in slot 0 of a
+// bucket and says that some key whose HOME this bucket is was placed further down its probe path: a search that finds
+// nothing at home and no such mark is over, however full the bucket is (at load 0.3 a bucket is full for 12 % of the
+// probes but overflowed for 2 %).
+constexpr uint32_t TAB_OVERFLOW = 1u << 30, TAB_PAYLOAD = 0x3FFFFFFFu;
 
 // ---------------------------------------------------------------------------
 // Base classification, 4 ASCII bytes at a time (SWAR).

@@ -66,14 +66,6 @@ struct DeviceIndex {
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
   bool tab_with_summary = false;
-  // k <= 18 and a sparse filter: EVERY canonical k-mer whose filter bit is set -- the reference's k-mers and the Bloom
-  // filter's false positives alike -- enumerated at build time into a table keyed by the k-mer (index_build.hip), with an
-  // LDS summary keyed by the same cheap hash; the classify kernel then needs no XXH64 at all
-  uint64_t *ktab = nullptr;
-  uint32_t ktab_lg = 0;       // log2(buckets); 0 = not built
-  uint32_t *klsum32 = nullptr;
-  uint32_t klsum_log2 = 0;    // 18 or 20
-  uint64_t n_keys = 0;
   uint64_t n_set = 0;
   uint64_t tot_idx = 0;
   bool wrap = false;         // more than 65 536 genes: lists sorted by 16-bit id WITH duplicates (index_build.hip), WRAP kernels

@@ -120,8 +120,7 @@ def test_synthetic_parity(oracle, probe, k, bf_bits, paired, read_len):
         assert "table" not in h.probe_mode()
     else:
         assert "table" in h.probe_mode()
-        if "kmer" not in h.probe_mode():      # (the k-mer-keyed table has no positions, so no remainder either)
-            assert h.probe_mode().endswith("-mod") == bool(bf_bits & (bf_bits - 1))
+        assert h.probe_mode().endswith("-mod") == bool(bf_bits & (bf_bits - 1))
     _compare_index(o, h, info)
     batch = synth.make_reads(rng, genes, 3000, read_len=read_len, paired=paired, on_target=0.6,
                              n_rate=0.01, lower_rate=0.05, var_len=True)
@@ -576,7 +575,7 @@ def test_cli_filter_size_not_a_power_of_two(oracle, bf_bits):
     rng = np.random.default_rng(4242)
     genes = synth.make_genes(rng, 30, 300, 2000, share_every=3)
     o, h, info = _build_both(oracle, genes, k=17, bf_bits=bf_bits)
-    assert h.probe_mode() in ("table-mod", "lds-summary+table-mod", "lds-summary+kmer-table")
+    assert h.probe_mode() in ("table-mod", "lds-summary+table-mod")
     _compare_index(o, h, info)
     batch = synth.make_reads(rng, genes, 4000, read_len=150, paired=True, on_target=0.5, n_rate=0.005)
     goff, _ = _compare_classify(o, h, batch)
@@ -807,9 +806,7 @@ def test_panel_sized_index_uses_the_big_lds_summary(oracle, bf_bits, monkeypatch
     rng = np.random.default_rng(2020)
     genes = synth.make_genes(rng, 100, 2000, 3000, share_every=5)
     o, h, info = _build_both(oracle, genes, k=17, bf_bits=bf_bits)
-    # (the position-keyed index reports its ordinary chain; where the filter is sparse enough for the k-mer-keyed table, the
-    # 2^20-bit summary is that table's own)
-    assert 180_000 < info["n_set_bits"] < 330_000 and h.probe_mode() in ("table", "table-mod", "lds-summary+kmer-table")
+    assert 180_000 < info["n_set_bits"] < 330_000 and "lds" not in h.probe_mode()
     uni = synth.make_reads(rng, genes, 3000, read_len=150, paired=True, on_target=0.6)
     rag = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.6, var_len=True)
     se = synth.make_reads(rng, genes, 1500, read_len=100, paired=False, on_target=0.6)
