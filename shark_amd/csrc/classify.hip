@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         more[j] = !mt[j] & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
         lane_more |= more[j];
       }
-      if (__ballot(lane_more)) {
+      if (__ballot(lane_more) && !SHK_ABL(P, 8u)) {   // (ablation 8: no walks)
         // rare: the key may sit behind its (full) home bucket.  Round d looks at bucket home+d of every probe that is
         // still searching, all U loads in flight together (the others read the spare bucket: one line for the wave) --
         // a memory round trip per displacement, not per probe.
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           }
         } while (__ballot(lane_more));
       }
-      if (__ballot(lane_any)) {
+      if (__ballot(lane_any) && !SHK_ABL(P, 16u)) {   // (ablation 16: no hit path)
         // ================= something matched in the table: the hit path =================
         KernargParams H = kernarg_params();
         const uint32_t hk = H->k;
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #pragma unroll
             for (int j = 0; j < U; ++j) mymin = cur[j] < mymin ? cur[j] : mymin;
             const uint32_t g = wave_min_u32(mymin);
-            if (g == GENE_INF) break;
+            if (g == GENE_INF || SHK_ABL(P, 32u)) break;   // (ablation 32: no merge)
             uint32_t nk = 0, cov = 0;
             auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
               const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           // ---- threshold + --single (ReadAnalyzer.hpp:104) ----
           uint32_t n_out = 0;
           if (n_best > 0 && (double)best_cov >= H->c * (double)len && (!H->single || n_best == 1)) n_out = n_best;
-          if (n_out > 0 && lane == 0) {
+          if (n_out > 0 && lane == 0 && !SHK_ABL(P, 64u)) {   // (ablation 64: no result store)
             const ClassifyOut *O = H->out;
             O->count[read] = n_out;
             uint2 pk;

@@ -364,10 +364,14 @@ int build_index(Ctx *ctx)
     // 10 M pairs; random lookups run at 266 G/s from L2 against 55-80 G/s behind it, tools/gather_bench)
     // (denser is worse even where it would bring the table back into L2: at load 0.46-0.6 the probe paths behind full home
     //  buckets diverge, 100 genes 19.4 -> 25-34 ms, 130 genes 22.7 -> 31-51 ms)
-#ifndef SHK_TAB_LOAD10
-#define SHK_TAB_LOAD10 3
+    while ((2ull << lg) * 3ull < 10ull * n_set) ++lg;
+    // ... and while the table stays small (2 MiB: half of an XCD's L2) it may as well be roomy, down to a load of 0.05: the
+    // searches that leave their home bucket -- a dependent memory round trip for the whole wave -- become that much rarer
+    // (20 000 k-mers, load 0.15 -> 0.076: 0 / 50 / 100 % on-target 7.8 / 9.8 / 13.0 -> 7.1 / 9.5 / 12.2 ms per 10 M pairs)
+#ifndef SHK_TAB_ROOMY_LG
+#define SHK_TAB_ROOMY_LG 17
 #endif
-    while ((2ull << lg) * SHK_TAB_LOAD10 < 10ull * n_set) ++lg;
+    while (lg < SHK_TAB_ROOMY_LG && (2ull << lg) < 20ull * n_set) ++lg;
     if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
     if (lg < lgB && lg <= 31) {                             // (bucket indices are 32-bit in the kernel)
       const uint64_t slots = 2ull << lg;
