@@ -895,12 +895,15 @@ __device__ __forceinline__ KernargParams kernarg_params()
 // genes); 20 = 128 KiB shared by ONE 1024-thread workgroup per CU -- four times the reach (pass rate <= 30 % up to ~3x10^5
 // set bits, i.e. panels of a hundred genes) at 4 waves per SIMD, for indices that would otherwise probe an L2-resident
 // summary through the vector L1 (one cache line per clock per CU) for every k-mer.
+#ifndef SHK_TAB_WAVES
+#define SHK_TAB_WAVES 8
+#endif
 template <int U, int MODE, int LSL>
 struct UniGeom {
   static constexpr int WAVES = (pm_lds(MODE) && LSL == 20) ? 16 : 8;
   static constexpr int THREADS = WAVES * 64;
   // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes are latency bound: 8 waves per SIMD
-  static constexpr int MIN_WAVES = WAVES == 16 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : 8));
+  static constexpr int MIN_WAVES = WAVES == 16 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
   static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (1u << LSL) : 0u;
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };
@@ -1145,44 +1148,53 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           bk[j] = load_bucket<LSUM && UNI>(tab16, bi);   // (the ragged instantiation runs out of registers with the short addresses)
         }
       }
-      // each probe keeps one word of its bucket: the low word of the slot that matched (mt[j] says whether one did)
+      // each probe ends up with one word of its bucket: the low word of the slot that matched (mt[j] says whether one did)
       bool lane_any = false, lane_more = false;
       bool more[U], mt[U];
       uint32_t slo[U];
+      // ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) settle that right away and walk
+      // all their probes per round; the 64-VGPR ones keep the buckets until the hit path and walk probe by probe
+      constexpr bool ROUNDS = LSUM;
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const uint32_t want = want_of(j);
         const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
-        mt[j] = m0 | m1;
-        slo[j] = m0 ? bk[j].x : bk[j].z;
-        lane_any |= mt[j];
-        more[j] = !mt[j] & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
+        if (ROUNDS) {
+          mt[j] = m0 | m1;
+          slo[j] = m0 ? bk[j].x : bk[j].z;
+        }
+        lane_any |= m0 | m1;
+        more[j] = !(m0 | m1) & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
         lane_more |= more[j];
       }
       if (__ballot(lane_more) && !SHK_ABL(P, 8u)) {   // (ablation 8: no walks)
-        // rare: the key may sit behind its (full) home bucket.  Round d looks at bucket home+d of every probe that is
-        // still searching, all U loads in flight together (the others read the spare bucket: one line for the wave) --
-        // a memory round trip per displacement, not per probe.
+        // rare: the key may sit behind its (full) home bucket
         auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
-        uint32_t d = 0;
-        do {
-          ++d;
+        if (ROUNDS) {
+          // round d looks at bucket home+d of every probe that is still searching, all U loads in flight together (the
+          // others read the spare bucket: one line for the wave) -- a memory round trip per displacement, not per probe
+          uint32_t d = 0;
+          do {
+            ++d;
 #pragma unroll
-          for (int j = 0; j < U; ++j) bk[j] = load_bucket<LSUM && UNI>(tab16, more[j] ? bucket_of(j, d) : spare);
-          lane_more = false;
+            for (int j = 0; j < U; ++j) bk[j] = load_bucket<LSUM && UNI>(tab16, more[j] ? bucket_of(j, d) : spare);
+            lane_more = false;
 #pragma unroll
-          for (int j = 0; j < U; ++j) {
-            const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
-            const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
-            const bool found = more[j] & (n0 | n1);
-            const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
-            slo[j] = found ? (n0 ? bk[j].x : bk[j].z) : slo[j];
-            mt[j] |= found;
-            lane_any |= found;
-            more[j] = more[j] & !found & !ends;
-            lane_more |= more[j];
-          }
-        } while (__ballot(lane_more));
+            for (int j = 0; j < U; ++j) {
+              const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
+              const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
+              const bool found = more[j] & (n0 | n1);
+              const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
+              slo[j] = found ? (n0 ? bk[j].x : bk[j].z) : slo[j];
+              mt[j] |= found;
+              lane_any |= found;
+              more[j] = more[j] & !found & !ends;
+              lane_more |= more[j];
+            }
+          } while (__ballot(lane_more));
+        } else {
+          walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of);   // (a key found is moved into bk[j] in home form)
+        }
       }
       if (__ballot(lane_any) && !SHK_ABL(P, 16u)) {   // (ablation 16: no hit path)
         // ================= something matched in the table: the hit path =================
@@ -1201,6 +1213,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           const uint32_t V = pp >> 6, vs = pp & 63u;
           const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
           const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+          if (!ROUNDS) {
+            const uint32_t want = want_of(j);
+            const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+            mt[j] = m0 | m1;
+            slo[j] = m0 ? bk[j].x : bk[j].z;
+          }
           hit[j] = LSUM ? (mt[j] & exists & ((win & kmask) == kmask)) : mt[j];   // (table modes settled that before the probe)
           any2 |= hit[j];
           payload[j] = slo[j] & TAB_PAYLOAD;
@@ -1611,7 +1629,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lsum32 = ctx->idx.lbig32;
     p.lsum_shift = ctx->idx.lbig_shift;
   }
-  const int min_waves = big ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : 8));
+  const int min_waves = big ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
   const uint64_t wpb = big ? 16 : 8;
   const uint64_t cap = big ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
