@@ -92,7 +92,8 @@ int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
  * "lds-summary+table", and for filter sizes that are not a power of two
  * "table-mod", "lds-summary+table-mod"
  * (every mode returns exactly the filter's bit).  Environment
- * SHK_PROBE=bitvector at finalize time disables the table (tests use it). */
+ * SHK_PROBE=bitvector at finalize time disables the table, SHK_TAB_DENSE=1
+ * builds it at up to 0.8 load (long probe paths); both are for the tests. */
 const char *shk_probe_mode(const shk_ctx *ctx);
 
 /* Parity introspection: copy the device-resident index to host buffers.

@@ -359,23 +359,25 @@ int build_index(Ctx *ctx)
     uint32_t lgB = 0;
     while ((1ull << lgB) < ix.bf_bits) ++lgB;
     uint32_t lg = 9;                                        // >= 512 buckets
-    // smallest power of two with a load factor <= 0.30: short probe paths (an empty slot ends a search), and panel-sized
-    // indices keep their table inside an XCD's L2 one size longer (60 genes: 4 MiB instead of 8, 23.2 -> 19.9 ms per
-    // 10 M pairs; random lookups run at 266 G/s from L2 against 55-80 G/s behind it, tools/gather_bench)
-    // (denser is worse even where it would bring the table back into L2: at load 0.46-0.6 the probe paths behind full home
-    //  buckets diverge, 100 genes 19.4 -> 25-34 ms, 130 genes 22.7 -> 31-51 ms)
+    // Smallest power of two with a load factor <= 0.30 -- and roomier while the table stays small, because a search that
+    // leaves its home bucket is a dependent memory round trip for the whole wave: down to a load of 0.05 up to 2 MiB (half
+    // of an XCD's L2), and of 0.15 up to 8 MiB, where random lookups still run at 121 G/s (82 G/s at 16 MiB, 55 G/s beyond;
+    // tools/gather_bench).  Per 10 M pairs, 50 % on-target (profiles/README.md):
+    //   20 000 k-mers: load 0.15 -> 0.076: 9.8 -> 9.3 ms;   71 000: 2 MiB, 0.27 -> 4 MiB, 0.14: 13.6 -> 11.8 ms;
+    //   143 000: 4 MiB, 0.27 -> 8 MiB, 0.14: 18.1 -> 12.6 ms;   238 000: 8 MiB, 0.23 stays (16 MiB, 0.11: 16.4 -> 19.7 ms)
+    // Denser than 0.30 is worse even where it would bring the table back into L2 (load 0.46: 100 genes 16.3 -> 22.0 ms).
+    // SHK_TAB_DENSE=1 (tests): load up to 0.8, so that long probe paths are exercised.
 #ifndef SHK_TAB_LOAD10
 #define SHK_TAB_LOAD10 3
 #endif
-    while ((2ull << lg) * SHK_TAB_LOAD10 < 10ull * n_set) ++lg;
-    // ... but roomier while the table stays small, because a search that leaves its home bucket is a dependent memory round
-    // trip for the whole wave: down to a load of 0.05 up to 2 MiB (half of an XCD's L2), and of 0.15 up to 8 MiB, where
-    // random lookups still run at 121 G/s (82 G/s at 16 MiB, tools/gather_bench).  Per 10 M pairs, 50 % on-target:
-    //   20 000 k-mers: load 0.15 -> 0.076: 9.8 -> 9.3 ms;   71 000: 2 MiB, 0.27 -> 4 MiB, 0.14: 13.6 -> 11.8 ms;
-    //   143 000: 4 MiB, 0.27 -> 8 MiB, 0.14: 18.1 -> 12.6 ms;   238 000: 8 MiB, 0.23 stays (16 MiB, 0.11: 16.4 -> 19.7 ms)
-    // (never beyond half of the filter's positions: bucket index and tag are cut from the position)
-    while (lg < 17 && lg + 1 < lgB && (2ull << lg) < 20ull * n_set) ++lg;
-    while (lg < 19 && lg + 1 < lgB && (2ull << lg) * 3ull < 20ull * n_set) ++lg;
+    if (getenv("SHK_TAB_DENSE")) {
+      while ((2ull << lg) * 8ull < 10ull * n_set) ++lg;
+    } else {
+      while ((2ull << lg) * SHK_TAB_LOAD10 < 10ull * n_set) ++lg;
+      // (never beyond half of the filter's positions: bucket index and tag are cut from the position)
+      while (lg < 17 && lg + 1 < lgB && (2ull << lg) < 20ull * n_set) ++lg;
+      while (lg < 19 && lg + 1 < lgB && (2ull << lg) * 3ull < 20ull * n_set) ++lg;
+    }
     if (lgB > 24 && lg < lgB - 24) lg = lgB - 24;           // tag must fit 24 bits
     if (lg < lgB && lg <= 31) {                             // (bucket indices are 32-bit in the kernel)
       const uint64_t slots = 2ull << lg;

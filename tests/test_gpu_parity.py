@@ -819,6 +819,36 @@ def test_panel_sized_index_uses_the_big_lds_summary(oracle, bf_bits, monkeypatch
         assert np.array_equal(g2, wg) and np.array_equal(i2, wi)
 
 
+@pytest.mark.parametrize("k,bf_bits,n_bases", [
+    (17, 1 << 33, 25_600),      # lds-summary+table: walks per round; 25 584 keys in 32 768 slots
+    (17, 5 << 32, 25_600),      # the same with hash % size
+    (17, 1 << 26, 410_000),     # summary+table / table: probe-by-probe walk in the 64-VGPR instantiations; load 0.78
+    (21, 1 << 30, 200_000),     # uniform batches: 128 KiB LDS summary; load 0.76
+])
+def test_dense_table_long_probe_paths(oracle, k, bf_bits, n_bases, monkeypatch):
+    """SHK_TAB_DENSE=1 builds the position table at up to 0.8 load: most home buckets are full, a fifth of the keys live
+    behind theirs, probe paths run over several buckets (the overflow mark, both walk forms, the match in either slot of a
+    later bucket, the empty slot that ends a search).  Uniform, trimmed and single-end batches -- every kernel that reads
+    the table -- must still equal the oracle, and the index must equal the oracle's word for word."""
+    monkeypatch.setenv("SHK_TAB_DENSE", "1")
+    rng = np.random.default_rng(n_bases + k)
+    n_genes = 8
+    genes = synth.make_genes(rng, n_genes, n_bases // n_genes, n_bases // n_genes + 1, share_every=3)
+    o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits)
+    assert "table" in h.probe_mode()
+    slots = 1024
+    while slots * 8 < 10 * info["n_set_bits"]:
+        slots *= 2
+    assert info["n_set_bits"] / slots > 0.55, "the case is meant to load the table heavily"
+    _compare_index(o, h, info)
+    for b in (synth.make_reads(rng, genes, 4000, read_len=150, paired=True, on_target=0.7),
+              synth.make_reads(rng, genes, 3000, read_len=150, paired=True, on_target=0.7, var_len=True, n_rate=0.01),
+              synth.make_reads(rng, genes, 2000, read_len=100, paired=False, on_target=0.7),
+              synth.make_reads(rng, genes, 1500, read_len=250, paired=True, on_target=0.7)):
+        goff, _ = _compare_classify(o, h, b)
+        assert goff[-1] > 0
+
+
 @pytest.mark.parametrize("shape", ["fixed_width", "ragged", "second_file_shorter", "first_file_shorter_no_final_newline", "bgzf", "single_end_gz"])
 def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
     """every way the CLI gets its reads -- arithmetic offsets of fixed-width records, the parallel newline count, the pair
