@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs.
-usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128")"""
+usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var"""
 import json, os, subprocess, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,28 +18,35 @@ td = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
 open(os.path.join(td, "g.fa"), "wb").write(b">gene0\n" + gene.tobytes() + b"\n")
 
 
+VAR = os.environ.get("HEADERS", "fixed") == "var"   # read names without zero padding: records of several widths (the general reader)
+
+
 def write_fastq(path, mate):
-    # whole file as one (n, record) byte matrix: "@r<9 digits>/m\n" + seq + "\n+\n" + qual + "\n"
-    W = 13 + 1 + L + 3 + L + 1
+    # runs of records of one width as (m, W) byte matrices: "@r<digits>/m\n" + seq + "\n+\n" + qual + "\n"
     chunk = 1_000_000
     with open(path, "wb") as f:
-        for b0 in range(0, n, chunk):
-            m = min(chunk, n - b0)
+        b0 = 0
+        while b0 < n:
+            nd = len(str(b0)) if VAR else 9
+            m = min(chunk, n - b0, (10 ** nd - b0) if VAR else n)
+            H = 2 + nd + 3                                   # "@r" digits "/m\n"
+            W = H + L + 3 + L + 1
             rec = np.empty((m, W), dtype=np.uint8)
             rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
             idx = np.arange(b0, b0 + m, dtype=np.int64)
-            for d in range(9):
-                rec[:, 2 + d] = ord("0") + (idx // 10 ** (8 - d)) % 10
-            rec[:, 11] = ord("/"); rec[:, 12] = ord("0") + mate; rec[:, 13] = 10
+            for d in range(nd):
+                rec[:, 2 + d] = ord("0") + (idx // 10 ** (nd - 1 - d)) % 10
+            rec[:, H - 3] = ord("/"); rec[:, H - 2] = ord("0") + mate; rec[:, H - 1] = 10
             prng = np.random.default_rng(1000 + b0)          # the same pairs are on-target in both mate files
             on = prng.random(m) < on_target
             st = prng.integers(0, len(gene) - 400, size=m)
             seqs = np.where(on[:, None], gene[st[:, None] + np.arange(L)[None, :]], acgt[rng.integers(0, 4, size=(m, L))])
-            rec[:, 14:14 + L] = seqs
-            rec[:, 14 + L] = 10; rec[:, 15 + L] = ord("+"); rec[:, 16 + L] = 10
-            rec[:, 17 + L:17 + 2 * L] = ord("I")
-            rec[:, 17 + 2 * L] = 10
+            rec[:, H:H + L] = seqs
+            rec[:, H + L] = 10; rec[:, H + L + 1] = ord("+"); rec[:, H + L + 2] = 10
+            rec[:, H + L + 3:H + 2 * L + 3] = ord("I")
+            rec[:, H + 2 * L + 3] = 10
             rec.tofile(f)
+            b0 += m
 
 
 t0 = time.time()
@@ -56,6 +63,6 @@ for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
                            stdout=so, stderr=subprocess.PIPE)
     dt = time.time() - t0
     print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
-                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args,
+                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "headers": "var" if VAR else "fixed",
                       "stderr_tail": r.stderr.decode()[-500:]}), flush=True)
 subprocess.run(["rm", "-rf", td])
