@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "kmer_device.hpp"
 #include "shark_internal.hpp"
@@ -259,10 +260,12 @@ __device__ __forceinline__ uint4 load_bucket(const uint4 *__restrict__ tab16, co
 // slots carry their displacement in the compared word.
 template <int U, bool POSKEY, typename WantOf, typename BucketOf>
 __device__ __forceinline__ void walk_probe_paths(const uint4 *__restrict__ tab16, uint4 (&bk)[U], bool (&more)[U], bool &lane_any,
-                                                 const WantOf want_of, const BucketOf bucket_of)
+                                                 const WantOf want_of, const BucketOf bucket_of, const uint32_t jlo = 0u,
+                                                 const uint32_t jhi = (uint32_t)U)
 {
 #pragma unroll
   for (int j = 0; j < U; ++j) {
+    if ((uint32_t)j < jlo || (uint32_t)j >= jhi) continue;   // (wave-uniform: the probes of the rounds being worked on)
     uint32_t d = 0;
     while (more[j]) {
       ++d;
@@ -885,6 +888,48 @@ __device__ __forceinline__ KernargParams kernarg_params()
   return p;
 }
 
+// ---- the bound cut -----------------------------------------------------------------------------------------------
+// ReadAnalyzer.hpp:104 keeps a read iff max >= c*len, where max is the largest per-gene coverage: the size of the union of
+// the intervals [p, p+k) of that gene's hits (header comment).  A gene's coverage is therefore at most the number of
+// bases covered by ALL k-mers that are in the filter.  classify_uni_kernel probes the slots of its first E rounds
+// (packed positions < 64 E) first; when none of them is in the filter, every hit the read can still have lies in the
+// remaining slots, which cover bases_behind(64 E) bases.  If that is below the threshold, no gene can reach it, the read
+// has no association whatever the remaining probes would say -- and they are not made.  (2 x 150 bp, k = 17, c = 0.6:
+// after two rounds the rest covers 22 + 150 = 172 < 180 bases, so an off-target pair costs 128 probes instead of 320.)
+// The result is the reference's for every read; tests/test_gpu_parity.py walks chimeric reads across the boundary.
+
+// the smallest integer t with (double)t >= c * (double)len: an integer coverage passes the reference's test iff it is >= t.
+// 0 when the product is not positive (or NaN): nothing can be ruled out
+__device__ __forceinline__ uint32_t cov_threshold(const double c, const uint32_t len)
+{
+  const double x = c * (double)len;
+  if (!(x > 0.0)) return 0u;
+  if (x >= 4294967295.0) return 0xFFFFFFFFu;
+  return (uint32_t)ceil(x);
+}
+
+// bases covered by the existing slots at packed positions >= s (mate 1: slots [0, nk1) cover [0, l1); mate 2 likewise at P2)
+__device__ __forceinline__ uint32_t bases_behind(const uint32_t s, const uint32_t nk1, const uint32_t nk2, const uint32_t P2,
+                                                 const uint32_t l1, const uint32_t l2)
+{
+  uint32_t u = s < nk1 ? l1 - s : 0u;
+  const uint32_t s2 = s > P2 ? s - P2 : 0u;
+  u += s2 < nk2 ? l2 - s2 : 0u;
+  return u;
+}
+
+// The number of first rounds is a compile-time constant of the code that runs (exact register liveness; a run-time split
+// keeps every round's state alive across both phases and spills).  Per U, the candidates that the usual shapes need at the
+// reference's default c = 0.6 (paired mates of equal length: about half the rounds; U = 5 is 2 x 150 bp: two rounds, three
+// for c down to 0.37; U = 3 also serves single-end 150 bp reads: one round).  A read whose bound holds for neither is probed
+// in one go.
+template <int U> struct CutPlan { static constexpr int E0 = U / 2, E1 = U / 2; };
+template <> struct CutPlan<3> { static constexpr int E0 = 1, E1 = 2; };
+template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
+// (-DSHK_NO_CUT=1: a build without the cut, for A/B timing)
+#ifndef SHK_NO_CUT
+#define SHK_NO_CUT 0
+#endif
 #ifndef SHK_UNI_WAVES
 #define SHK_UNI_WAVES 6   // 75 VGPRs, nothing spilled; at 8 waves per SIMD (64 VGPRs) the loop reloads spilled lane constants from scratch and measures 1-6 % slower
 #endif
@@ -967,6 +1012,21 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
   };
   set_geometry(L1, L2);
+  // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
+  uint32_t cutE = U, cutUb = 0;
+  auto plan_cut = [&](const uint32_t l1, const uint32_t l2) {
+    const uint32_t thr = SHK_NO_CUT ? 0u : cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
+    cutE = U;
+    cutUb = 0;
+    // bases_behind falls with e: the smaller candidate is tried last and wins when it qualifies
+    if (CutPlan<U>::E1 != CutPlan<U>::E0) {
+      const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E1, nk1, nk2, P2, l1, l2);
+      if (ub < thr) { cutE = (uint32_t)CutPlan<U>::E1; cutUb = ub; }
+    }
+    const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E0, nk1, nk2, P2, l1, l2);
+    if (ub < thr) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
+  };
+  if (UNI) plan_cut(L1, L2);
   const uint32_t b_uni = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
   const uint8_t *const sbase = (m2 ? P.seq2 : P.seq1) + b_uni;
   const uint8_t *const qbase = HASQ ? (m2 ? P.qual2 : P.qual1) + b_uni : nullptr;
@@ -1037,6 +1097,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (!skip) {
 
     // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
+    uint32_t inv_real = 0u;   // invalid characters among the lane's bases that belong to the read
     if (act) {
       const uint32_t sh = w_cur.shn & 3u;
       const uint32_t lo = __builtin_amdgcn_alignbyte(w_cur.d1, w_cur.d0, sh);
@@ -1059,143 +1120,179 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       reinterpret_cast<uint16_t *>(fw)[lane] = (uint16_t)(lsb >> 16);
       reinterpret_cast<uint16_t *>(rv)[(rcap >> 3) - 1u - (uint32_t)lane] = (uint16_t)msb16;
       reinterpret_cast<uint8_t *>(vbits)[lane] = (uint8_t)(~inv8 & 0xFFu);
+      inv_real = inv8 & ~tail_inv;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- U canonical k-mers, U hashes, U summary probes --------------------------
+    // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
+    if (!UNI) plan_cut(m_cur.L1, m_cur.L2);
+    bool cut_ok = cutE < (uint32_t)U;
+    if (cut_ok) {
+      // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
+      if (__ballot(inv_real != 0u)) {
+        const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
+        cut_ok = cutUb < cov_threshold(P.c, len);
+      }
+    }
+
+    // ---- everything behind the staging, for a compile-time E (rounds [0, E) first; E == U: all at once, no cut) ----
+    auto classify_staged = [&](auto e_const) {
+    constexpr int E = decltype(e_const)::value;
     uint64_t pos[U];
-    {
-      const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
-      const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const uint32_t *f = fw + ((uint32_t)lane >> 4) + 4 * j;
-        const uint32_t *r = rv + (qU >> 4) + 4 * (U - 1 - j);
-        const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
-        const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
-        const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
-        const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
-        const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
-        const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
-        const uint64_t hsh = xxh64_u64(canon);
-        // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
-        pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
-      }
-    }
     uint32_t okm[U];   // all ones where the slot's probe has to be made, else 0
-    bool something = false;
-    if (!LSUM) {
-      // slot pp exists and all its k characters are valid (process_read, slot_ok); then the L2-resident summary
-      const uint64_t kmask0 = (1ull << k) - 1ull;
-      bool ok[U];
+    uint4 bk[U];
+    // each probe ends up with one word of its bucket: the low word of the slot that matched (mt[j] says whether one did)
+    bool mt[U];
+    uint32_t slo[U];
+    bool lane_any = false;
+    // ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) reduce a bucket to that word right
+    // away and walk all their probes per round; the 64-VGPR ones keep the buckets until the hit path and walk probe by probe
+    constexpr bool ROUNDS = LSUM;
+    const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
+    const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
+    const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
+    const uint32_t spare = 1u << P.tab_lg;
+    // the word a slot's high word is compared with (0 = empty slot): tag | valid | displacement 0
+    auto want_of = [&](const int j) -> uint32_t {
+      const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
+      return (tag << 8) | 0x80u;
+    };
+    auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
+    // ---- canonical k-mers, hashes, summary probes, table probes of the rounds [JLO, JHI) ----
+    auto probe_rounds = [&](auto lo_const, auto hi_const) {
+      constexpr int JLO = decltype(lo_const)::value, JHI = decltype(hi_const)::value;
+      {
+        const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
+        const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const uint32_t pp = (uint32_t)lane + 64u * j;
-        const bool exists = (pp < nk1) | ((pp - P2) < nk2);
-        const uint32_t V = pp >> 6, vs = pp & 63u;
-        const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
-        const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
-        ok[j] = exists & ((win & kmask0) == kmask0);
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t *f = fw + ((uint32_t)lane >> 4) + 4 * j;
+          const uint32_t *r = rv + (qU >> 4) + 4 * (U - 1 - j);
+          const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+          const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+          const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
+          const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
+          const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+          const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
+          const uint64_t hsh = xxh64_u64(canon);
+          // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+          pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
+        }
       }
-      if (SUM) {
-        uint32_t sw[U];
+      bool something = false;
+      if (!LSUM) {
+        // slot pp exists and all its k characters are valid (process_read, slot_ok); then the L2-resident summary
+        const uint64_t kmask0 = (1ull << k) - 1ull;
+        bool ok[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t pp = (uint32_t)lane + 64u * j;
+          const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+          const uint32_t V = pp >> 6, vs = pp & 63u;
+          const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
+          const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+          ok[j] = exists & ((win & kmask0) == kmask0);
+        }
+        if (SUM) {
+          uint32_t sw[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
+          for (int j = JLO; j < JHI; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
+#pragma unroll
+          for (int j = JLO; j < JHI; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
+        }
+        bool any = false;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) { okm[j] = ok[j] ? 0xFFFFFFFFu : 0u; any |= ok[j]; }
+        something = __ballot(any) != 0ull;
+      } else {
+        uint32_t si[U], sw[U];
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
+          sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          okm[j] = (uint32_t)__builtin_amdgcn_sbfe((int)sw[j], si[j], 1u);   // v_bfe_i32: bit (si & 31), sign extended
+          any |= okm[j];
+        }
+        something = __ballot(any != 0u) != 0ull;
       }
-      bool any = false;
+      if (something) {
+        // ---- position table: the probes that passed read their home bucket, the others the spare empty bucket ----
 #pragma unroll
-      for (int j = 0; j < U; ++j) { okm[j] = ok[j] ? 0xFFFFFFFFu : 0u; any |= ok[j]; }
-      something = __ballot(any) != 0ull;
-    } else {
-      uint32_t si[U], sw[U];
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t bb = (uint32_t)pos[j] & bmask;
+          const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
+          if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
+            bk[j] = make_uint4(v.x, v.y, v.z, v.w);
+          } else {
+            bk[j] = load_bucket<LSUM && UNI>(tab16, bi);   // (the ragged instantiation runs out of registers with the short addresses)
+          }
+        }
+        bool lane_more = false;
+        bool more[U];
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
-        sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t want = want_of(j);
+          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+          if (ROUNDS) {
+            mt[j] = m0 | m1;
+            slo[j] = m0 ? bk[j].x : bk[j].z;
+          }
+          lane_any |= m0 | m1;
+          more[j] = !(m0 | m1) & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
+          lane_more |= more[j];
+        }
+        if (__ballot(lane_more) && !SHK_ABL(P, 8u)) {   // (ablation 8: no walks)
+          // rare: the key may sit behind its (full) home bucket
+          if (ROUNDS) {
+            // round d looks at bucket home+d of every probe that is still searching, all loads in flight together (the
+            // others read the spare bucket: one line for the wave) -- a memory round trip per displacement, not per probe
+            uint32_t d = 0;
+            do {
+              ++d;
+#pragma unroll
+              for (int j = JLO; j < JHI; ++j) bk[j] = load_bucket<LSUM && UNI>(tab16, more[j] ? bucket_of(j, d) : spare);
+              lane_more = false;
+#pragma unroll
+              for (int j = JLO; j < JHI; ++j) {
+                const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
+                const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
+                const bool found = more[j] & (n0 | n1);
+                const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
+                slo[j] = found ? (n0 ? bk[j].x : bk[j].z) : slo[j];
+                mt[j] |= found;
+                lane_any |= found;
+                more[j] = more[j] & !found & !ends;
+                lane_more |= more[j];
+              }
+            } while (__ballot(lane_more));
+          } else {
+            walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
+          }
+        }
+      } else {
+        // nothing of these rounds passed the summary: no matches (the hit path may still run for the other rounds)
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          if (ROUNDS) { mt[j] = false; slo[j] = 0u; }
+          else bk[j] = make_uint4(0u, 0u, 0u, 0u);   // (an empty slot's compared word is 0: matches nothing)
+        }
       }
-      uint32_t any = 0;
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        okm[j] = (uint32_t)__builtin_amdgcn_sbfe((int)sw[j], si[j], 1u);   // v_bfe_i32: bit (si & 31), sign extended
-        any |= okm[j];
-      }
-      something = __ballot(any != 0u) != 0ull;
+    };
+    probe_rounds(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{});
+    if (E < U) {
+      // the bound cut: no k-mer of the first rounds is in the filter, and the slots of the remaining rounds cover fewer
+      // bases than c * len -- no gene can reach the threshold (ReadAnalyzer.hpp:104), the read has no association
+      if (cut_ok && !__ballot(lane_any)) return;
+      probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, std::integral_constant<int, U>{});
     }
-    if (something) {
-      // ---- position table: the probes that passed read their home bucket, the others the spare empty bucket ----
-      const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
-      const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
-      const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
-      const uint32_t spare = 1u << P.tab_lg;
-      // the word a slot's high word is compared with (0 = empty slot): tag | valid | displacement 0
-      auto want_of = [&](const int j) -> uint32_t {
-        const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
-        return (tag << 8) | 0x80u;
-      };
-      uint4 bk[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const uint32_t bb = (uint32_t)pos[j] & bmask;
-        const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
-        if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
-          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
-          bk[j] = make_uint4(v.x, v.y, v.z, v.w);
-        } else {
-          bk[j] = load_bucket<LSUM && UNI>(tab16, bi);   // (the ragged instantiation runs out of registers with the short addresses)
-        }
-      }
-      // each probe ends up with one word of its bucket: the low word of the slot that matched (mt[j] says whether one did)
-      bool lane_any = false, lane_more = false;
-      bool more[U], mt[U];
-      uint32_t slo[U];
-      // ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) settle that right away and walk
-      // all their probes per round; the 64-VGPR ones keep the buckets until the hit path and walk probe by probe
-      constexpr bool ROUNDS = LSUM;
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const uint32_t want = want_of(j);
-        const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
-        if (ROUNDS) {
-          mt[j] = m0 | m1;
-          slo[j] = m0 ? bk[j].x : bk[j].z;
-        }
-        lane_any |= m0 | m1;
-        more[j] = !(m0 | m1) & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
-        lane_more |= more[j];
-      }
-      if (__ballot(lane_more) && !SHK_ABL(P, 8u)) {   // (ablation 8: no walks)
-        // rare: the key may sit behind its (full) home bucket
-        auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
-        if (ROUNDS) {
-          // round d looks at bucket home+d of every probe that is still searching, all U loads in flight together (the
-          // others read the spare bucket: one line for the wave) -- a memory round trip per displacement, not per probe
-          uint32_t d = 0;
-          do {
-            ++d;
-#pragma unroll
-            for (int j = 0; j < U; ++j) bk[j] = load_bucket<LSUM && UNI>(tab16, more[j] ? bucket_of(j, d) : spare);
-            lane_more = false;
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-              const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
-              const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
-              const bool found = more[j] & (n0 | n1);
-              const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
-              slo[j] = found ? (n0 ? bk[j].x : bk[j].z) : slo[j];
-              mt[j] |= found;
-              lane_any |= found;
-              more[j] = more[j] & !found & !ends;
-              lane_more |= more[j];
-            }
-          } while (__ballot(lane_more));
-        } else {
-          walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of);   // (a key found is moved into bk[j] in home form)
-        }
-      }
+    {
       if (__ballot(lane_any) && !SHK_ABL(P, 16u)) {   // (ablation 16: no hit path)
         // ================= something matched in the table: the hit path =================
         KernargParams H = kernarg_params();
@@ -1316,6 +1413,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         }
       }
     }
+    };   // classify_staged
+    // the first-round counts this specialisation is compiled for (CutPlan<U>): cutE is one of them, or U
+    if (cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, CutPlan<U>::E0>{});
+    else if (CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, CutPlan<U>::E1>{});
+    else classify_staged(std::integral_constant<int, U>{});
     }   // !skip
     if (!have_nxt) break;
     retire_loads(w_nxt);

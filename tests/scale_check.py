@@ -21,6 +21,7 @@ ap.add_argument("--q", type=int, default=0)
 ap.add_argument("--single", action="store_true")
 ap.add_argument("--oracle-pairs", type=int, default=200000)
 ap.add_argument("--skip-bitvector", action="store_true")
+ap.add_argument("--on-target", type=float, default=0.5)
 a = ap.parse_args()
 
 BF_BITS = a.bf_bits if a.bf_bits else 1 << a.bf_log2
@@ -32,7 +33,7 @@ for g in range(9, a.genes, 10):          # every 10th gene shares its first half
     genes[g][:h] = genes[g - 1][:h]
 print("reference: %d genes, %.3e bases" % (a.genes, float(lens.sum())), flush=True)
 dev = torch.device("cuda:0")
-batch = synth.make_pairs_device(a.pairs, genes, dev, seed=synth.SEED + 7, read_len=a.read_len, with_qual=a.q > 0)
+batch = synth.make_pairs_device(a.pairs, genes, dev, seed=synth.SEED + 7, read_len=a.read_len, with_qual=a.q > 0, on_target=a.on_target)
 torch.cuda.synchronize()
 ptr = {k: (v.data_ptr() if v is not None else 0) for k, v in batch.items()}
 res = {}

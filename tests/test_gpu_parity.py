@@ -913,3 +913,66 @@ def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
         assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
         if paired:
             assert (tmp_path / "h2.fq").read_bytes() == (tmp_path / "o2.fq").read_bytes()
+
+
+# ---------------------------------------------------------------------------
+# the bound cut of classify_uni_kernel (classify.hip: rounds [0, E) first; a read none of whose first slots is in the filter
+# ends there when the remaining slots cannot reach c * len): chimeric reads whose on-target part starts or ends anywhere
+# in either mate, for thresholds on both sides of what the remaining rounds cover
+# ---------------------------------------------------------------------------
+def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual):
+    m1s, m2s, q1s, q2s = [], [], [], []
+    for _ in range(n):
+        g = genes[int(rng.integers(0, len(genes)))]
+        mates = []
+        for L in (L1, L2):
+            if L == 0:
+                continue
+            l = int(rng.integers(max(1, (2 * L) // 3), L + 1)) if ragged else L
+            m = synth.random_seq(rng, l)
+            st = int(rng.integers(0, len(g) - l + 1))
+            src = g[st:st + l] if rng.random() < 0.5 else synth.revcomp(g[st:st + l])
+            form = int(rng.integers(0, 5))          # 0: off-target; 1: prefix; 2: suffix; 3: middle; 4: whole mate
+            s = int(rng.integers(0, l + 1))
+            if form == 1:
+                m[:s] = src[:s]
+            elif form == 2:
+                m[l - s:] = src[l - s:]
+            elif form == 3:
+                a = int(rng.integers(0, l - s + 1))
+                m[a:a + s] = src[a:a + s]
+            elif form == 4:
+                m[:] = src
+            if with_n and rng.random() < 0.4:
+                m[rng.integers(0, l, size=int(rng.integers(1, 4)))] = ord("N")
+            mates.append(m)
+        m1s.append(mates[0])
+        if L2:
+            m2s.append(mates[1])
+        if qual:
+            for lst, m in zip((q1s, q2s), mates):
+                q = np.where(rng.random(len(m)) < 0.93, rng.integers(25, 42, size=len(m)), rng.integers(2, 20, size=len(m)))
+                lst.append((q + 33).astype(np.uint8))
+    return synth.batch_from_lists(m1s, m2s if L2 else None, q1s if qual else None, q2s if (qual and L2) else None)
+
+
+@pytest.mark.parametrize("env", [{}, {"SHK_NO_LDS_SUMMARY": "1"}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"}, {"BF": str(3 << 24)}])
+@pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (100, 100, 17), (150, 0, 17), (250, 250, 21), (60, 50, 9)])
+def test_bound_cut_chimeric_reads(oracle, monkeypatch, env, L1, L2, k):
+    bf_bits = 1 << 26
+    for name, v in env.items():
+        if name == "BF":
+            bf_bits = int(v)
+        else:
+            monkeypatch.setenv(name, v)
+    rng = np.random.default_rng(9000 + L1 + 7 * L2 + k)
+    genes = synth.make_genes(rng, 6, 1200, 4000, share_every=3)
+    for c in (0.25, 0.45, 0.6, 0.75, 1.0):
+        for q in (0, 20):
+            o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits, c=c, min_quality=q)
+            assert "table" in h.probe_mode()
+            for ragged in (False, True):
+                batch = _chimeric_batch(rng, genes, 700, L1, L2, ragged, with_n=True, qual=q > 0)
+                goff, _ = _compare_classify(o, h, batch)
+                assert goff[-1] > 0 or c > 0.6 or q > 0
+            h.close()
