@@ -286,12 +286,15 @@ def main():
             prof_note = "profiles/pmc_counters.json unreadable: %r" % (ex,)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "kernel": "classify_uni_kernel" if h.probe_mode().startswith("lds-summary") else "classify_fast_kernel",
+                "kernel": "classify_uni_kernel" if "table" in h.probe_mode() else "classify_fast_kernel",
                 "kernel_ms": round(kern_ms, 4), "launches": int(tm["n_launches"]),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / (2 * n), 1),
                 "kmers": int(w["n_kmers"]), "hits": int(w["n_hits"]),
-                "binding_resource": "VALU issue (the algorithmic bytes above mostly never reach HBM: the LDS summary proves clear probes clear, "
+                "binding_resource": "VALU issue (the algorithmic bytes above mostly never reach HBM: this index's exact table is held in LDS, "
+                                    "and a pair none of whose first 128 slots is in the filter ends there -- the other slots cannot reach c*len)"
+                                    if h.probe_mode() == "lds-table" else
+                                    "VALU issue (the algorithmic bytes above mostly never reach HBM: the LDS summary proves clear probes clear, "
                                     "hits are served by the L2-resident position table)",
                 "valu": valu, "hbm_actual": hbm_actual, "kernel_src_sha": sha, "counters": prof_note}
 

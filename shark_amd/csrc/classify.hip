@@ -936,6 +936,8 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 // MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
 // probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
 // only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
+// LSL = 21: no summary -- the workgroup keeps the index's LDS-resident exact table (shark_internal.hpp LTAB_*; 144 KiB, one
+// 1024-thread workgroup per CU): a probe is two LDS reads, a pair of a tiny index touches no memory but its own bases.
 // LSL: log2 of the LDS summary's bits.  18 = 32 KiB, several 512-thread workgroups per CU (the sparse indices of a few
 // genes); 20 = 128 KiB shared by ONE 1024-thread workgroup per CU -- four times the reach (pass rate <= 30 % up to ~3x10^5
 // set bits, i.e. panels of a hundred genes) at 4 waves per SIMD, for indices that would otherwise probe an L2-resident
@@ -945,11 +947,12 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #endif
 template <int U, int MODE, int LSL>
 struct UniGeom {
-  static constexpr int WAVES = (pm_lds(MODE) && LSL == 20) ? 16 : 8;
+  static constexpr bool LX = pm_lds(MODE) && LSL == 21;   // the exact table of a tiny index in LDS instead of a summary
+  static constexpr int WAVES = (pm_lds(MODE) && LSL >= 20) ? 16 : 8;
   static constexpr int THREADS = WAVES * 64;
   // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes are latency bound: 8 waves per SIMD
   static constexpr int MIN_WAVES = WAVES == 16 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
-  static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (1u << LSL) : 0u;
+  static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (LX ? LTAB_BYTES * 8u : (1u << LSL)) : 0u;   // what the workgroup keeps in LDS
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };
 
@@ -964,6 +967,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
   using UG = UniGeom<U, MODE, LSL>;
+  constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
   constexpr uint32_t S = 64 * U;
   constexpr uint32_t WORDS = stage_words_for(S);
@@ -1206,6 +1210,32 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) { okm[j] = ok[j] ? 0xFFFFFFFFu : 0u; any |= ok[j]; }
         something = __ballot(any) != 0ull;
+      } else if (LX) {
+        // the exact table in LDS: displacement of the position's group, then the slot (shark_internal.hpp)
+        const uint32_t *T = lsum;
+        const char *D = reinterpret_cast<const char *>(lsum + LTAB_T_WORDS);
+        const uint32_t tagmask15 = (uint32_t)(P.bf_mask >> LTAB_SLOT_LG);
+        const uint32_t gmask2 = (tagmask15 & ((1u << LTAB_GROUP_LG) - 1u)) << 1;   // (pos[] is the raw hash: only the filter's bits count)
+        uint32_t dd[U], ee[U];
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j)
+          dd[j] = *reinterpret_cast<const uint16_t *>(D + (((uint32_t)pos[j] >> (LTAB_SLOT_LG - 1)) & gmask2));
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j)
+          ee[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + ((((uint32_t)pos[j] + dd[j]) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+        bool esc = false, any = false;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], LTAB_SLOT_LG) & tagmask15;
+          mt[j] = (ee[j] >> 13) == ((tag << 1) | 1u);
+          slo[j] = ee[j] & LTAB_ESC;
+          okm[j] = mt[j] ? 0xFFFFFFFFu : 0u;
+          any |= mt[j];
+          esc |= mt[j] & (slo[j] == LTAB_ESC);
+        }
+        // a multi-gene list (or a gene id beyond 13 bits) is not in the entry: the position table answers for these rounds
+        something = __ballot(esc) != 0ull;
+        if (!something) lane_any |= any;
       } else {
         uint32_t si[U], sw[U];
 #pragma unroll
@@ -1276,7 +1306,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
             walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
           }
         }
-      } else {
+      } else if (!LX) {
         // nothing of these rounds passed the summary: no matches (the hit path may still run for the other rounds)
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) {
@@ -1648,6 +1678,7 @@ const char *probe_mode_name(const Ctx *ctx)
 {
   static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table",
                                 "table-mod", "lds-summary+table-mod"};
+  if (ctx->idx.ltab) return "lds-table";   // (uniform batches of up to 5 rounds; other batches take lds-summary+table)
   return names[probe_mode(ctx->idx)];
 }
 
@@ -1698,13 +1729,17 @@ bool uni_kernel_available(const Ctx *ctx)
 }
 
 template <int U>
-static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool uni, unsigned grid, hipStream_t s)
+static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s)
 {
 #define LU4(M_, L_, HQ_, UN_) hipLaunchKernelGGL((classify_uni_kernel<U, M_, HQ_, L_, UN_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p)
 #define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
                         else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
   switch (mode) {
-  case PM_LDS_TAB: if (big) LU(PM_LDS_TAB, 20); else LU(PM_LDS_TAB, 18); break;
+  case PM_LDS_TAB:
+    if (lx) { if constexpr (U <= 5) LU(PM_LDS_TAB, 21); }   // (launch_classify_uni asks for it only where it is compiled)
+    else if (big) LU(PM_LDS_TAB, 20);
+    else LU(PM_LDS_TAB, 18);
+    break;
   case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
   case PM_TAB: LU(PM_TAB, 18); break;
   case PM_TAB_MOD: LU(PM_TAB_MOD, 18); break;
@@ -1731,17 +1766,21 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lsum32 = ctx->idx.lbig32;
     p.lsum_shift = ctx->idx.lbig_shift;
   }
-  const int min_waves = big ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
-  const uint64_t wpb = big ? 16 : 8;
-  const uint64_t cap = big ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
+  // tiny indices: the exact table in LDS (uniform batches; power-of-two filters)
+  const bool lx = uni && mode == PM_LDS_TAB && ctx->idx.ltab != nullptr && u <= 5;
+  if (lx) p.lsum32 = ctx->idx.ltab;
+  const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
+  const int min_waves = wg16 ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
+  const uint64_t wpb = wg16 ? 16 : 8;
+  const uint64_t cap = wg16 ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  if (u == 2) launch_uni_u<2>(p, mode, hasq, big, uni, grid, stream);
-  else if (u == 3) launch_uni_u<3>(p, mode, hasq, big, uni, grid, stream);
-  else if (u == 4) launch_uni_u<4>(p, mode, hasq, big, uni, grid, stream);
-  else if (u == 5) launch_uni_u<5>(p, mode, hasq, big, uni, grid, stream);
-  else if (u == 6) launch_uni_u<6>(p, mode, hasq, false, uni, grid, stream);
-  else launch_uni_u<8>(p, mode, hasq, false, uni, grid, stream);
+  if (u == 2) launch_uni_u<2>(p, mode, hasq, big, lx, uni, grid, stream);
+  else if (u == 3) launch_uni_u<3>(p, mode, hasq, big, lx, uni, grid, stream);
+  else if (u == 4) launch_uni_u<4>(p, mode, hasq, big, lx, uni, grid, stream);
+  else if (u == 5) launch_uni_u<5>(p, mode, hasq, big, lx, uni, grid, stream);
+  else if (u == 6) launch_uni_u<6>(p, mode, hasq, false, false, uni, grid, stream);
+  else launch_uni_u<8>(p, mode, hasq, false, false, uni, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }

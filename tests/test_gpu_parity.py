@@ -18,14 +18,17 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "bitvector"])
+@pytest.fixture(params=["auto", "bitvector", "no-lds-table"])
 def probe(request, monkeypatch):
-    """run a test once with the index's automatic probe structure (position table where possible)
-    and once forced onto the plain filter words (+rank directory)"""
+    """run a test once with the index's automatic probe structure (position table where possible; tiny indices: the exact
+    table in LDS for uniform batches), once forced onto the plain filter words (+rank directory), and once without the
+    LDS-resident table (so that tiny indices also exercise the LDS-summary + position-table chain on uniform batches)"""
+    monkeypatch.delenv("SHK_PROBE", raising=False)
+    monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
     if request.param == "bitvector":
         monkeypatch.setenv("SHK_PROBE", "bitvector")
-    else:
-        monkeypatch.delenv("SHK_PROBE", raising=False)
+    elif request.param == "no-lds-table":
+        monkeypatch.setenv("SHK_NO_LDS_TABLE", "1")
     return request.param
 
 
@@ -831,6 +834,7 @@ def test_dense_table_long_probe_paths(oracle, k, bf_bits, n_bases, monkeypatch):
     later bucket, the empty slot that ends a search).  Uniform, trimmed and single-end batches -- every kernel that reads
     the table -- must still equal the oracle, and the index must equal the oracle's word for word."""
     monkeypatch.setenv("SHK_TAB_DENSE", "1")
+    monkeypatch.setenv("SHK_NO_LDS_TABLE", "1")   # (uniform batches of the two small cases would not read the position table otherwise)
     rng = np.random.default_rng(n_bases + k)
     n_genes = 8
     genes = synth.make_genes(rng, n_genes, n_bases // n_genes, n_bases // n_genes + 1, share_every=3)
@@ -956,7 +960,8 @@ def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual):
     return synth.batch_from_lists(m1s, m2s if L2 else None, q1s if qual else None, q2s if (qual and L2) else None)
 
 
-@pytest.mark.parametrize("env", [{}, {"SHK_NO_LDS_SUMMARY": "1"}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"}, {"BF": str(3 << 24)}])
+@pytest.mark.parametrize("env", [{}, {"SHK_NO_LDS_TABLE": "1"}, {"SHK_NO_LDS_SUMMARY": "1"}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"},
+                                 {"BF": str(3 << 24)}])
 @pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (100, 100, 17), (150, 0, 17), (250, 250, 21), (60, 50, 9)])
 def test_bound_cut_chimeric_reads(oracle, monkeypatch, env, L1, L2, k):
     bf_bits = 1 << 26
@@ -976,3 +981,49 @@ def test_bound_cut_chimeric_reads(oracle, monkeypatch, env, L1, L2, k):
                 goff, _ = _compare_classify(o, h, batch)
                 assert goff[-1] > 0 or c > 0.6 or q > 0
             h.close()
+
+
+# ---------------------------------------------------------------------------
+# tiny indices: the exact table held in LDS (classify_uni_kernel LSL = 21, shark_internal.hpp LTAB_*)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k,bf_bits,n_genes,gene_len,share", [
+    (17, 1 << 33, 1, 20_000, 0),        # the bench index
+    (17, 1 << 33, 4, 6_400, 0),         # 25 5xx keys: load 0.78 of the 2^15 slots
+    (17, 1 << 30, 12, 1_500, 3),        # shared halves: multi-gene lists escape to the position table
+    (31, 1 << 28, 3, 5_000, 0),
+    (11, 1 << 24, 2, 3_000, 0),         # smallest filter that gets one; groups use 9 of their 13 bits
+    (17, 1 << 33, 8_400, 19, 0),        # gene ids beyond the entry's 13 bits escape as well
+])
+def test_lds_table_tiny_indices(oracle, monkeypatch, k, bf_bits, n_genes, gene_len, share):
+    monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
+    rng = np.random.default_rng(31 * k + n_genes)
+    genes = synth.make_genes(rng, n_genes, gene_len, gene_len, share_every=share)
+    reads_from = genes if gene_len >= 300 else [np.concatenate(genes[i:i + 40]) for i in range(0, n_genes, 40)]
+    for q, single in ((0, False), (20, True)):
+        o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits, min_quality=q, single=single)
+        assert h.probe_mode() == "lds-table", (h.probe_mode(), info)
+        _compare_index(o, h, info)
+        monkeypatch.setenv("SHK_NO_LDS_TABLE", "1")
+        h0 = _hip(k=k, bf_bits=bf_bits, min_quality=q, single=single)
+        h0.build([bytes(g) for g in genes])
+        monkeypatch.delenv("SHK_NO_LDS_TABLE")
+        assert h0.probe_mode() == "lds-summary+table"
+        for L, paired, var in ((150, True, False), (100, True, False), (150, False, False), (75, True, False), (150, True, True)):
+            batch = synth.make_reads(rng, reads_from, 1500, read_len=L, paired=paired, on_target=0.6, n_rate=0.004, qual=q > 0, var_len=var)
+            og, oi = _compare_classify(o, h, batch)
+            g0, i0 = h0.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"])
+            assert np.array_equal(g0, og) and np.array_equal(i0, oi)
+            assert og[-1] > 0 or gene_len < 300
+        h.close()
+        h0.close()
+
+
+def test_lds_table_is_not_built_for_larger_indices(oracle):
+    rng = np.random.default_rng(5)
+    genes = synth.make_genes(rng, 3, 9_000, 9_000)      # ~27 000 keys > LTAB_MAX_KEYS
+    h = _hip(k=17, bf_bits=1 << 33)
+    h.build([bytes(g) for g in genes])
+    assert h.probe_mode() == "lds-summary+table"
+    h2 = _hip(k=17, bf_bits=1 << 34)                    # tag would need 19 bits
+    h2.build([bytes(genes[0])])
+    assert h2.probe_mode() == "lds-summary+table"
