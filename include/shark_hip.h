@@ -89,11 +89,14 @@ typedef struct shk_index_info {
 int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
 /* How the classify kernels look a k-mer's filter position up on this index:
  * "bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table",
- * "lds-summary+table", and for filter sizes that are not a power of two
+ * "lds-summary+table", "lds-table" (tiny indices: the exact table is held
+ * in LDS for batches of one read length; other batches of such an index take
+ * lds-summary+table), and for filter sizes that are not a power of two
  * "table-mod", "lds-summary+table-mod"
  * (every mode returns exactly the filter's bit).  Environment
  * SHK_PROBE=bitvector at finalize time disables the table, SHK_TAB_DENSE=1
- * builds it at up to 0.8 load (long probe paths); both are for the tests. */
+ * builds it at up to 0.8 load (long probe paths), SHK_NO_LDS_TABLE=1 leaves
+ * the LDS-resident table out; all three are for the tests. */
 const char *shk_probe_mode(const shk_ctx *ctx);
 
 /* Parity introspection: copy the device-resident index to host buffers.

@@ -966,6 +966,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
+  // the bound cut is compiled in except behind the L2-resident summary: there an off-target pair is already cheap (the summary
+  // rejects its probes without memory traffic) and the second dependent step costs on-target pairs more than the cut saves
+  // (250 / 1 000 genes: 29.0 / 33.9 -> 31.8 / 35.1 ms per 10 M pairs with it)
+  constexpr bool CUT = !SUM && !SHK_NO_CUT;
   using UG = UniGeom<U, MODE, LSL>;
   constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
@@ -1019,9 +1023,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
   uint32_t cutE = U, cutUb = 0;
   auto plan_cut = [&](const uint32_t l1, const uint32_t l2) {
-    const uint32_t thr = SHK_NO_CUT ? 0u : cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
     cutE = U;
     cutUb = 0;
+    if (!CUT) return;
+    const uint32_t thr = cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
     // bases_behind falls with e: the smaller candidate is tried last and wins when it qualifies
     if (CutPlan<U>::E1 != CutPlan<U>::E0) {
       const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E1, nk1, nk2, P2, l1, l2);
@@ -1153,7 +1158,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     bool lane_any = false;
     // ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) reduce a bucket to that word right
     // away and walk all their probes per round; the 64-VGPR ones keep the buckets until the hit path and walk probe by probe
-    constexpr bool ROUNDS = LSUM;
+#ifndef SHK_ROUNDS_ALL
+#define SHK_ROUNDS_ALL 0
+#endif
+    constexpr bool ROUNDS = LSUM || SHK_ROUNDS_ALL;
     const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
     const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
     const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
@@ -1445,8 +1453,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     };   // classify_staged
     // the first-round counts this specialisation is compiled for (CutPlan<U>): cutE is one of them, or U
-    if (cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, CutPlan<U>::E0>{});
-    else if (CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, CutPlan<U>::E1>{});
+    if (CUT && cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E0 : U)>{});
+    else if (CUT && CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E1 : U)>{});
     else classify_staged(std::integral_constant<int, U>{});
     }   // !skip
     if (!have_nxt) break;
