@@ -62,6 +62,23 @@ def kernel_src_sha():
     return h.hexdigest()[:16]
 
 
+def load_pmc(k, bf_log2):
+    """profiles/pmc_counters.json, only when it was taken on the kernel sources being run -> (dict or None, note)"""
+    pfile = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    sha = kernel_src_sha()
+    if not os.path.exists(pfile):
+        return None, "profiles/pmc_counters.json absent"
+    try:
+        pj = json.load(open(pfile))
+    except Exception as ex:   # a broken profile file must not break the bench line
+        return None, "profiles/pmc_counters.json unreadable: %r" % (ex,)
+    if pj.get("kernel_src_sha") != sha:
+        return None, "profiles/pmc_counters.json was taken on other kernel sources (%s, now %s): not used" % (pj.get("kernel_src_sha"), sha)
+    if pj.get("k") != k or pj.get("bf_log2") != bf_log2:
+        return None, "profiles/pmc_counters.json has no entry for this workload"
+    return pj, "counters from profiles/pmc_counters.json (commit %s, same kernel sources)" % pj.get("commit")
+
+
 def cpu_info():
     model, phys = "", set()
     try:
@@ -208,12 +225,21 @@ def main():
                 "index_build_s": round(t_build2, 3), "n_set_bits": int(info2["n_set_bits"]), "tot_idx": int(info2["tot_idx"]),
                 "assoc_per_step": n_assoc2 // steps2, "tie_reads": int(tm2["last_n_tie"])}
         if w2:
-            # this index is bound by the RATE of random lookups behind the caches: one 16-byte bucket per valid k-mer (plus list
-            # entries for multi-gene hits); ceiling measured with tools/gather_bench on an 8 GiB table (profiles/r02_gather_ceiling.jsonl)
-            cfg2["roofline"] = {"bound": "random 16-B lookups behind L2 (request rate, not bytes)", "kmers_probed": int(w2["n_kmers"]),
-                                "G_lookups_per_s": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1), "ceiling_G_lookups_per_s": RANDOM_LOOKUP_CEILING_G,
-                                "frac": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9 / RANDOM_LOOKUP_CEILING_G, 3),
-                                "sector_GBps": round(64 * w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1)}
+            # this index is bound by random lookups behind the caches: one 16-byte bucket per k-mer that is looked up (plus list entries
+            # for multi-gene hits); ceiling measured with tools/gather_bench on an 8 GiB table (profiles/r02_gather_ceiling.jsonl).
+            # The bound cut ends an off-target pair after 128 of its 320 slots, so fewer k-mers are looked up than the reads hold:
+            # the requests actually made are the TCC misses of the counter pass (same kernel sources), when that file is usable.
+            rl = {"bound": "random 16-B lookups behind L2 (request rate, not bytes)", "kmers_in_reads": int(w2["n_kmers"]),
+                  "G_kmers_per_s": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1), "ceiling_G_lookups_per_s": RANDOM_LOOKUP_CEILING_G}
+            pj2, note2 = load_pmc(17, 33)
+            e2 = pj2.get("workloads", {}).get("configs2") if pj2 else None
+            if e2 and e2.get("TCC_MISS_sum"):
+                rl["memory_side_requests_per_launch"] = int(e2["TCC_MISS_sum"])
+                rl["G_requests_per_s"] = round(e2["TCC_MISS_sum"] / (k2 * 1e-3) / 1e9, 1)
+                rl["frac"] = round(e2["TCC_MISS_sum"] / (k2 * 1e-3) / 1e9 / RANDOM_LOOKUP_CEILING_G, 3)
+                rl["sector_GBps"] = round(64 * e2["TCC_MISS_sum"] / (k2 * 1e-3) / 1e9, 1)
+            rl["counters"] = note2
+            cfg2["roofline"] = rl
         h2.close()
         del b2
         # BASELINE configs[4] shape on this GPU's shard: k=31, -q 20, --single, 2^37-bit filter (the quality-mask path at max k)
@@ -253,37 +279,30 @@ def main():
     kern_ms = tm["total_ms"] / max(tm["n_launches"], 1)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     sha = kernel_src_sha()
-    traffic, valu, hbm_actual, prof_note = None, None, None, "profiles/pmc_counters.json absent"
-    pfile = os.path.join(ROOT, "profiles", "pmc_counters.json")
-    if os.path.exists(pfile):
-        try:
-            pj = json.load(open(pfile))
-            e = pj.get("workloads", {}).get("configs1_ot%.2f" % args.on_target)
-            if pj.get("kernel_src_sha") != sha:
-                prof_note = "profiles/pmc_counters.json was taken on other kernel sources (%s, now %s): not used" % (pj.get("kernel_src_sha"), sha)
-            elif not e or e.get("pairs") != n or pj.get("k") != k or pj.get("bf_log2") != args.bf_log2:
-                prof_note = "profiles/pmc_counters.json has no entry for this workload"
-            else:
-                prof_note = "counters from profiles/pmc_counters.json (commit %s, same kernel sources), per launch of %d pairs" % (pj.get("commit"), n)
-                fetch, write = e["FETCH_SIZE_KB"] * 1024.0, e["WRITE_SIZE_KB"] * 1024.0
-                traffic = int(2 * fetch + write)          # the guide's gfx950 correction (FETCH_SIZE x2)
-                hbm_actual = {"fetch_bytes_counter": int(fetch), "write_bytes_counter": int(write),
-                              "bytes_uncorrected": int(fetch + write), "bytes_fetch_x2": traffic,
-                              "GBps_uncorrected": round((fetch + write) / (kern_ms * 1e-3) / 1e9, 1),
-                              "GBps_fetch_x2": round(traffic / (kern_ms * 1e-3) / 1e9, 1),
-                              "frac_of_peak_uncorrected": round((fetch + write) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "frac_of_peak_fetch_x2": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "known_input_bytes": int(w["n_bases"] + 16 * (n + 1)),
-                              "load_width": "input bases are fetched as aligned dwords (4 B per lane, 3 per lane per read), offsets as 8-B loads; "
-                                            "the guide calibrates the x2 only for 16 B-per-lane streams, so both figures are given"}
-                iv = e["SQ_INSTS_VALU"]
-                valu = {"insts_per_pair": round(iv / n, 1), "salu_per_pair": round(e.get("SQ_INSTS_SALU", 0) / n, 1),
-                        "lds_per_pair": round(e.get("SQ_INSTS_LDS", 0) / n, 1),
-                        "cycles_per_valu_inst": round(kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / iv, 2),
-                        "frac_of_issue_ceiling": round(iv * 2.0 / (kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD), 4),
-                        "ceiling": "1024 SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction" % CLK_GHZ}
-        except Exception as ex:   # a broken profile file must not break the bench line
-            prof_note = "profiles/pmc_counters.json unreadable: %r" % (ex,)
+    traffic, valu, hbm_actual = None, None, None
+    pj, prof_note = load_pmc(k, args.bf_log2)
+    e = pj.get("workloads", {}).get("configs1_ot%.2f" % args.on_target) if pj else None
+    if pj and (not e or e.get("pairs") != n):
+        prof_note = "profiles/pmc_counters.json has no entry for this workload"
+    elif pj:
+        prof_note += ", per launch of %d pairs" % n
+        fetch, write = e["FETCH_SIZE_KB"] * 1024.0, e["WRITE_SIZE_KB"] * 1024.0
+        traffic = int(2 * fetch + write)          # the guide's gfx950 correction (FETCH_SIZE x2)
+        hbm_actual = {"fetch_bytes_counter": int(fetch), "write_bytes_counter": int(write),
+                      "bytes_uncorrected": int(fetch + write), "bytes_fetch_x2": traffic,
+                      "GBps_uncorrected": round((fetch + write) / (kern_ms * 1e-3) / 1e9, 1),
+                      "GBps_fetch_x2": round(traffic / (kern_ms * 1e-3) / 1e9, 1),
+                      "frac_of_peak_uncorrected": round((fetch + write) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                      "frac_of_peak_fetch_x2": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                      "known_input_bytes": int(w["n_bases"] + 16 * (n + 1)),
+                      "load_width": "input bases are fetched as aligned dwords (4 B per lane, 3 per lane per read), offsets as 8-B loads; "
+                                    "the guide calibrates the x2 only for 16 B-per-lane streams, so both figures are given"}
+        iv = e["SQ_INSTS_VALU"]
+        valu = {"insts_per_pair": round(iv / n, 1), "salu_per_pair": round(e.get("SQ_INSTS_SALU", 0) / n, 1),
+                "lds_per_pair": round(e.get("SQ_INSTS_LDS", 0) / n, 1),
+                "cycles_per_valu_inst": round(kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / iv, 2),
+                "frac_of_issue_ceiling": round(iv * 2.0 / (kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD), 4),
+                "ceiling": "1024 SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction" % CLK_GHZ}
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                 "kernel": "classify_uni_kernel" if "table" in h.probe_mode() else "classify_fast_kernel",
@@ -291,6 +310,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / (2 * n), 1),
                 "kmers": int(w["n_kmers"]), "hits": int(w["n_hits"]),
+                "algorithmic_bytes": "SURVEY 8(d) per-read figure over every k-mer of every read, as the reference visits them; the kernel's bound "
+                                     "cut (DESIGN.md 3) proves most probes of an off-target pair irrelevant and does not make them",
                 "binding_resource": "VALU issue (the algorithmic bytes above mostly never reach HBM: this index's exact table is held in LDS, "
                                     "and a pair none of whose first 128 slots is in the filter ends there -- the other slots cannot reach c*len)"
                                     if h.probe_mode() == "lds-table" else

@@ -930,6 +930,9 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_NO_CUT
 #define SHK_NO_CUT 0
 #endif
+#ifndef SHK_NO_TOL
+#define SHK_NO_TOL 0
+#endif
 #ifndef SHK_UNI_WAVES
 #define SHK_UNI_WAVES 6   // 75 VGPRs, nothing spilled; at 8 waves per SIMD (64 VGPRs) the loop reloads spilled lane constants from scratch and measures 1-6 % slower
 #endif
@@ -970,6 +973,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // rejects its probes without memory traffic) and the second dependent step costs on-target pairs more than the cut saves
   // (250 / 1 000 genes: 29.0 / 33.9 -> 31.8 / 35.1 ms per 10 M pairs with it)
   constexpr bool CUT = !SUM && !SHK_NO_CUT;
+  constexpr bool TOL = CUT && !pm_lds(MODE) && !SHK_NO_TOL;   // table modes: matches are counted, and there is a second cut point
   using UG = UniGeom<U, MODE, LSL>;
   constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
@@ -1021,19 +1025,20 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   };
   set_geometry(L1, L2);
   // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
-  uint32_t cutE = U, cutUb = 0;
+  uint32_t cutE = U, cutUb = 0, cutUb2 = 0, thr_full = 0;
   auto plan_cut = [&](const uint32_t l1, const uint32_t l2) {
     cutE = U;
     cutUb = 0;
     if (!CUT) return;
-    const uint32_t thr = cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
+    thr_full = cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
     // bases_behind falls with e: the smaller candidate is tried last and wins when it qualifies
     if (CutPlan<U>::E1 != CutPlan<U>::E0) {
       const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E1, nk1, nk2, P2, l1, l2);
-      if (ub < thr) { cutE = (uint32_t)CutPlan<U>::E1; cutUb = ub; }
+      if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E1; cutUb = ub; }
     }
     const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E0, nk1, nk2, P2, l1, l2);
-    if (ub < thr) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
+    if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
+    if (TOL) cutUb2 = bases_behind(64u * (cutE + 1u), nk1, nk2, P2, l1, l2);   // the second cut point, one round later
   };
   if (UNI) plan_cut(L1, L2);
   const uint32_t b_uni = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
@@ -1137,12 +1142,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
     if (!UNI) plan_cut(m_cur.L1, m_cur.L2);
-    bool cut_ok = cutE < (uint32_t)U;
-    if (cut_ok) {
+    uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
+    if (cutE < (uint32_t)U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
       if (__ballot(inv_real != 0u)) {
         const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
-        cut_ok = cutUb < cov_threshold(P.c, len);
+        thr_r = cov_threshold(P.c, len);
       }
     }
 
@@ -1173,8 +1178,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     };
     auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
     // ---- canonical k-mers, hashes, summary probes, table probes of the rounds [JLO, JHI) ----
-    auto probe_rounds = [&](auto lo_const, auto hi_const) {
+    // (returns false when nothing of these rounds can have matched: no probe passed its summary / no slot is a valid k-mer)
+    auto probe_rounds = [&](auto lo_const, auto hi_const) -> bool {
       constexpr int JLO = decltype(lo_const)::value, JHI = decltype(hi_const)::value;
+      constexpr bool ALL = JLO == 0 && JHI == U;   // the only phase: its caller ends the read when nothing can have matched
       {
         const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
         const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
@@ -1314,7 +1321,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
             walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
           }
         }
-      } else if (!LX) {
+      } else if (!LX && !ALL) {
         // nothing of these rounds passed the summary: no matches (the hit path may still run for the other rounds)
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) {
@@ -1322,13 +1329,49 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           else bk[j] = make_uint4(0u, 0u, 0u, 0u);   // (an empty slot's compared word is 0: matches nothing)
         }
       }
+      return LX || something;
     };
-    probe_rounds(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{});
+    // bases covered by the k-mers of the rounds [0, J) that are in the filter: the union of [p, p + k) over those slots,
+    // counted as the hit path counts a gene's coverage (one ballot per round)
+    auto found_cover = [&](auto j_const) -> uint32_t {
+      constexpr int J = decltype(j_const)::value;
+      const uint64_t kthr = 1ull << (64u - k);
+      auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
+        const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
+        return (uint32_t)__builtin_popcountll(__ballot(t >= kthr));
+      };
+      uint64_t Hp = 0ull;
+      uint32_t cv = 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        bool m;
+        if (ROUNDS) m = mt[j];
+        else { const uint32_t want = want_of(j); m = (bk[j].y == want) | (bk[j].w == want); }
+        const uint64_t Hc = __ballot(m);
+        cv += cover(Hc, Hp);
+        Hp = Hc;
+      }
+      return cv + cover(0ull, Hp);
+    };
+    if (!probe_rounds(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}) && E == U) return;
     if (E < U) {
-      // the bound cut: no k-mer of the first rounds is in the filter, and the slots of the remaining rounds cover fewer
-      // bases than c * len -- no gene can reach the threshold (ReadAnalyzer.hpp:104), the read has no association
-      if (cut_ok && !__ballot(lane_any)) return;
-      probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, std::integral_constant<int, U>{});
+      // the bound cut: what is in the filter so far covers `cv` bases, the slots of the remaining rounds cover cutUb: together
+      // fewer than c * len -- no gene can reach the threshold (ReadAnalyzer.hpp:104), the read has no association.
+      // LDS modes stop only without any match (their matches are not validated yet, and a gene's k-mers are rare among
+      // an off-target read's); the table modes -- large references, where a random k-mer IS in the filter every few dozen
+      // slots -- count what the matches cover, and try once more a round later.
+      constexpr int E2 = (TOL && E + 1 < U) ? E + 1 : U;
+      const bool anyA = __ballot(lane_any) != 0ull;
+      if (!anyA || TOL) {
+        const uint32_t cv = anyA ? found_cover(std::integral_constant<int, E>{}) : 0u;
+        if (cutUb + cv < thr_r) return;
+      }
+      if (E2 < U) {
+        probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, std::integral_constant<int, E2>{});
+        const uint32_t cv = __ballot(lane_any) ? found_cover(std::integral_constant<int, E2>{}) : 0u;
+        if (cutUb2 + cv < thr_r) return;
+      }
+      probe_rounds(std::integral_constant<int, (E2 < U ? E2 : (E < U ? E : 0))>{}, std::integral_constant<int, U>{});
     }
     {
       if (__ballot(lane_any) && !SHK_ABL(P, 16u)) {   // (ablation 16: no hit path)

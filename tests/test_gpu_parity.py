@@ -961,7 +961,7 @@ def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual):
 
 
 @pytest.mark.parametrize("env", [{}, {"SHK_NO_LDS_TABLE": "1"}, {"SHK_NO_LDS_SUMMARY": "1"}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"},
-                                 {"BF": str(3 << 24)}])
+                                 {"BF": str(3 << 24)}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1", "BF": str(3 << 24)}])
 @pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (100, 100, 17), (150, 0, 17), (250, 250, 21), (60, 50, 9)])
 def test_bound_cut_chimeric_reads(oracle, monkeypatch, env, L1, L2, k):
     bf_bits = 1 << 26

@@ -1,0 +1,13 @@
+#!/bin/bash
+# tolerant bound cut (table modes): parity tests, fuzz (both biases), configs[2] with the oracle sample, then A/B against tools/variants/old.so
+export TMPDIR=/tmp
+mkdir -p gpurun_out/cut4
+( time timeout -k 10 700 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "lds_table or dense_table or panel or bound_cut or synthetic_parity or handworked or example_bit_exact or quality_mask or ragged or long" ) > gpurun_out/cut4/tests.log 2>&1 || { tail -30 gpurun_out/cut4/tests.log; exit 1; }
+tail -3 gpurun_out/cut4/tests.log
+( timeout -k 10 150 python tests/fuzz_parity.py 250 888001 ) > gpurun_out/cut4/fuzz.log 2>&1 || { tail -15 gpurun_out/cut4/fuzz.log; exit 1; }
+tail -1 gpurun_out/cut4/fuzz.log
+( FUZZ_UNI=1 timeout -k 10 100 python tests/fuzz_parity.py 200 999001 ) > gpurun_out/cut4/fuzz_uni.log 2>&1 || { tail -15 gpurun_out/cut4/fuzz_uni.log; exit 1; }
+tail -1 gpurun_out/cut4/fuzz_uni.log
+( timeout -k 10 400 python tests/scale_check.py --skip-bitvector --oracle-pairs 100000 ) > gpurun_out/cut4/scale.log 2>&1 || { tail -15 gpurun_out/cut4/scale.log; exit 1; }
+grep "kernel_ms\|parity\|OK" gpurun_out/cut4/scale.log | cut -c1-300
+bash tools/gpu_big.sh base old 2>&1 | tee gpurun_out/cut4/big.txt
