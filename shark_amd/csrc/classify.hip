@@ -1331,15 +1331,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
       return LX || something;
     };
-    // bases covered by the k-mers of the rounds [0, J) that are in the filter: the union of [p, p + k) over those slots,
-    // counted as the hit path counts a gene's coverage (one ballot per round)
+    // bases covered by the slots of a hit mask (one ballot per round): the union of [p, p + k), counted as the hit path
+    // counts a gene's coverage
+    const uint64_t kthr_c = 1ull << (64u - k);
+    auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
+      const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
+      return (uint32_t)__builtin_popcountll(__ballot(t >= kthr_c));
+    };
+    // ... by ALL k-mers of the rounds [0, J) that are in the filter
     auto found_cover = [&](auto j_const) -> uint32_t {
       constexpr int J = decltype(j_const)::value;
-      const uint64_t kthr = 1ull << (64u - k);
-      auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
-        const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
-        return (uint32_t)__builtin_popcountll(__ballot(t >= kthr));
-      };
       uint64_t Hp = 0ull;
       uint32_t cv = 0;
 #pragma unroll
@@ -1352,6 +1353,59 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         Hp = Hc;
       }
       return cv + cover(0ull, Hp);
+    };
+    // ... by the k-mers of the rounds [0, J) that can belong to ONE gene, maximised over the genes: a match with a single-gene
+    // list counts for that gene only, a match with a multi-gene list for every gene.  (The matches of an off-target read of a
+    // large reference are isolated k-mers of different genes: k bases each, whatever their number.)  At most 8 genes are
+    // looked at; beyond that the answer is "everything" (no cut).
+    auto gene_cover = [&](auto j_const) -> uint32_t {
+      constexpr int J = decltype(j_const)::value;
+      uint64_t H[J], W[J];
+      uint32_t gid[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const uint32_t want = want_of(j);
+        const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+        const uint32_t lo = ROUNDS ? slo[j] : (m0 ? bk[j].x : bk[j].z);
+        const bool m = ROUNDS ? mt[j] : (m0 | m1), multi = (lo >> 31) != 0u;
+        gid[j] = lo & 0xFFFFu;
+        H[j] = __ballot(m & !multi);
+        W[j] = __ballot(m & multi);
+      }
+      uint32_t best = 0;
+      {
+        uint64_t Hp = 0ull;
+#pragma unroll
+        for (int j = 0; j < J; ++j) { best += cover(W[j], Hp); Hp = W[j]; }
+        best += cover(0ull, Hp);
+      }
+      for (int it = 0; it < 8; ++it) {
+        uint32_t g = 0;
+        bool have = false;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if (!have && H[j] != 0ull) {
+            g = (uint32_t)__builtin_amdgcn_readlane((int)gid[j], (int)__builtin_ctzll(H[j]));
+            have = true;
+          }
+        if (!have) return best;
+        uint64_t Hp = 0ull;
+        uint32_t cv = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const uint64_t G = __ballot((((H[j] >> (uint32_t)lane) & 1ull) != 0ull) & (gid[j] == g));
+          H[j] &= ~G;
+          const uint64_t M = G | W[j];
+          cv += cover(M, Hp);
+          Hp = M;
+        }
+        cv += cover(0ull, Hp);
+        best = cv > best ? cv : best;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (H[j] != 0ull) return 0xFFFFFFFFu;
+      return best;
     };
     if (!probe_rounds(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}) && E == U) return;
     if (E < U) {
@@ -1368,8 +1422,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
       if (E2 < U) {
         probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, std::integral_constant<int, E2>{});
-        const uint32_t cv = __ballot(lane_any) ? found_cover(std::integral_constant<int, E2>{}) : 0u;
-        if (cutUb2 + cv < thr_r) return;
+        uint32_t cv = __ballot(lane_any) ? found_cover(std::integral_constant<int, E2>{}) : 0u;
+        if (cutUb2 + cv >= thr_r) cv = gene_cover(std::integral_constant<int, E2>{});   // (the cheap bound first)
+        if (cutUb2 < thr_r && cv < thr_r - cutUb2) return;
       }
       probe_rounds(std::integral_constant<int, (E2 < U ? E2 : (E < U ? E : 0))>{}, std::integral_constant<int, U>{});
     }

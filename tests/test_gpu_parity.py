@@ -924,7 +924,7 @@ def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
 # ends there when the remaining slots cannot reach c * len): chimeric reads whose on-target part starts or ends anywhere
 # in either mate, for thresholds on both sides of what the remaining rounds cover
 # ---------------------------------------------------------------------------
-def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual):
+def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual, k_hint=17):
     m1s, m2s, q1s, q2s = [], [], [], []
     for _ in range(n):
         g = genes[int(rng.integers(0, len(genes)))]
@@ -936,7 +936,7 @@ def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual):
             m = synth.random_seq(rng, l)
             st = int(rng.integers(0, len(g) - l + 1))
             src = g[st:st + l] if rng.random() < 0.5 else synth.revcomp(g[st:st + l])
-            form = int(rng.integers(0, 5))          # 0: off-target; 1: prefix; 2: suffix; 3: middle; 4: whole mate
+            form = int(rng.integers(0, 7))          # 0: off-target; 1: prefix; 2: suffix; 3: middle; 4: whole mate; 5, 6: mosaic
             s = int(rng.integers(0, l + 1))
             if form == 1:
                 m[:s] = src[:s]
@@ -947,6 +947,16 @@ def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual):
                 m[a:a + s] = src[a:a + s]
             elif form == 4:
                 m[:] = src
+            elif form >= 5:
+                # pieces of several genes side by side: together they cover much, no single gene does (the per-gene bound)
+                p = 0
+                while p < l:
+                    w = int(rng.integers(k_hint, 3 * k_hint + 8))
+                    g2 = genes[int(rng.integers(0, len(genes)))]
+                    st2 = int(rng.integers(0, len(g2) - w + 1))
+                    if rng.random() < 0.8:
+                        m[p:p + w] = g2[st2:st2 + w][:l - p]
+                    p += w
             if with_n and rng.random() < 0.4:
                 m[rng.integers(0, l, size=int(rng.integers(1, 4)))] = ord("N")
             mates.append(m)
@@ -971,13 +981,13 @@ def test_bound_cut_chimeric_reads(oracle, monkeypatch, env, L1, L2, k):
         else:
             monkeypatch.setenv(name, v)
     rng = np.random.default_rng(9000 + L1 + 7 * L2 + k)
-    genes = synth.make_genes(rng, 6, 1200, 4000, share_every=3)
+    genes = synth.make_genes(rng, 12, 1200, 4000, share_every=3)
     for c in (0.25, 0.45, 0.6, 0.75, 1.0):
         for q in (0, 20):
             o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits, c=c, min_quality=q)
             assert "table" in h.probe_mode()
             for ragged in (False, True):
-                batch = _chimeric_batch(rng, genes, 700, L1, L2, ragged, with_n=True, qual=q > 0)
+                batch = _chimeric_batch(rng, genes, 700, L1, L2, ragged, with_n=True, qual=q > 0, k_hint=k)
                 goff, _ = _compare_classify(o, h, batch)
                 assert goff[-1] > 0 or c > 0.6 or q > 0
             h.close()
