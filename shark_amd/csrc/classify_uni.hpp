@@ -1,0 +1,746 @@
+// classify_uni.hpp -- classify_uni_kernel and its launcher template.  Included by classify_uni_u<U>.hip (one translation unit
+// per unroll U: the instantiations of one U take about half a minute to compile, and there are six).
+#pragma once
+#include "classify_common.hpp"
+
+namespace shk {
+
+// ---------------------------------------------------------------------------
+// classify_uni_kernel: batches whose reads all have ONE length per mate (what a sequencer delivers) on an index
+// in LDS-summary + position-table mode.  Same algorithm and data layout as classify_fast_kernel<.., PM_LDS_TAB>, but
+// everything that depends only on the read lengths is computed once per wave instead of once per read: which mate and
+// which 8 bases a lane stages, tail masks, LDS addresses; a read's bytes are at read * L, so no offsets are loaded at
+// all; the 8 bases are fetched as three unconditional aligned dwords (only the last reads of the batch, where the
+// third dword could leave the buffer, take the guarded loads).  The code for a pair without any hit -- stage, U
+// canonical k-mers, U hashes, U summary probes, table probes of the few that pass -- is one straight line; everything
+// a hit needs (decode, lazy validity, vote, emit) sits behind the wave-uniform "something matched" branch and re-reads
+// its parameters there, so it holds no registers while off-target reads stream through.  count[] is zeroed by the host
+// before the launch; only reads with associations write it.
+// ---------------------------------------------------------------------------
+#ifndef SHK_STREAM_READS
+#define SHK_STREAM_READS 0
+#endif
+__device__ __forceinline__ Raw8 load8_issue_all(const uint8_t *p, uint32_t nbytes)
+{
+  const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 3u;
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
+  Raw8 r;
+#if SHK_STREAM_READS
+  r.d0 = __builtin_nontemporal_load(q);
+  r.d1 = __builtin_nontemporal_load(q + 1);
+  r.d2 = __builtin_nontemporal_load(q + 2);
+#else
+  r.d0 = q[0];
+  r.d1 = q[1];
+  r.d2 = q[2];
+#endif
+  r.shn = sh | (nbytes << 4);
+  return r;
+}
+
+// kernel arguments re-read where they are needed: scalar loads from the kernarg segment (the ClassifyParams is the
+// kernel's only argument, at offset 0); the empty asm keeps LICM from turning them into loop-long SGPRs.  (Taking the
+// address of the by-value parameter instead would make the compiler copy all of it to scratch memory.)
+typedef const ClassifyParams __attribute__((address_space(4))) * KernargParams;
+__device__ __forceinline__ KernargParams kernarg_params()
+{
+  KernargParams p = (KernargParams)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// ---- the bound cut -----------------------------------------------------------------------------------------------
+// ReadAnalyzer.hpp:104 keeps a read iff max >= c*len, where max is the largest per-gene coverage: the size of the union of
+// the intervals [p, p+k) of that gene's hits (header comment).  A gene's coverage is therefore at most the number of
+// bases covered by ALL k-mers that are in the filter.  classify_uni_kernel probes the slots of its first E rounds
+// (packed positions < 64 E) first; when none of them is in the filter, every hit the read can still have lies in the
+// remaining slots, which cover bases_behind(64 E) bases.  If that is below the threshold, no gene can reach it, the read
+// has no association whatever the remaining probes would say -- and they are not made.  (2 x 150 bp, k = 17, c = 0.6:
+// after two rounds the rest covers 22 + 150 = 172 < 180 bases, so an off-target pair costs 128 probes instead of 320.)
+// The result is the reference's for every read; tests/test_gpu_parity.py walks chimeric reads across the boundary.
+
+// the smallest integer t with (double)t >= c * (double)len: an integer coverage passes the reference's test iff it is >= t.
+// 0 when the product is not positive (or NaN): nothing can be ruled out
+__device__ __forceinline__ uint32_t cov_threshold(const double c, const uint32_t len)
+{
+  const double x = c * (double)len;
+  if (!(x > 0.0)) return 0u;
+  if (x >= 4294967295.0) return 0xFFFFFFFFu;
+  return (uint32_t)ceil(x);
+}
+
+// bases covered by the existing slots at packed positions >= s (mate 1: slots [0, nk1) cover [0, l1); mate 2 likewise at P2)
+__device__ __forceinline__ uint32_t bases_behind(const uint32_t s, const uint32_t nk1, const uint32_t nk2, const uint32_t P2,
+                                                 const uint32_t l1, const uint32_t l2)
+{
+  uint32_t u = s < nk1 ? l1 - s : 0u;
+  const uint32_t s2 = s > P2 ? s - P2 : 0u;
+  u += s2 < nk2 ? l2 - s2 : 0u;
+  return u;
+}
+
+// The number of first rounds is a compile-time constant of the code that runs (exact register liveness; a run-time split
+// keeps every round's state alive across both phases and spills).  Per U, the candidates that the usual shapes need at the
+// reference's default c = 0.6 (paired mates of equal length: about half the rounds; U = 5 is 2 x 150 bp: two rounds, three
+// for c down to 0.37; U = 3 also serves single-end 150 bp reads: one round).  A read whose bound holds for neither is probed
+// in one go.
+template <int U> struct CutPlan { static constexpr int E0 = U / 2, E1 = U / 2; };
+template <> struct CutPlan<3> { static constexpr int E0 = 1, E1 = 2; };
+template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
+// (-DSHK_NO_CUT=1: a build without the cut, for A/B timing)
+#ifndef SHK_NO_CUT
+#define SHK_NO_CUT 0
+#endif
+#ifndef SHK_NO_TOL
+#define SHK_NO_TOL 0
+#endif
+// MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
+// probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
+// only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
+// LSL = 21: no summary -- the workgroup keeps the index's LDS-resident exact table (shark_internal.hpp LTAB_*; 144 KiB, one
+// 1024-thread workgroup per CU): a probe is two LDS reads, a pair of a tiny index touches no memory but its own bases.
+// LSL: log2 of the LDS summary's bits.  18 = 32 KiB, several 512-thread workgroups per CU (the sparse indices of a few
+// genes); 20 = 128 KiB shared by ONE 1024-thread workgroup per CU -- four times the reach (pass rate <= 30 % up to ~3x10^5
+// set bits, i.e. panels of a hundred genes) at 4 waves per SIMD, for indices that would otherwise probe an L2-resident
+// summary through the vector L1 (one cache line per clock per CU) for every k-mer.
+template <int U, int MODE, int LSL>
+struct UniGeom {
+  static constexpr bool LX = pm_lds(MODE) && LSL == 21;   // the exact table of a tiny index in LDS instead of a summary
+  static constexpr int WAVES = (pm_lds(MODE) && LSL >= 20) ? 16 : 8;
+  static constexpr int THREADS = WAVES * 64;
+  // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes are latency bound: 8 waves per SIMD
+  static constexpr int MIN_WAVES = WAVES == 16 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
+  static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (LX ? LTAB_BYTES * 8u : (1u << LSL)) : 0u;   // what the workgroup keeps in LDS
+  static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
+};
+
+// UNI = false: the same kernel for batches of mixed read lengths (trimmed reads).  The geometry is then per read --
+// offsets prefetched two reads ahead, bases one read ahead, as classify_fast_kernel does it -- but the structure is this
+// kernel's: straight-line miss path, the hit path behind one branch with its own parameter loads, count[] pre-zeroed.  A
+// read with more than 64 U slots or more than 64 staging groups goes to the general kernel's queue.
+template <int U, int MODE, bool HASQ, int LSL, bool UNI>
+__global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
+{
+  constexpr bool POW2 = pm_pow2(MODE);
+  constexpr bool LSUM = pm_lds(MODE);
+  constexpr bool SUM = MODE == PM_TAB_SUM;
+  // the bound cut is compiled in except behind the L2-resident summary: there an off-target pair is already cheap (the summary
+  // rejects its probes without memory traffic) and the second dependent step costs on-target pairs more than the cut saves
+  // (250 / 1 000 genes: 29.0 / 33.9 -> 31.8 / 35.1 ms per 10 M pairs with it)
+  constexpr bool CUT = !SUM && !SHK_NO_CUT;
+  constexpr bool TOL = CUT && !pm_lds(MODE) && !SHK_NO_TOL;   // table modes: matches are counted, and there is a second cut point
+  using UG = UniGeom<U, MODE, LSL>;
+  constexpr bool LX = UG::LX;
+  constexpr int WAVES = UG::WAVES;
+  constexpr uint32_t S = 64 * U;
+  constexpr uint32_t WORDS = stage_words_for(S);
+  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
+  if (P.uni_flag) {
+    // both launches are made when only the device knows whether the batch is uniform: exactly one of them works
+    if ((P.uni_flag[0] == 1u) != UNI) return;
+    L1 = P.uni_flag[1];
+    L2 = P.uni_flag[2];
+  }
+  L1 = __builtin_amdgcn_readfirstlane(L1);
+  L2 = __builtin_amdgcn_readfirstlane(L2);
+  if (LSUM) {
+    // stage the summary: 16 bytes per thread per pass, once per (persistent) workgroup
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
+  uint64_t *wbase = lds + UG::SUM_WORDS64 + wave * WORDS;
+  uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
+  uint32_t *const rv = fw + code_dwords_for(S);
+  uint64_t *const vbits = wbase + code_dwords_for(S);
+  constexpr uint32_t rcap = stage_cap_bases(S);
+
+  // ---- geometry: of every read of the batch (UNI) or of the current read ----------
+  const uint32_t k = P.k;
+  uint32_t nk1, nk2, P2, g2, n_groups, tail_inv, Lm;
+  bool act, m2;
+  auto set_geometry = [&](const uint32_t l1, const uint32_t l2) {
+    nk1 = l1 >= k ? l1 - k + 1 : 0;
+    nk2 = l2 >= k ? l2 - k + 1 : 0;
+    P2 = (l1 + 7u) & ~7u;
+    g2 = P2 >> 3;
+    n_groups = g2 + ((l2 + 7u) >> 3);                 // <= 64 (UNI: checked before this kernel is chosen; else: per read below)
+    // lane -> the 8 bases it stages
+    act = (uint32_t)lane < n_groups;
+    m2 = (uint32_t)lane >= g2;
+    const uint32_t b = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
+    Lm = m2 ? l2 : l1;
+    const uint32_t rem = act ? Lm - b : 8u;
+    tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
+  };
+  set_geometry(L1, L2);
+  // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
+  uint32_t cutE = U, cutUb = 0, cutUb2 = 0, thr_full = 0;
+  auto plan_cut = [&](const uint32_t l1, const uint32_t l2) {
+    cutE = U;
+    cutUb = 0;
+    if (!CUT) return;
+    thr_full = cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
+    // bases_behind falls with e: the smaller candidate is tried last and wins when it qualifies
+    if (CutPlan<U>::E1 != CutPlan<U>::E0) {
+      const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E1, nk1, nk2, P2, l1, l2);
+      if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E1; cutUb = ub; }
+    }
+    const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E0, nk1, nk2, P2, l1, l2);
+    if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
+    if (TOL) cutUb2 = bases_behind(64u * (cutE + 1u), nk1, nk2, P2, l1, l2);   // the second cut point, one round later
+  };
+  if (UNI) plan_cut(L1, L2);
+  const uint32_t b_uni = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
+  const uint8_t *const sbase = (m2 ? P.seq2 : P.seq1) + b_uni;
+  const uint8_t *const qbase = HASQ ? (m2 ? P.qual2 : P.qual1) + b_uni : nullptr;
+  // the unguarded loads read up to 11 bytes behind a group's first byte: fine while that stays inside the mate's buffer
+  const uint32_t n32 = (uint32_t)P.n, stride = gridDim.x * WAVES;
+  const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
+  const uint32_t guard_reads = Lmin >= 12u ? 1u : (Lmin ? (12u + Lmin - 1u) / Lmin : n32);   // trailing reads with guarded loads
+
+  // UNI: read r of a mate is at r * L
+  auto issue = [&](const uint32_t r, Raw8 &w, Raw8 &q) {
+    w = Raw8{0u, 0u, 0u, 0u};
+    q = Raw8{0u, 0u, 0u, 0u};
+    if (act) {
+      const uint64_t o = (uint64_t)r * Lm;
+      if (n32 - r > guard_reads) {
+        w = load8_issue_all(sbase + o, 8u);
+        if (HASQ) q = load8_issue_all(qbase + o, 8u);
+      } else {
+        const uint32_t rem = Lm - b_uni;   // (the last reads of the batch: what is left of the mate decides which dwords exist)
+        w = load8_issue(sbase + o, rem);
+        if (HASQ) q = load8_issue(qbase + o, rem);
+      }
+    }
+  };
+
+  uint32_t read = blockIdx.x * WAVES + wave;
+  if (read >= n32) return;
+  Raw8 w_cur, q_cur;
+  ReadMeta m_cur{}, m_nxt{};
+  if (UNI) {
+    issue(read, w_cur, q_cur);
+  } else {
+    m_cur = fetch_meta(P, read);
+    fetch_group<HASQ>(P, m_cur, (uint32_t)lane, w_cur, q_cur);
+    const uint32_t n1 = n32 - read > stride ? read + stride : n32;
+    m_nxt = fetch_meta(P, n1 < n32 ? n1 : read);
+  }
+  retire_loads(w_cur);
+  retire_loads(q_cur);
+  const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
+  for (;;) {
+    const uint32_t nxt = n32 - read > stride ? read + stride : n32;   // saturates at n32
+    const bool have_nxt = nxt < n32;
+    Raw8 w_nxt = Raw8{0u, 0u, 0u, 0u}, q_nxt = Raw8{0u, 0u, 0u, 0u};
+    ReadMetaRaw r_nn{};
+    uint32_t nn = n32;
+    if (UNI) {
+      if (have_nxt) issue(nxt, w_nxt, q_nxt);
+    } else {
+      if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
+      nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
+      r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
+      set_geometry(m_cur.L1, m_cur.L2);
+    }
+    bool skip = false;
+    if (!UNI) {
+      const uint32_t ns = nk2 ? P2 + nk2 : nk1;
+      if (ns > S || n_groups > 64u) {   // does not fit this specialisation: the general kernel's queue (as process_read does)
+        if (lane == 0) {
+          const ClassifyOut *O = out_ptrs(P);
+          const uint32_t qi = atomicAdd(&O->counters[CTR_LONG], 1u);
+          O->long_queue[qi] = read;
+          atomicMax(&O->counters[CTR_MAX_SLOTS], ns);
+        }
+        skip = true;
+      }
+    }
+    if (!skip) {
+
+    // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
+    uint32_t inv_real = 0u;   // invalid characters among the lane's bases that belong to the read
+    if (act) {
+      const uint32_t sh = w_cur.shn & 3u;
+      const uint32_t lo = __builtin_amdgcn_alignbyte(w_cur.d1, w_cur.d0, sh);
+      const uint32_t hi = __builtin_amdgcn_alignbyte(w_cur.d2, w_cur.d1, sh);
+      uint32_t c_lo, c_hi, i_lo, i_hi;
+      classify4(lo, c_lo, i_lo);
+      classify4(hi, c_hi, i_hi);
+      const uint32_t msb16 = (pack4(c_lo) << 8) | pack4(c_hi);           // first base in bits 15:14
+      // (bytes behind the mate's end are whatever follows in the buffer: their codes land at packed positions that no
+      // existing slot's window covers, and tail_inv marks them invalid)
+      uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4) | tail_inv;
+      if (HASQ) {
+        const uint32_t qs = q_cur.shn & 3u;
+        const uint32_t qlo = __builtin_amdgcn_alignbyte(q_cur.d1, q_cur.d0, qs);
+        const uint32_t qhi = __builtin_amdgcn_alignbyte(q_cur.d2, q_cur.d1, qs);
+        inv8 |= gather4(qmask4(qlo, P.mq)) | (gather4(qmask4(qhi, P.mq)) << 4);
+      }
+      uint32_t lsb = __builtin_bitreverse32(msb16);                      // lands in the high half
+      lsb = ((lsb >> 1) & 0x55555555u) | ((lsb & 0x55555555u) << 1);
+      reinterpret_cast<uint16_t *>(fw)[lane] = (uint16_t)(lsb >> 16);
+      reinterpret_cast<uint16_t *>(rv)[(rcap >> 3) - 1u - (uint32_t)lane] = (uint16_t)msb16;
+      reinterpret_cast<uint8_t *>(vbits)[lane] = (uint8_t)(~inv8 & 0xFFu);
+      inv_real = inv8 & ~tail_inv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
+    if (!UNI) plan_cut(m_cur.L1, m_cur.L2);
+    uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
+    if (cutE < (uint32_t)U) {
+      // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
+      if (__ballot(inv_real != 0u)) {
+        const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
+        thr_r = cov_threshold(P.c, len);
+      }
+    }
+
+    // ---- everything behind the staging, for a compile-time E (rounds [0, E) first; E == U: all at once, no cut) ----
+    auto classify_staged = [&](auto e_const) {
+    constexpr int E = decltype(e_const)::value;
+    uint64_t pos[U];
+    uint32_t okm[U];   // all ones where the slot's probe has to be made, else 0
+    uint4 bk[U];
+    // each probe ends up with one word of its bucket: the low word of the slot that matched (mt[j] says whether one did)
+    bool mt[U];
+    uint32_t slo[U];
+    bool lane_any = false;
+    // ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) reduce a bucket to that word right
+    // away and walk all their probes per round; the 64-VGPR ones keep the buckets until the hit path and walk probe by probe
+#ifndef SHK_ROUNDS_ALL
+#define SHK_ROUNDS_ALL 0
+#endif
+    constexpr bool ROUNDS = LSUM || SHK_ROUNDS_ALL;
+    const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
+    const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
+    const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
+    const uint32_t spare = 1u << P.tab_lg;
+    // the word a slot's high word is compared with (0 = empty slot): tag | valid | displacement 0
+    auto want_of = [&](const int j) -> uint32_t {
+      const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
+      return (tag << 8) | 0x80u;
+    };
+    auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
+    // ---- canonical k-mers, hashes, summary probes, table probes of the rounds [JLO, JHI) ----
+    // (returns false when nothing of these rounds can have matched: no probe passed its summary / no slot is a valid k-mer)
+    auto probe_rounds = [&](auto lo_const, auto hi_const) -> bool {
+      constexpr int JLO = decltype(lo_const)::value, JHI = decltype(hi_const)::value;
+      constexpr bool ALL = JLO == 0 && JHI == U;   // the only phase: its caller ends the read when nothing can have matched
+      {
+        const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
+        const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t *f = fw + ((uint32_t)lane >> 4) + 4 * j;
+          const uint32_t *r = rv + (qU >> 4) + 4 * (U - 1 - j);
+          const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+          const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+          const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
+          const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
+          const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+          const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
+          const uint64_t hsh = xxh64_u64(canon);
+          // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+          pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
+        }
+      }
+      bool something = false;
+      if (!LSUM) {
+        // slot pp exists and all its k characters are valid (process_read, slot_ok); then the L2-resident summary
+        const uint64_t kmask0 = (1ull << k) - 1ull;
+        bool ok[U];
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t pp = (uint32_t)lane + 64u * j;
+          const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+          const uint32_t V = pp >> 6, vs = pp & 63u;
+          const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
+          const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+          ok[j] = exists & ((win & kmask0) == kmask0);
+        }
+        if (SUM) {
+          uint32_t sw[U];
+#pragma unroll
+          for (int j = JLO; j < JHI; ++j) sw[j] = ok[j] ? P.sum32[(pos[j] >> P.sum_shift) >> 5] : 0u;
+#pragma unroll
+          for (int j = JLO; j < JHI; ++j) ok[j] = (sw[j] >> ((uint32_t)(pos[j] >> P.sum_shift) & 31u)) & 1u;
+        }
+        bool any = false;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) { okm[j] = ok[j] ? 0xFFFFFFFFu : 0u; any |= ok[j]; }
+        something = __ballot(any) != 0ull;
+      } else if (LX) {
+        // the exact table in LDS: displacement of the position's group, then the slot (shark_internal.hpp)
+        const uint32_t *T = lsum;
+        const char *D = reinterpret_cast<const char *>(lsum + LTAB_T_WORDS);
+        const uint32_t tagmask15 = (uint32_t)(P.bf_mask >> LTAB_SLOT_LG);
+        const uint32_t gmask2 = (tagmask15 & ((1u << LTAB_GROUP_LG) - 1u)) << 1;   // (pos[] is the raw hash: only the filter's bits count)
+        uint32_t dd[U], ee[U];
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j)
+          dd[j] = *reinterpret_cast<const uint16_t *>(D + (((uint32_t)pos[j] >> (LTAB_SLOT_LG - 1)) & gmask2));
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j)
+          ee[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + ((((uint32_t)pos[j] + dd[j]) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+        bool esc = false, any = false;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], LTAB_SLOT_LG) & tagmask15;
+          mt[j] = (ee[j] >> 13) == ((tag << 1) | 1u);
+          slo[j] = ee[j] & LTAB_ESC;
+          okm[j] = mt[j] ? 0xFFFFFFFFu : 0u;
+          any |= mt[j];
+          esc |= mt[j] & (slo[j] == LTAB_ESC);
+        }
+        // a multi-gene list (or a gene id beyond 13 bits) is not in the entry: the position table answers for these rounds
+        something = __ballot(esc) != 0ull;
+        if (!something) lane_any |= any;
+      } else {
+        uint32_t si[U], sw[U];
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          si[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.lsum_shift);   // low LSL bits = summary index
+          sw[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lsum) + ((si[j] >> 3) & (UG::SUM_BITS / 8 - 4)));
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          okm[j] = (uint32_t)__builtin_amdgcn_sbfe((int)sw[j], si[j], 1u);   // v_bfe_i32: bit (si & 31), sign extended
+          any |= okm[j];
+        }
+        something = __ballot(any != 0u) != 0ull;
+      }
+      if (something) {
+        // ---- position table: the probes that passed read their home bucket, the others the spare empty bucket ----
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t bb = (uint32_t)pos[j] & bmask;
+          const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
+          if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
+            bk[j] = make_uint4(v.x, v.y, v.z, v.w);
+          } else {
+            bk[j] = load_bucket<LSUM && UNI>(tab16, bi);   // (the ragged instantiation runs out of registers with the short addresses)
+          }
+        }
+        bool lane_more = false;
+        bool more[U];
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t want = want_of(j);
+          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+          if (ROUNDS) {
+            mt[j] = m0 | m1;
+            slo[j] = m0 ? bk[j].x : bk[j].z;
+          }
+          lane_any |= m0 | m1;
+          more[j] = !(m0 | m1) & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
+          lane_more |= more[j];
+        }
+        if (__ballot(lane_more) && !SHK_ABL(P, 8u)) {   // (ablation 8: no walks)
+          // rare: the key may sit behind its (full) home bucket
+          if (ROUNDS) {
+            // round d looks at bucket home+d of every probe that is still searching, all loads in flight together (the
+            // others read the spare bucket: one line for the wave) -- a memory round trip per displacement, not per probe
+            uint32_t d = 0;
+            do {
+              ++d;
+#pragma unroll
+              for (int j = JLO; j < JHI; ++j) bk[j] = load_bucket<LSUM && UNI>(tab16, more[j] ? bucket_of(j, d) : spare);
+              lane_more = false;
+#pragma unroll
+              for (int j = JLO; j < JHI; ++j) {
+                const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
+                const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
+                const bool found = more[j] & (n0 | n1);
+                const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
+                slo[j] = found ? (n0 ? bk[j].x : bk[j].z) : slo[j];
+                mt[j] |= found;
+                lane_any |= found;
+                more[j] = more[j] & !found & !ends;
+                lane_more |= more[j];
+              }
+            } while (__ballot(lane_more));
+          } else {
+            walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
+          }
+        }
+      } else if (!LX && !ALL) {
+        // nothing of these rounds passed the summary: no matches (the hit path may still run for the other rounds)
+#pragma unroll
+        for (int j = JLO; j < JHI; ++j) {
+          if (ROUNDS) { mt[j] = false; slo[j] = 0u; }
+          else bk[j] = make_uint4(0u, 0u, 0u, 0u);   // (an empty slot's compared word is 0: matches nothing)
+        }
+      }
+      return LX || something;
+    };
+    // bases covered by the slots of a hit mask (one ballot per round): the union of [p, p + k), counted as the hit path
+    // counts a gene's coverage
+    const uint64_t kthr_c = 1ull << (64u - k);
+    auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
+      const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
+      return (uint32_t)__builtin_popcountll(__ballot(t >= kthr_c));
+    };
+    // ... by ALL k-mers of the rounds [0, J) that are in the filter
+    auto found_cover = [&](auto j_const) -> uint32_t {
+      constexpr int J = decltype(j_const)::value;
+      uint64_t Hp = 0ull;
+      uint32_t cv = 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        bool m;
+        if (ROUNDS) m = mt[j];
+        else { const uint32_t want = want_of(j); m = (bk[j].y == want) | (bk[j].w == want); }
+        const uint64_t Hc = __ballot(m);
+        cv += cover(Hc, Hp);
+        Hp = Hc;
+      }
+      return cv + cover(0ull, Hp);
+    };
+    // ... by the k-mers of the rounds [0, J) that can belong to ONE gene, maximised over the genes: a match with a single-gene
+    // list counts for that gene only, a match with a multi-gene list for every gene.  (The matches of an off-target read of a
+    // large reference are isolated k-mers of different genes: k bases each, whatever their number.)  At most 8 genes are
+    // looked at; beyond that the answer is "everything" (no cut).
+    auto gene_cover = [&](auto j_const) -> uint32_t {
+      constexpr int J = decltype(j_const)::value;
+      uint64_t H[J], W[J];
+      uint32_t gid[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const uint32_t want = want_of(j);
+        const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+        const uint32_t lo = ROUNDS ? slo[j] : (m0 ? bk[j].x : bk[j].z);
+        const bool m = ROUNDS ? mt[j] : (m0 | m1), multi = (lo >> 31) != 0u;
+        gid[j] = lo & 0xFFFFu;
+        H[j] = __ballot(m & !multi);
+        W[j] = __ballot(m & multi);
+      }
+      uint32_t best = 0;
+      {
+        uint64_t Hp = 0ull;
+#pragma unroll
+        for (int j = 0; j < J; ++j) { best += cover(W[j], Hp); Hp = W[j]; }
+        best += cover(0ull, Hp);
+      }
+      for (int it = 0; it < 8; ++it) {
+        uint32_t g = 0;
+        bool have = false;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if (!have && H[j] != 0ull) {
+            g = (uint32_t)__builtin_amdgcn_readlane((int)gid[j], (int)__builtin_ctzll(H[j]));
+            have = true;
+          }
+        if (!have) return best;
+        uint64_t Hp = 0ull;
+        uint32_t cv = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const uint64_t G = __ballot((((H[j] >> (uint32_t)lane) & 1ull) != 0ull) & (gid[j] == g));
+          H[j] &= ~G;
+          const uint64_t M = G | W[j];
+          cv += cover(M, Hp);
+          Hp = M;
+        }
+        cv += cover(0ull, Hp);
+        best = cv > best ? cv : best;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (H[j] != 0ull) return 0xFFFFFFFFu;
+      return best;
+    };
+    if (!probe_rounds(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}) && E == U) return;
+    if (E < U) {
+      // the bound cut: what is in the filter so far covers `cv` bases, the slots of the remaining rounds cover cutUb: together
+      // fewer than c * len -- no gene can reach the threshold (ReadAnalyzer.hpp:104), the read has no association.
+      // LDS modes stop only without any match (their matches are not validated yet, and a gene's k-mers are rare among
+      // an off-target read's); the table modes -- large references, where a random k-mer IS in the filter every few dozen
+      // slots -- count what the matches cover, and try once more a round later.
+      constexpr int E2 = (TOL && E + 1 < U) ? E + 1 : U;
+      const bool anyA = __ballot(lane_any) != 0ull;
+      if (!anyA || TOL) {
+        const uint32_t cv = anyA ? found_cover(std::integral_constant<int, E>{}) : 0u;
+        if (cutUb + cv < thr_r) return;
+      }
+      if (E2 < U) {
+        probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, std::integral_constant<int, E2>{});
+        uint32_t cv = __ballot(lane_any) ? found_cover(std::integral_constant<int, E2>{}) : 0u;
+        if (cutUb2 + cv >= thr_r) cv = gene_cover(std::integral_constant<int, E2>{});   // (the cheap bound first)
+        if (cutUb2 < thr_r && cv < thr_r - cutUb2) return;
+      }
+      probe_rounds(std::integral_constant<int, (E2 < U ? E2 : (E < U ? E : 0))>{}, std::integral_constant<int, U>{});
+    }
+    {
+      if (__ballot(lane_any) && !SHK_ABL(P, 16u)) {   // (ablation 16: no hit path)
+        // ================= something matched in the table: the hit path =================
+        KernargParams H = kernarg_params();
+        const uint32_t hk = H->k;
+        const uint64_t kmask = (1ull << hk) - 1ull;
+        uint32_t cur[U], rs[U], re[U];
+        bool hit[U], multi[U];
+        uint32_t payload[U];
+        bool any2 = false;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          // the probe was issued without looking at the slot: it has to exist and be a valid k-mer (process_read, slot_ok)
+          const uint32_t pp = (uint32_t)lane + 64u * j;
+          const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+          const uint32_t V = pp >> 6, vs = pp & 63u;
+          const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
+          const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+          if (!ROUNDS) {
+            const uint32_t want = want_of(j);
+            const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+            mt[j] = m0 | m1;
+            slo[j] = m0 ? bk[j].x : bk[j].z;
+          }
+          hit[j] = LSUM ? (mt[j] & exists & ((win & kmask) == kmask)) : mt[j];   // (table modes settled that before the probe)
+          any2 |= hit[j];
+          payload[j] = slo[j] & TAB_PAYLOAD;
+          multi[j] = (slo[j] >> 31) != 0u;
+        }
+        if (__ballot(any2)) {
+          bool lane_multi = false;
+#pragma unroll
+          for (int j = 0; j < U; ++j) lane_multi |= hit[j] & multi[j];
+          if (__ballot(lane_multi)) {   // multi-gene lists (rare): entry r gives start/len/first gene
+            ListEntry le[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) le[j] = H->ent[(hit[j] & multi[j]) ? payload[j] : 0u];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              if (hit[j] & multi[j]) {
+                rs[j] = le[j].start;
+                re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : H->ent[payload[j] + 1].start;
+                cur[j] = le[j].gene0;
+              } else {
+                rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
+          }
+          // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49)
+          const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
+          uint32_t best_cov = 0, best_nk = 0, n_best = 0;
+          uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
+          // ---- k-way merge over the hit lists, ascending gene id (see process_read for the derivation) ----
+          const uint64_t kthr = 1ull << (64u - hk);
+          for (;;) {
+            uint32_t mymin = GENE_INF;
+#pragma unroll
+            for (int j = 0; j < U; ++j) mymin = cur[j] < mymin ? cur[j] : mymin;
+            const uint32_t g = wave_min_u32(mymin);
+            if (g == GENE_INF || SHK_ABL(P, 32u)) break;   // (ablation 32: no merge)
+            uint32_t nk = 0, cov = 0;
+            auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
+              const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
+              return (uint32_t)__builtin_popcountll(__ballot(t >= kthr));
+            };
+            uint64_t Hm[U];
+            bool more_ids = false;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              const bool h = cur[j] == g;
+              Hm[j] = __ballot(h);
+              rs[j] += h ? 1u : 0u;
+              more_ids |= h & (rs[j] < re[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+              nk += (uint32_t)__builtin_popcountll(Hm[j]);
+              cov += cover(Hm[j], j ? Hm[j - 1] : 0ull);
+            }
+            cov += cover(0ull, Hm[U - 1]);
+            if (__ballot(more_ids)) {
+#pragma unroll
+              for (int j = 0; j < U; ++j)
+                if ((Hm[j] >> lane) & 1ull) cur[j] = rs[j] < re[j] ? (uint32_t)H->ids[rs[j]] : GENE_INF;
+            } else {
+#pragma unroll
+              for (int j = 0; j < U; ++j) cur[j] = ((Hm[j] >> lane) & 1ull) ? GENE_INF : cur[j];
+            }
+            // arg-max with ties in ascending gene order, as selects (see the compiler note in process_read)
+            const bool gt = (cov > best_cov) | ((cov == best_cov) & (nk > best_nk));
+            const bool eq = (cov == best_cov) & (nk == best_nk);
+            best_id[0] = gt ? g : best_id[0];
+#pragma unroll
+            for (int i = 1; i < SHK_INLINE_IDS; ++i) best_id[i] = (eq & (n_best == (uint32_t)i)) ? g : best_id[i];
+            n_best = gt ? 1u : (eq ? n_best + 1u : n_best);
+            best_cov = gt ? cov : best_cov;
+            best_nk = gt ? nk : best_nk;
+          }
+          // ---- threshold + --single (ReadAnalyzer.hpp:104) ----
+          uint32_t n_out = 0;
+          if (n_best > 0 && (double)best_cov >= H->c * (double)len && (!H->single || n_best == 1)) n_out = n_best;
+          if (n_out > 0 && lane == 0 && !SHK_ABL(P, 64u)) {   // (ablation 64: no result store)
+            const ClassifyOut *O = H->out;
+            O->count[read] = n_out;
+            uint2 pk;
+            pk.x = (best_id[0] & 0xFFFFu) | (best_id[1] << 16);
+            pk.y = (best_id[2] & 0xFFFFu) | (best_id[3] << 16);
+            *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+            if (n_out > SHK_INLINE_IDS) {
+              const uint32_t qi = atomicAdd(&O->counters[CTR_TIE], 1u);
+              O->tie_queue[3 * qi + 0] = read;
+              O->tie_queue[3 * qi + 1] = best_cov;
+              O->tie_queue[3 * qi + 2] = best_nk;
+            }
+          }
+        }
+      }
+    }
+    };   // classify_staged
+    // the first-round counts this specialisation is compiled for (CutPlan<U>): cutE is one of them, or U
+    if (CUT && cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E0 : U)>{});
+    else if (CUT && CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E1 : U)>{});
+    else classify_staged(std::integral_constant<int, U>{});
+    }   // !skip
+    if (!have_nxt) break;
+    retire_loads(w_nxt);
+    retire_loads(q_nxt);
+    if (!UNI) {
+      retire_meta(r_nn);
+      m_cur = m_nxt;
+      m_nxt = meta_finish(r_nn);
+    }
+    read = nxt; w_cur = w_nxt; q_cur = q_nxt;
+  }
+}
+
+template <int U>
+static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s)
+{
+#define LU4(M_, L_, HQ_, UN_) hipLaunchKernelGGL((classify_uni_kernel<U, M_, HQ_, L_, UN_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p)
+#define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
+                        else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
+  switch (mode) {
+  case PM_LDS_TAB:
+    if (lx) { if constexpr (U <= 5) LU(PM_LDS_TAB, 21); }   // (launch_classify_uni asks for it only where it is compiled)
+    else if (big) LU(PM_LDS_TAB, 20);
+    else LU(PM_LDS_TAB, 18);
+    break;
+  case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
+  case PM_TAB: LU(PM_TAB, 18); break;
+  case PM_TAB_MOD: LU(PM_TAB_MOD, 18); break;
+  default: LU(PM_TAB_SUM, 18); break;
+  }
+#undef LU
+#undef LU4
+}
+
+}  // namespace shk

@@ -454,7 +454,7 @@ int build_index(Ctx *ctx)
             ix.lsum_shift = sh;
           }
         }
-        // too dense for 2^18 bits: a 2^20-bit summary for the uniform-length kernel (128 KiB of LDS, classify.hip LSL = 20)
+        // too dense for 2^18 bits: a 2^20-bit summary for the uniform-length kernel (128 KiB of LDS, classify_uni.hpp LSL = 20)
         ix.lbig_shift = 0;
         // (only where the table has outgrown an XCD's L2: 100 genes 24.4 -> 20.2 ms, 150 genes 26.3 -> 24.5 ms per 10 M pairs;
         //  with a 4 MiB table probing it directly is as fast, 60 genes 19.7 ms)
@@ -471,7 +471,7 @@ int build_index(Ctx *ctx)
           }
         }
         // tiny indices (a gene or a few): the whole table fits the LDS of a CU as a perfect hash -- uniform batches then
-        // touch no memory but their own bases (classify.hip LSL = 21); the chains above stay for trimmed reads
+        // touch no memory but their own bases (classify_uni.hpp LSL = 21); the chains above stay for trimmed reads
         if (ix.ltab) { (void)hipFree(ix.ltab); ix.ltab = nullptr; }
         if (ix.pow2 && ix.lsum_shift && lgB >= 24 && lgB <= LTAB_SLOT_LG + 18 && n_set <= LTAB_MAX_KEYS && !getenv("SHK_NO_LDS_TABLE")) {
           std::vector<uint64_t> h_tab(slots);

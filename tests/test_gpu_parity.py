@@ -920,7 +920,7 @@ def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
 
 
 # ---------------------------------------------------------------------------
-# the bound cut of classify_uni_kernel (classify.hip: rounds [0, E) first; a read none of whose first slots is in the filter
+# the bound cut of classify_uni_kernel (classify_uni.hpp: rounds [0, E) first; a read none of whose first slots is in the filter
 # ends there when the remaining slots cannot reach c * len): chimeric reads whose on-target part starts or ends anywhere
 # in either mate, for thresholds on both sides of what the remaining rounds cover
 # ---------------------------------------------------------------------------
