@@ -18,6 +18,11 @@
 #define SHK_TAB_WAVES 8
 #endif
 
+// waves of the one workgroup per CU that holds the LDS-resident table (16 = the most a workgroup can have; 8 for the occupancy experiment)
+#ifndef SHK_LX_WAVES
+#define SHK_LX_WAVES 16
+#endif
+
 namespace shk {
 
 constexpr int CF_WAVES = 4;              // wavefronts per workgroup
