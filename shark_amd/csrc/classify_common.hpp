@@ -18,6 +18,10 @@
 #define SHK_TAB_WAVES 8
 #endif
 
+// (-DSHK_NO_ACCEPT=1: a build without the early decision, for A/B timing)
+#ifndef SHK_NO_ACCEPT
+#define SHK_NO_ACCEPT 0
+#endif
 // waves of the one workgroup per CU that holds the LDS-resident table (16 = the most a workgroup can have; 8 for the occupancy experiment)
 #ifndef SHK_LX_WAVES
 #define SHK_LX_WAVES 16

@@ -129,6 +129,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // (250 / 1 000 genes: 29.0 / 33.9 -> 31.8 / 35.1 ms per 10 M pairs with it)
   constexpr bool CUT = !SUM && !SHK_NO_CUT;
   constexpr bool TOL = CUT && !pm_lds(MODE) && !SHK_NO_TOL;   // table modes: matches are counted, and there is a second cut point
+  constexpr bool ACCEPT = !SHK_NO_ACCEPT;                      // the early decision (vote<J> with J < U)
   using UG = UniGeom<U, MODE, LSL>;
   constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
@@ -180,10 +181,13 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   };
   set_geometry(L1, L2);
   // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
-  uint32_t cutE = U, cutUb = 0, cutUb2 = 0, thr_full = 0;
+  // ubJA = the same for the stop of the early decision (JA_ROUNDS rounds; vote<J> below)
+  constexpr int JA_ROUNDS = (ACCEPT && CutPlan<U>::E0 + 1 < U) ? CutPlan<U>::E0 + 1 : U;
+  uint32_t cutE = U, cutUb = 0, ubJA = 0, thr_full = 0;
   auto plan_cut = [&](const uint32_t l1, const uint32_t l2) {
     cutE = U;
     cutUb = 0;
+    if (JA_ROUNDS < U) ubJA = bases_behind(64u * (uint32_t)JA_ROUNDS, nk1, nk2, P2, l1, l2);
     if (!CUT) return;
     thr_full = cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
     // bases_behind falls with e: the smaller candidate is tried last and wins when it qualifies
@@ -193,7 +197,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E0, nk1, nk2, P2, l1, l2);
     if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
-    if (TOL) cutUb2 = bases_behind(64u * (cutE + 1u), nk1, nk2, P2, l1, l2);   // the second cut point, one round later
   };
   if (UNI) plan_cut(L1, L2);
   const uint32_t b_uni = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
@@ -562,39 +565,27 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         if (H[j] != 0ull) return 0xFFFFFFFFu;
       return best;
     };
-    if (!probe_rounds(std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}) && E == U) return;
-    if (E < U) {
-      // the bound cut: what is in the filter so far covers `cv` bases, the slots of the remaining rounds cover cutUb: together
-      // fewer than c * len -- no gene can reach the threshold (ReadAnalyzer.hpp:104), the read has no association.
-      // LDS modes stop only without any match (their matches are not validated yet, and a gene's k-mers are rare among
-      // an off-target read's); the table modes -- large references, where a random k-mer IS in the filter every few dozen
-      // slots -- count what the matches cover, and try once more a round later.
-      constexpr int E2 = (TOL && E + 1 < U) ? E + 1 : U;
-      const bool anyA = __ballot(lane_any) != 0ull;
-      if (!anyA || TOL) {
-        const uint32_t cv = anyA ? found_cover(std::integral_constant<int, E>{}) : 0u;
-        if (cutUb + cv < thr_r) return;
-      }
-      if (E2 < U) {
-        probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, std::integral_constant<int, E2>{});
-        uint32_t cv = __ballot(lane_any) ? found_cover(std::integral_constant<int, E2>{}) : 0u;
-        if (cutUb2 + cv >= thr_r) cv = gene_cover(std::integral_constant<int, E2>{});   // (the cheap bound first)
-        if (cutUb2 < thr_r && cv < thr_r - cutUb2) return;
-      }
-      probe_rounds(std::integral_constant<int, (E2 < U ? E2 : (E < U ? E : 0))>{}, std::integral_constant<int, U>{});
-    }
-    {
-      if (__ballot(lane_any) && !SHK_ABL(P, 16u)) {   // (ablation 16: no hit path)
+    // ---- the vote over the matches of the rounds [0, J) (ReadAnalyzer.hpp:56-62, :79-108) ------------------------------------
+    // J == U: every slot is probed, the result is final and written.  J < U (the early decision): the slots not probed yet cover
+    // `ub_rest` bases, so every gene's final coverage is at most (its coverage now) + ub_rest, and the best gene's is at least
+    // what it is now.  If that gene alone is best, passes c * len already, and leads every other gene -- those without a match so
+    // far included -- by more than ub_rest, the remaining probes cannot change the outcome: it is the read's only association
+    // (whatever its final coverage and k-mer count, which the reference does not output).  Returns true when the read is settled.
+    auto vote = [&](auto j_const, const uint32_t ub_rest) -> bool {
+      constexpr int J = decltype(j_const)::value;
+      constexpr bool FINAL = J == U;
+      if (!__ballot(lane_any) || SHK_ABL(P, 16u)) return FINAL;   // nothing matched (ablation 16: no hit path)
+      {
         // ================= something matched in the table: the hit path =================
         KernargParams H = kernarg_params();
         const uint32_t hk = H->k;
         const uint64_t kmask = (1ull << hk) - 1ull;
-        uint32_t cur[U], rs[U], re[U];
-        bool hit[U], multi[U];
-        uint32_t payload[U];
+        uint32_t cur[J], rs[J], re[J];
+        bool hit[J], multi[J];
+        uint32_t payload[J];
         bool any2 = false;
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
+        for (int j = 0; j < J; ++j) {
           // the probe was issued without looking at the slot: it has to exist and be a valid k-mer (process_read, slot_ok)
           const uint32_t pp = (uint32_t)lane + 64u * j;
           const bool exists = (pp < nk1) | ((pp - P2) < nk2);
@@ -612,16 +603,17 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           payload[j] = slo[j] & TAB_PAYLOAD;
           multi[j] = (slo[j] >> 31) != 0u;
         }
-        if (__ballot(any2)) {
+        if (!__ballot(any2)) return FINAL;
+        {
           bool lane_multi = false;
 #pragma unroll
-          for (int j = 0; j < U; ++j) lane_multi |= hit[j] & multi[j];
+          for (int j = 0; j < J; ++j) lane_multi |= hit[j] & multi[j];
           if (__ballot(lane_multi)) {   // multi-gene lists (rare): entry r gives start/len/first gene
-            ListEntry le[U];
+            ListEntry le[J];
 #pragma unroll
-            for (int j = 0; j < U; ++j) le[j] = H->ent[(hit[j] & multi[j]) ? payload[j] : 0u];
+            for (int j = 0; j < J; ++j) le[j] = H->ent[(hit[j] & multi[j]) ? payload[j] : 0u];
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
+            for (int j = 0; j < J; ++j) {
               if (hit[j] & multi[j]) {
                 rs[j] = le[j].start;
                 re[j] = le[j].len != 0xFFFFu ? le[j].start + le[j].len : H->ent[payload[j] + 1].start;
@@ -632,49 +624,45 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
             }
           } else {
 #pragma unroll
-            for (int j = 0; j < U; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
+            for (int j = 0; j < J; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
           }
           // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49)
           const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
-          uint32_t best_cov = 0, best_nk = 0, n_best = 0;
+          uint32_t best_cov = 0, best_nk = 0, n_best = 0, second_cov = 0;
           uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
           // ---- k-way merge over the hit lists, ascending gene id (see process_read for the derivation) ----
-          const uint64_t kthr = 1ull << (64u - hk);
           for (;;) {
             uint32_t mymin = GENE_INF;
 #pragma unroll
-            for (int j = 0; j < U; ++j) mymin = cur[j] < mymin ? cur[j] : mymin;
+            for (int j = 0; j < J; ++j) mymin = cur[j] < mymin ? cur[j] : mymin;
             const uint32_t g = wave_min_u32(mymin);
             if (g == GENE_INF || SHK_ABL(P, 32u)) break;   // (ablation 32: no merge)
             uint32_t nk = 0, cov = 0;
-            auto cover = [&](const uint64_t Hc, const uint64_t Hp) -> uint32_t {
-              const uint64_t t = (Hc << (63u - (uint32_t)lane)) | ((Hp >> 1) >> (uint32_t)lane);
-              return (uint32_t)__builtin_popcountll(__ballot(t >= kthr));
-            };
-            uint64_t Hm[U];
+            uint64_t Hm[J];
             bool more_ids = false;
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
+            for (int j = 0; j < J; ++j) {
               const bool h = cur[j] == g;
               Hm[j] = __ballot(h);
               rs[j] += h ? 1u : 0u;
               more_ids |= h & (rs[j] < re[j]);
             }
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
+            for (int j = 0; j < J; ++j) {
               nk += (uint32_t)__builtin_popcountll(Hm[j]);
               cov += cover(Hm[j], j ? Hm[j - 1] : 0ull);
             }
-            cov += cover(0ull, Hm[U - 1]);
+            cov += cover(0ull, Hm[J - 1]);
             if (__ballot(more_ids)) {
 #pragma unroll
-              for (int j = 0; j < U; ++j)
+              for (int j = 0; j < J; ++j)
                 if ((Hm[j] >> lane) & 1ull) cur[j] = rs[j] < re[j] ? (uint32_t)H->ids[rs[j]] : GENE_INF;
             } else {
 #pragma unroll
-              for (int j = 0; j < U; ++j) cur[j] = ((Hm[j] >> lane) & 1ull) ? GENE_INF : cur[j];
+              for (int j = 0; j < J; ++j) cur[j] = ((Hm[j] >> lane) & 1ull) ? GENE_INF : cur[j];
             }
             // arg-max with ties in ascending gene order, as selects (see the compiler note in process_read)
+            { const uint32_t lower = cov < best_cov ? cov : best_cov; second_cov = lower > second_cov ? lower : second_cov; }   // largest coverage that is not the best one's
             const bool gt = (cov > best_cov) | ((cov == best_cov) & (nk > best_nk));
             const bool eq = (cov == best_cov) & (nk == best_nk);
             best_id[0] = gt ? g : best_id[0];
@@ -686,7 +674,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           }
           // ---- threshold + --single (ReadAnalyzer.hpp:104) ----
           uint32_t n_out = 0;
-          if (n_best > 0 && (double)best_cov >= H->c * (double)len && (!H->single || n_best == 1)) n_out = n_best;
+          if (FINAL) {
+            if (n_best > 0 && (double)best_cov >= H->c * (double)len && (!H->single || n_best == 1)) n_out = n_best;
+          } else {
+            if (n_best == 1 && best_cov > second_cov + ub_rest && (double)best_cov >= H->c * (double)len) n_out = 1;
+          }
           if (n_out > 0 && lane == 0 && !SHK_ABL(P, 64u)) {   // (ablation 64: no result store)
             const ClassifyOut *O = H->out;
             O->count[read] = n_out;
@@ -701,9 +693,52 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
               O->tie_queue[3 * qi + 2] = best_nk;
             }
           }
+          return FINAL || n_out > 0;
         }
       }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IE = std::integral_constant<int, E>;
+    using IU = std::integral_constant<int, U>;
+    // JA: the stop at which the early decision is tried (one round behind the usual first stop), and where the table modes
+    // try the cut a second time
+    constexpr int JA = JA_ROUNDS;
+    using IA = std::integral_constant<int, JA>;
+    // the bound cut at a stop behind the rounds [0, J): what is in the filter so far covers `cv` bases, the slots not probed
+    // yet cover `ub`: together fewer than c * len -- no gene can reach the threshold (ReadAnalyzer.hpp:104), the read has no
+    // association.  LDS modes stop only without any match (their matches are not validated yet, and a gene's k-mers are rare
+    // among an off-target read's); the table modes -- large references, where a random k-mer IS in the filter every few dozen
+    // slots -- count what the matches cover: the union of everything found first, then the largest coverage for ONE gene.
+    auto ruled_out = [&](auto j_const, const uint32_t ub, const bool per_gene) -> bool {
+      if (ub >= thr_r) return false;
+      if (!__ballot(lane_any)) return true;
+      if (!TOL) return false;
+      if (found_cover(j_const) < thr_r - ub) return true;
+      return per_gene && gene_cover(j_const) < thr_r - ub;
+    };
+    if constexpr (JA >= U) {
+      // nothing to decide early (two rounds): the cut's first stop at most
+      if constexpr (E < U) {
+        probe_rounds(I0{}, IE{});
+        if (ruled_out(IE{}, cutUb, false)) return;
+        probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, IU{});
+      } else {
+        if (!probe_rounds(I0{}, IU{})) return;
+      }
+    } else {
+      if constexpr (E < JA) {
+        probe_rounds(I0{}, IE{});
+        if (ruled_out(IE{}, cutUb, false)) return;
+        probe_rounds(std::integral_constant<int, (E < JA ? E : 0)>{}, IA{});
+        if (ruled_out(IA{}, ubJA, true)) return;
+      } else {
+        probe_rounds(I0{}, IA{});
+        if (E == JA && ruled_out(IA{}, ubJA, true)) return;   // (E == U: no cut for this read's geometry and c)
+      }
+      if (vote(IA{}, ubJA)) return;
+      probe_rounds(std::integral_constant<int, (JA < U ? JA : 0)>{}, IU{});
     }
+    vote(IU{}, 0u);
     };   // classify_staged
     // the first-round counts this specialisation is compiled for (CutPlan<U>): cutE is one of them, or U
     if (CUT && cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E0 : U)>{});

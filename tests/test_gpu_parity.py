@@ -932,6 +932,8 @@ def _chimeric_batch(rng, genes, n, L1, L2, ragged, with_n, qual, k_hint=17):
         for L in (L1, L2):
             if L == 0:
                 continue
+            if mates and rng.random() < 0.3:        # mate 2 from another gene: two genes lead by turns (the early decision)
+                g = genes[int(rng.integers(0, len(genes)))]
             l = int(rng.integers(max(1, (2 * L) // 3), L + 1)) if ragged else L
             m = synth.random_seq(rng, l)
             st = int(rng.integers(0, len(g) - l + 1))
