@@ -188,8 +188,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     cutE = U;
     cutUb = 0;
     if (JA_ROUNDS < U) ubJA = bases_behind(64u * (uint32_t)JA_ROUNDS, nk1, nk2, P2, l1, l2);
-    if (!CUT) return;
     thr_full = cov_threshold(P.c, l1 + l2);   // len <= l1 + l2: the joiner is not a valid character
+    if (!CUT) return;
     // bases_behind falls with e: the smaller candidate is tried last and wins when it qualifies
     if (CutPlan<U>::E1 != CutPlan<U>::E0) {
       const uint32_t ub = bases_behind(64u * (uint32_t)CutPlan<U>::E1, nk1, nk2, P2, l1, l2);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
     if (!UNI) plan_cut(m_cur.L1, m_cur.L2);
     uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
-    if (cutE < (uint32_t)U) {
+    if (cutE < (uint32_t)U || JA_ROUNDS < U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
       if (__ballot(inv_real != 0u)) {
         const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
@@ -732,8 +732,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         probe_rounds(std::integral_constant<int, (E < JA ? E : 0)>{}, IA{});
         if (ruled_out(IA{}, ubJA, true)) return;
       } else {
+        // (E == JA: the cut's first stop.  E == U: no stop was planned -- c is small, or the index sits behind the L2 summary,
+        //  where a stop of its own cost more than it saved -- but this one exists anyway, so the cut is tried at it)
         probe_rounds(I0{}, IA{});
-        if (E == JA && ruled_out(IA{}, ubJA, true)) return;   // (E == U: no cut for this read's geometry and c)
+        if (ruled_out(IA{}, ubJA, true)) return;
       }
       if (vote(IA{}, ubJA)) return;
       probe_rounds(std::integral_constant<int, (JA < U ? JA : 0)>{}, IU{});
