@@ -311,9 +311,11 @@ def main():
                 "bytes_per_read": round(alg_bytes / (2 * n), 1),
                 "kmers": int(w["n_kmers"]), "hits": int(w["n_hits"]),
                 "algorithmic_bytes": "SURVEY 8(d) per-read figure over every k-mer of every read, as the reference visits them; the kernel's bound "
-                                     "cut (DESIGN.md 3) proves most probes of an off-target pair irrelevant and does not make them",
-                "binding_resource": "VALU issue (the algorithmic bytes above mostly never reach HBM: this index's exact table is held in LDS, "
-                                    "and a pair none of whose first 128 slots is in the filter ends there -- the other slots cannot reach c*len)"
+                                     "cut and early decision (DESIGN.md 3) prove most probes of an off-target pair and two fifths of an "
+                                     "on-target pair's irrelevant and do not make them",
+                "binding_resource": "VALU issue (the algorithmic bytes above mostly never reach HBM: this index's exact table is held in LDS; "
+                                    "a pair none of whose first 128 slots is in the filter ends there -- the other slots cannot reach c*len --, and "
+                                    "a pair whose best gene after 192 slots cannot be caught up by any other is decided there)"
                                     if h.probe_mode() == "lds-table" else
                                     "VALU issue (the algorithmic bytes above mostly never reach HBM: the LDS summary proves clear probes clear, "
                                     "hits are served by the L2-resident position table)",
