@@ -892,7 +892,10 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   // tiny indices: the exact table in LDS (uniform batches; power-of-two filters).  Trimmed reads stay on the LDS-summary chain:
   // measured 9.8 ms per 10 M pairs with the table in LDS (4 waves per SIMD) against 9.7 ms (6 waves per SIMD)
   const bool lx = uni && mode == PM_LDS_TAB && ctx->idx.ltab != nullptr && u <= 5;
-  if (lx) p.lsum32 = ctx->idx.ltab;
+  if (lx) {
+    p.lsum32 = ctx->idx.ltab;
+    p.lsum_shift = ctx->idx.ltab_mul;   // (no summary in this mode: the field carries the table's slot multiplier)
+  }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
   const uint64_t wpb = lx ? SHK_LX_WAVES : (wg16 ? 16 : 8);

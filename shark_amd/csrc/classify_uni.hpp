@@ -389,18 +389,21 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const char *D = reinterpret_cast<const char *>(lsum + LTAB_T_WORDS);
         const uint32_t tagmask15 = (uint32_t)(P.bf_mask >> LTAB_SLOT_LG);
         const uint32_t gmask2 = (tagmask15 & ((1u << LTAB_GROUP_LG) - 1u)) << 1;   // (pos[] is the raw hash: only the filter's bits count)
-        uint32_t dd[U], ee[U];
+        uint32_t dd[U], ee[U], tg[U];
 #pragma unroll
-        for (int j = JLO; j < JHI; ++j)
+        for (int j = JLO; j < JHI; ++j) {
           dd[j] = *reinterpret_cast<const uint16_t *>(D + (((uint32_t)pos[j] >> (LTAB_SLOT_LG - 1)) & gmask2));
+          tg[j] = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], LTAB_SLOT_LG) & tagmask15;
+        }
 #pragma unroll
-        for (int j = JLO; j < JHI; ++j)
-          ee[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + ((((uint32_t)pos[j] + dd[j]) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+        for (int j = JLO; j < JHI; ++j) {
+          const uint32_t base = (uint32_t)pos[j] + (tg[j] >> LTAB_GROUP_LG) * P.lsum_shift;   // (lds_table.hpp: the bits above the group spread the slots; lsum_shift = the multiplier)
+          ee[j] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + (((base + dd[j]) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+        }
         bool esc = false, any = false;
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) {
-          const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], LTAB_SLOT_LG) & tagmask15;
-          mt[j] = (ee[j] >> 13) == ((tag << 1) | 1u);
+          mt[j] = (ee[j] >> 13) == ((tg[j] << 1) | 1u);
           slo[j] = ee[j] & LTAB_ESC;
           okm[j] = mt[j] ? 0xFFFFFFFFu : 0u;
           any |= mt[j];

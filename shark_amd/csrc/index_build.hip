@@ -206,14 +206,11 @@ __global__ __launch_bounds__(256) void table_build_kernel(const uint64_t *__rest
   }
 }
 
-// LDS-resident exact table of a tiny index (shark_internal.hpp): the keys are read back from the position table just built,
-// the displacements are found greedily, largest group first (a few thousand groups of a handful of keys: microseconds).
+// LDS-resident exact table of a tiny index (lds_table.hpp): the keys are read back from the position table just built.
 // false = no displacement fits some group (the caller keeps the LDS-summary chain).
-static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, std::vector<uint32_t> &img)
+static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, std::vector<uint32_t> &img, uint32_t *mul)
 {
-  struct Key { uint32_t low, tag, payload; };
-  constexpr uint32_t NG = 1u << LTAB_GROUP_LG, NS = 1u << LTAB_SLOT_LG;
-  std::vector<std::vector<Key>> groups(NG);
+  std::vector<LtabKey> keys;
   const uint64_t n_buckets = 1ull << tab_lg;
   for (uint64_t b = 0; b < n_buckets; ++b)
     for (int sidx = 0; sidx < 2; ++sidx) {
@@ -221,32 +218,10 @@ static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, s
       const uint32_t hi = (uint32_t)(e >> 32), lo = (uint32_t)e;
       if (!(hi & 0x80u)) continue;
       const uint64_t home = (b - (hi & 0x3Fu)) & (n_buckets - 1);
-      const uint64_t pos = ((uint64_t)(hi >> 8) << tab_lg) | home;
       const uint32_t gene = lo & TAB_PAYLOAD;
-      const uint32_t payload = ((lo >> 31) || gene >= LTAB_ESC) ? LTAB_ESC : gene;
-      groups[(pos >> LTAB_SLOT_LG) & (NG - 1)].push_back(Key{(uint32_t)pos & (NS - 1), (uint32_t)(pos >> LTAB_SLOT_LG), payload});
+      keys.push_back(LtabKey{((uint64_t)(hi >> 8) << tab_lg) | home, ((lo >> 31) || gene >= LTAB_ESC) ? LTAB_ESC : gene});
     }
-  std::vector<uint32_t> order(NG);
-  for (uint32_t g = 0; g < NG; ++g) order[g] = g;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return groups[a].size() > groups[b].size(); });
-  img.assign(LTAB_BYTES / 4, 0u);
-  uint16_t *D = reinterpret_cast<uint16_t *>(img.data() + LTAB_T_WORDS);
-  for (const uint32_t g : order) {
-    const auto &ks = groups[g];
-    if (ks.empty()) break;
-    bool placed = false;
-    for (uint32_t d = 0; d < NS && !placed; ++d) {
-      bool free_all = true;
-      for (const Key &kk : ks)
-        if (img[(kk.low + d) & (NS - 1)]) { free_all = false; break; }
-      if (!free_all) continue;
-      for (const Key &kk : ks) img[(kk.low + d) & (NS - 1)] = (kk.tag << 14) | (1u << 13) | kk.payload;
-      D[g] = (uint16_t)d;
-      placed = true;
-    }
-    if (!placed) return false;
-  }
-  return true;
+  return ltab_build(keys, img, mul);
 }
 
 static unsigned grid_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -473,12 +448,12 @@ int build_index(Ctx *ctx)
         // tiny indices (a gene or a few): the whole table fits the LDS of a CU as a perfect hash -- uniform batches then
         // touch no memory but their own bases (classify_uni.hpp LSL = 21); the chains above stay for trimmed reads
         if (ix.ltab) { (void)hipFree(ix.ltab); ix.ltab = nullptr; }
-        if (ix.pow2 && ix.lsum_shift && lgB >= 24 && lgB <= LTAB_SLOT_LG + 18 && n_set <= LTAB_MAX_KEYS && !getenv("SHK_NO_LDS_TABLE")) {
+        if (ix.pow2 && ix.lsum_shift && lgB >= 24 && lgB <= LTAB_MAX_POS_LG && n_set <= LTAB_MAX_KEYS && !getenv("SHK_NO_LDS_TABLE")) {
           std::vector<uint64_t> h_tab(slots);
           std::vector<uint32_t> img;
           BI_HIP(hipMemcpyAsync(h_tab.data(), ix.tab, slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
           BI_HIP(hipStreamSynchronize(st));
-          if (build_lds_table(h_tab, lg, img)) {
+          if (build_lds_table(h_tab, lg, img, &ix.ltab_mul)) {
             BI_HIP(hipMalloc((void **)&ix.ltab, LTAB_BYTES));
             BI_HIP(hipMemcpyAsync(ix.ltab, img.data(), LTAB_BYTES, hipMemcpyHostToDevice, st));
             BI_HIP(hipStreamSynchronize(st));

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/shark_hip.h"
+#include "lds_table.hpp"   // LTAB_*: the LDS-resident exact table of a tiny index
 
 namespace shk {
 
@@ -42,17 +43,6 @@ namespace shk {
 constexpr uint32_t LDS_SUM_LOG2 = 18;                 // 2^18 bits = 32 KiB of LDS per workgroup
 constexpr uint32_t LDS_SUM_BITS = 1u << LDS_SUM_LOG2;
 
-// LDS-resident exact table (indices of up to LTAB_MAX_KEYS set bits, filters of 2^24 .. 2^33 bits): a perfect hash by
-// displacement.  Group g = bits [15, 28) of the position, D[g] = the group's displacement, slot = (pos + D[g]) mod 2^15,
-//   T[slot] = tag(18) = pos >> 15 | valid(1) | payload(13): gene of a single-gene list, or LTAB_ESC (ask the position table).
-// The tag contains the group, so a matching entry was placed with the same displacement: its low 15 bits are the probe's --
-// a match is exact, and a lookup is two LDS reads without any search (classify_uni_kernel, LSL = 21).
-constexpr uint32_t LTAB_SLOT_LG = 15, LTAB_GROUP_LG = 13;
-constexpr uint32_t LTAB_T_WORDS = 1u << LTAB_SLOT_LG;                                  // 128 KiB
-constexpr uint32_t LTAB_BYTES = LTAB_T_WORDS * 4u + (1u << LTAB_GROUP_LG) * 2u;        // + 16 KiB of displacements
-constexpr uint32_t LTAB_ESC = 0x1FFFu;
-constexpr uint32_t LTAB_MAX_KEYS = 26000;                                              // load <= 0.8
-
 struct ListEntry {
   uint32_t start;
   uint16_t len;     // clipped at 0xFFFF: then the true end is the next entry's start
@@ -74,7 +64,8 @@ struct DeviceIndex {
   uint32_t lsum_shift = 0;    // 0 = not used
   uint32_t *lbig32 = nullptr; // 2^20-bit summary (128 KiB of LDS, one 1024-thread workgroup per CU): classify_uni_kernel on
   uint32_t lbig_shift = 0;    //   indices too dense for the 2^18-bit one; 0 = not built
-  uint32_t *ltab = nullptr;   // LDS-resident EXACT table of a tiny index (LTAB_BYTES image: T[2^15] then D[2^13]; layout below)
+  uint32_t *ltab = nullptr;   // LDS-resident EXACT table of a tiny index (LTAB_BYTES image: T[2^15] then D[2^13]; lds_table.hpp)
+  uint32_t ltab_mul = 0;      //   the multiplier its slots were computed with
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
   bool tab_with_summary = false;
