@@ -1032,6 +1032,8 @@ def test_lds_table_tiny_indices(oracle, monkeypatch, k, bf_bits, n_genes, gene_l
         kb = synth.batch_from_lists(kmers, None, [b"I" * k] * len(kmers) if q > 0 else None)
         og, oi = _compare_classify(o, h, kb)
         assert single or int(og[-1]) >= len(kmers)
+        g0, i0 = h0.classify(kb["seq1"], kb["off1"], kb["seq2"], kb["off2"], kb["qual1"], kb["qual2"])   # (and the position table)
+        assert np.array_equal(g0, og) and np.array_equal(i0, oi)
         h.close()
         h0.close()
 
