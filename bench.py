@@ -52,7 +52,7 @@ N_SIMD = 256 * 4            # 256 CUs x 4 SIMD-32
 CLK_GHZ = 2.4               # max clock; a wave64 VALU instruction issues over 2 cycles
 LAUNCH_PAIRS = 10_000_000
 RANDOM_LOOKUP_CEILING_G = 54.6   # G independent 16-B lookups/s in an 8 GiB table, streaming loads (tools/gather_bench on MI355X)
-KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp"]
+KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]
 
 
 def kernel_src_sha():

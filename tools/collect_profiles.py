@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "profiles")
-KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp"]    # same list as bench.py
+KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]    # same list as bench.py
 
 
 def kernel_src_sha():
