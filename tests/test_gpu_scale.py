@@ -10,6 +10,9 @@ name; the per-GPU shard of the 8-GPU configs).  Checked per config:
   * both probe chains (position table vs filter words + rank directory) give identical results
   * a 200 000-pair sample of the batch is bit-equal to the oracle's associations
   * per-gene counters equal the histogram of the per-read results
+  * membership at scale: 50 M reference k-mers, each classified as a read of its own, all come back assigned (a key
+    the position table had lost, or a search that ends too early, would show here and nowhere in whole-read parity),
+    and both probe chains return the same associations for them
 The oracle builds each index in ~80 s single-threaded (pass 2 of the reference is single-threaded,
 main.cpp:154-189), which is what sizes this file's run time (~4 min)."""
 import os
@@ -27,6 +30,21 @@ pytestmark = pytest.mark.gpu
 PAIRS = 10_000_000
 SAMPLE = 200_000
 L = 150
+KMER_READS = 50_000_000
+
+
+def _reference_kmers_as_reads(genes, k, dev, with_qual):
+    """the first KMER_READS windows of k bases that lie inside one gene, as a single-end batch of reads of length k"""
+    lens = np.array([len(g) for g in genes], dtype=np.int64)
+    n_bases = int(np.searchsorted(np.cumsum(lens), KMER_READS + 100 * k)) + 1      # genes that hold that many windows
+    cat = torch.from_numpy(np.concatenate(genes[:n_bases])).to(dev)
+    gid = torch.repeat_interleave(torch.arange(n_bases, device=dev, dtype=torch.int32), torch.from_numpy(lens[:n_bases]).to(dev))
+    inside = gid[:len(gid) - k + 1] == gid[k - 1:]
+    reads = cat.unfold(0, k, 1)[inside][:KMER_READS].contiguous()
+    n = reads.shape[0]
+    off = torch.arange(0, (n + 1) * k, k, dtype=torch.int64, device=dev)
+    qual = torch.full((n * k,), ord("I"), dtype=torch.uint8, device=dev) if with_qual else None
+    return n, reads.reshape(-1), off, qual
 
 
 def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words):
@@ -42,7 +60,7 @@ def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words):
     o = oracle.Shark(k=k, c=0.6, bf_bits=1 << bf_log2, min_quality=q, single=single)
     nidx = o.build(gbytes)
 
-    res = {}
+    res, kres = {}, {}
     for mode in ("auto", "bitvector"):
         if mode == "bitvector":
             monkeypatch.setenv("SHK_PROBE", "bitvector")
@@ -74,9 +92,26 @@ def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words):
         counts = h.gene_counts(65536)
         assert np.array_equal(counts, np.bincount(gids, minlength=65536).astype(np.uint64))
         res[mode] = (goff, gids)
+        # every reference k-mer as a read of its own
+        nk, kseq, koff, kqual = _reference_kmers_as_reads(genes, k, dev, q > 0)
+        torch.cuda.synchronize()
+        rk = h.classify_device(nk, kseq.data_ptr(), koff.data_ptr(), 0, 0, kqual.data_ptr() if kqual is not None else 0, 0, max_read_len=k)
+        koffs = np.empty(nk + 1, np.uint32)
+        hip_memcpy_dtoh(koffs, rk.gene_off, koffs.nbytes)
+        kids = np.empty(int(rk.n_assoc), np.uint16)
+        hip_memcpy_dtoh(kids, rk.gene_ids, kids.nbytes)
+        kcnt = np.diff(koffs.astype(np.int64))
+        if not single:
+            assert kcnt.min() >= 1, "reference k-mer %d is not found in the index" % int(np.argmin(kcnt))
+        else:
+            assert (kcnt == 1).mean() > 0.9      # --single drops the k-mers that several genes share
+        kres[mode] = (koffs, kids)
+        del kseq, koff, kqual
         h.close()
     assert np.array_equal(res["auto"][0], res["bitvector"][0]) and np.array_equal(res["auto"][1], res["bitvector"][1]), \
         "the two probe chains disagree"
+    assert np.array_equal(kres["auto"][0], kres["bitvector"][0]) and np.array_equal(kres["auto"][1], kres["bitvector"][1]), \
+        "the two probe chains disagree on the reference's own k-mers"
 
     hb = synth.to_host_sample(batch, SAMPLE, L)
     og, oi = o.classify(hb["seq1"], hb["off1"], hb["seq2"], hb["off2"], hb["qual1"], hb["qual2"],
