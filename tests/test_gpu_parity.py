@@ -69,6 +69,15 @@ def _compare_classify(o, h, batch, nthreads=2):
     return og, oi
 
 
+def _probe_every_kmer(o, h, genes, k, stride=1):
+    """every (stride-th) reference k-mer as a single-end read of its own: the associations must be the oracle's, i.e. each
+    k-mer must be found with its whole gene list -- the key-by-key check of whatever structure the index is probed through
+    (whole reads cannot give it: a single lost k-mer hides behind its neighbours' coverage)"""
+    kmers = [g[i:i + k] for g in genes for i in range(0, len(g) - k + 1, stride)]
+    og, _ = _compare_classify(o, h, synth.batch_from_lists(kmers, None))
+    return og, len(kmers)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE config 1: the bundled example, k=17 c=0.6 bf=1GB
 # ---------------------------------------------------------------------------
@@ -129,6 +138,7 @@ def test_synthetic_parity(oracle, probe, k, bf_bits, paired, read_len):
                              n_rate=0.01, lower_rate=0.05, var_len=True)
     goff, _ = _compare_classify(o, h, batch)
     assert goff[-1] > 0
+    _probe_every_kmer(o, h, genes, k)
 
 
 def test_quality_mask_and_single(oracle):
@@ -814,6 +824,8 @@ def test_panel_sized_index_uses_the_big_lds_summary(oracle, bf_bits, monkeypatch
     rag = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.6, var_len=True)
     se = synth.make_reads(rng, genes, 1500, read_len=100, paired=False, on_target=0.6)
     want = [_compare_classify(o, h, b) for b in (uni, rag, se)]
+    og, n = _probe_every_kmer(o, h, genes, 17, stride=2)
+    assert int(og[-1]) >= n
     monkeypatch.setenv("SHK_NO_BIG_LDS_SUMMARY", "1")
     h2 = _hip(k=17, bf_bits=bf_bits)
     h2.build([bytes(g) for g in genes])
@@ -851,6 +863,8 @@ def test_dense_table_long_probe_paths(oracle, k, bf_bits, n_bases, monkeypatch):
               synth.make_reads(rng, genes, 1500, read_len=250, paired=True, on_target=0.7)):
         goff, _ = _compare_classify(o, h, b)
         assert goff[-1] > 0
+    og, n = _probe_every_kmer(o, h, genes, k, stride=3 if n_bases > 100_000 else 1)
+    assert int(og[-1]) >= n
 
 
 @pytest.mark.parametrize("shape", ["fixed_width", "ragged", "second_file_shorter", "first_file_shorter_no_final_newline", "bgzf", "single_end_gz"])
