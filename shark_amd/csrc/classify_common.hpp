@@ -14,8 +14,10 @@
 #ifndef SHK_UNI_WAVES
 #define SHK_UNI_WAVES 6   // 75 VGPRs, nothing spilled; at 8 waves per SIMD (64 VGPRs) the loop reloads spilled lane constants from scratch and measures 1-6 % slower
 #endif
+// (table modes at 6: 80 VGPRs -- the quality-mask instantiations do not spill -- measured against 8 waves / 64 VGPRs: configs[4] shape
+//  11.2 -> 10.4 ms, configs[2] index 41.8 -> 40.6 ms, everything else within 0.5 %)
 #ifndef SHK_TAB_WAVES
-#define SHK_TAB_WAVES 8
+#define SHK_TAB_WAVES 6
 #endif
 
 // (-DSHK_NO_ACCEPT=1: a build without the early decision, for A/B timing)

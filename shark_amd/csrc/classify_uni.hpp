@@ -108,7 +108,7 @@ struct UniGeom {
   static constexpr bool LX = pm_lds(MODE) && LSL == 21;   // the exact table of a tiny index in LDS instead of a summary
   static constexpr int WAVES = (pm_lds(MODE) && LSL >= 20) ? (LSL == 21 ? SHK_LX_WAVES : 16) : 8;
   static constexpr int THREADS = WAVES * 64;
-  // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes are latency bound: 8 waves per SIMD
+  // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes likewise (SHK_TAB_WAVES, classify_common.hpp)
   static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
   static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (LX ? LTAB_BYTES * 8u : (1u << LSL)) : 0u;   // what the workgroup keeps in LDS
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
