@@ -99,6 +99,51 @@ def cpu_info():
     return model, len(phys)
 
 
+def spawn_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher: this process starts the N ranks itself, one process per GPU -- as the
+    reference starts its N workers from the one command line (main.cpp:219-223) -- forwards rank 0's JSON line and exits
+    non-zero when any rank does.  It never imports torch and never touches a GPU (a process that has initialised the GPU
+    must not be replaced or forked on this pool); the ranks are ordinary child processes of it."""
+    import socket
+    import subprocess
+    import threading
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0:
+                    rc = c if c > 0 else 1
+                    print("bench.py: rank %d of %d exited with code %d" % (r, n, c), file=sys.stderr)
+        time.sleep(0.05)
+    for r in live:          # a rank failed: the others would wait for it at the next barrier -- stop exactly the processes started here
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    reader.join(timeout=20)
+    sys.stdout.write(b"".join(lines).decode(errors="replace"))
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +162,10 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = threads x 50 000 (one reference chunk per thread)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)           # (does not return)
 
     import numpy as np
     import torch
@@ -126,9 +175,17 @@ def main():
     from shark_amd.capi import hip_memcpy_dtoh
 
     rank, local_rank, world = sdist.env_rank()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    local_rank %= max(torch.cuda.device_count(), 1)   # (a gloo dry run may put several ranks on one GPU)
+    if world != args.gpus:
+        # the line's n_gpus must be what was asked for: a launcher that started another number of ranks is an error, not a warning
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python3 bench.py --gpus N`, or with a launcher whose "
+                 "--nproc-per-node equals --gpus)" % (args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py: no GPU (there is no CPU path)")
+    if world > n_dev and sdist.backend_name() == "nccl":
+        sys.exit("bench.py: --gpus %d but this node has %d GPU(s); one process per GPU over RCCL needs a GPU per rank "
+                 "(SHARK_DIST_BACKEND=gloo rehearses the N-rank path on fewer)" % (world, n_dev))
+    local_rank %= n_dev                    # (a gloo dry run may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sdist.init(sdist.backend_name(), dev)
@@ -161,6 +218,9 @@ def main():
     info = h.build([g.tobytes() for g in genes])
     t_build = time.time() - t0
     h.dist_init(sdist)                                 # RCCL communicator inside the library (no-op for world 1)
+    comm_rank, ranks_seen = h.dist_info()              # what that communicator says (ncclCommCount), not what the environment said
+    if ranks_seen != world or comm_rank != rank:
+        sys.exit("bench.py: rank %d of %d, but the communicator reports rank %d of %d" % (rank, world, comm_rank, ranks_seen))
 
     # ---- this rank's shard of the read set, generated in HBM ------------------------
     batches = [synth.make_pairs_device(chunk_pairs, genes, dev, seed=synth.SEED + 1 + cidx, read_len=L, on_target=args.on_target)
@@ -399,6 +459,7 @@ def main():
         "value": round(value, 1),
         "unit": "reads/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -415,7 +476,9 @@ def main():
                    "seed": synth.SEED, "index_build_s": round(t_build, 3), "n_set_bits": int(info["n_set_bits"]),
                    "assoc_per_step": int(n_assoc.item()) // args.steps,
                    "gene_count_checksum": int(np.asarray(counts, dtype=np.uint64).sum()) // args.steps,
-                   "gene_counts_allreduce": "shk_dist_gene_counts_allreduce (RCCL inside libsharkhip)" if world > 1 else "single GPU: no collective",
+                   "gene_counts_allreduce": ("single GPU: no collective" if world == 1 else
+                                             "shk_dist_gene_counts_allreduce (RCCL inside libsharkhip; ranks_seen = ncclCommCount)" if sdist.backend_name() == "nccl"
+                                             else "gloo dry run (SHARK_DIST_BACKEND): torch.distributed all-reduce of the library's local counters"),
                    "long_reads": int(tm["last_n_long"]), "tie_reads": int(tm["last_n_tie"]), "probe_mode": h.probe_mode()},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -186,6 +186,10 @@ int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint3
 int shk_dist_unique_id(uint8_t *id);
 int shk_dist_init(shk_ctx *ctx, const uint8_t *id, int rank, int world);
 int shk_dist_gene_counts_allreduce(shk_ctx *ctx, uint64_t *totals, uint32_t n);
+/* What the communicator itself says about the job this context joined with shk_dist_init: ncclCommUserRank /
+ * ncclCommCount (a context that never joined one reports rank 0 of 1).  bench.py prints it as `ranks_seen`, so a
+ * run that was asked for N GPUs and reached the collective with fewer cannot go unnoticed. */
+int shk_dist_info(const shk_ctx *ctx, int *rank, int *world);
 
 /* ---- measurement --------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel (classify) on the context's own

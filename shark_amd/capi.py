@@ -50,6 +50,7 @@ EXPORTS = [
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
     "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode", "shk_gene_counts_allreduce",
     "shk_classify_submit", "shk_classify_wait", "shk_dist_unique_id", "shk_dist_init", "shk_dist_gene_counts_allreduce",
+    "shk_dist_info",
 ]
 SHK_PIPE_DEPTH = 3
 SHK_DIST_ID_BYTES = 128
@@ -98,6 +99,7 @@ def load():
     L.shk_dist_unique_id.restype = C.c_int; L.shk_dist_unique_id.argtypes = [p]
     L.shk_dist_init.restype = C.c_int; L.shk_dist_init.argtypes = [p, p, C.c_int, C.c_int]
     L.shk_dist_gene_counts_allreduce.restype = C.c_int; L.shk_dist_gene_counts_allreduce.argtypes = [p, p, C.c_uint32]
+    L.shk_dist_info.restype = C.c_int; L.shk_dist_info.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -264,6 +266,16 @@ class SharkHip:
         td.broadcast(t, 0)
         ident = (C.c_uint8 * SHK_DIST_ID_BYTES)(*t.cpu().tolist())
         self._check(self.L.shk_dist_init(self.h, ident, rank, world), "shk_dist_init")
+
+    def dist_info(self):
+        """(rank, world) as the communicator the collective runs over reports them: RCCL's own ncclCommUserRank /
+        ncclCommCount for an RCCL job, torch.distributed's for a gloo dry run, (0, 1) without a job"""
+        td = getattr(self, "_td", None)
+        if td is not None:
+            return td.get_rank(), td.get_world_size()
+        r, w = C.c_int(), C.c_int()
+        self._check(self.L.shk_dist_info(self.h, C.byref(r), C.byref(w)), "shk_dist_info")
+        return r.value, w.value
 
     def dist_gene_counts_allreduce(self, n=65536):
         a = np.zeros(n, dtype=np.uint64)

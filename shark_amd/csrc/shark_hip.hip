@@ -431,6 +431,8 @@ struct RcclApi {
   int (*CommInitRank)(rccl_comm_t *, int, rccl_uid, int) = nullptr;
   int (*GetUniqueId)(rccl_uid *) = nullptr;
   int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*CommCount)(rccl_comm_t, int *) = nullptr;
+  int (*CommUserRank)(rccl_comm_t, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -447,10 +449,13 @@ static RcclApi &rccl()
       api.CommInitRank = (int (*)(rccl_comm_t *, int, rccl_uid, int))dlsym(api.lib, "ncclCommInitRank");
       api.GetUniqueId = (int (*)(rccl_uid *))dlsym(api.lib, "ncclGetUniqueId");
       api.CommDestroy = (int (*)(rccl_comm_t))dlsym(api.lib, "ncclCommDestroy");
+      api.CommCount = (int (*)(rccl_comm_t, int *))dlsym(api.lib, "ncclCommCount");
+      api.CommUserRank = (int (*)(rccl_comm_t, int *))dlsym(api.lib, "ncclCommUserRank");
       api.AllReduce = (int (*)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.lib, "ncclAllReduce");
       api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
       api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
-      api.ok = api.CommInitAll && api.CommInitRank && api.GetUniqueId && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+      api.ok = api.CommInitAll && api.CommInitRank && api.GetUniqueId && api.CommDestroy && api.CommCount && api.CommUserRank && api.AllReduce &&
+               api.GroupStart && api.GroupEnd;
     }
   }
   return api;
@@ -906,6 +911,18 @@ int shk_dist_init(shk_ctx *ctx, const uint8_t *id, int rank, int world)
   ctx->dist_comm = comm;
   ctx->dist_rank = rank;
   ctx->dist_world = world;
+  return SHK_OK;
+}
+
+int shk_dist_info(const shk_ctx *ctx, int *rank, int *world)
+{
+  if (!ctx || !rank || !world) return SHK_ERR_ARG;
+  *rank = 0;
+  *world = 1;
+  if (ctx->dist_comm) {
+    // asked of the communicator, not remembered from shk_dist_init's arguments
+    if (rccl().CommUserRank(ctx->dist_comm, rank) != 0 || rccl().CommCount(ctx->dist_comm, world) != 0) return SHK_ERR_HIP;
+  }
   return SHK_OK;
 }
 

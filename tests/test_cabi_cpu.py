@@ -87,3 +87,19 @@ def test_cli_argument_contract(built, tmp_path):
     assert r.returncode == 1 and "shark: at least 1 thread is required." in r.stderr
     r = _run_cli(["--bogus"])
     assert r.returncode == 1 and "shark : unknown argument" in r.stderr
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python3 bench.py --gpus 2` (no launcher): the parent starts two ranks before touching torch or a GPU and passes a
+    rank's failure on -- here every rank fails because there is no GPU and no CPU path"""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert r.stderr.count("no GPU (there is no CPU path)") >= 1 and "of 2 exited with code" in r.stderr
+    env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

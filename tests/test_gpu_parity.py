@@ -354,33 +354,61 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("scaling", ["strong", "weak"])
-def test_bench_two_ranks_dry_run(tmp_path, scaling):
+@pytest.mark.parametrize("launcher,scaling", [("self", "strong"), ("torchrun", "strong"), ("self", "weak")])
+def test_bench_two_ranks_dry_run(tmp_path, launcher, scaling):
     """the N>1 code path of bench.py (rank env, shards of one read set, barrier, MAX over ranks, count all-reduce) with
-    two ranks sharing the one GPU of the test box over gloo; the real multi-GPU run uses RCCL inside the library"""
+    two ranks sharing the one GPU of the test box over gloo; the real multi-GPU run uses RCCL inside the library.
+    launcher "self": exactly the driver's form, `python3 bench.py --gpus 2 ...` -- bench.py starts its two ranks itself
+    (main.cpp:219-223 starts the reference's workers from the one command line); "torchrun": the contract's launcher form."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SHARK_DIST_BACKEND="gloo")
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
     base = [os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "250000", "--total-pairs", "1000000",
             "--scaling", scaling, "--no-configs", "--no-boundary", "--no-cpu-baseline"]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port())] + base + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    if launcher == "self":
+        cmd = ["python3"] + base + ["--gpus", "2"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + base + ["--gpus", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    j = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
-    assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["cpu_baseline"] is None
+    out_lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(out_lines) == 1, r.stdout[-2000:]          # ONE JSON line, rank 0's
+    j = json.loads(out_lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == scaling and j["cpu_baseline"] is None
     assert j["config"]["gene_count_checksum"] == j["config"]["assoc_per_step"] > 0
     if scaling == "strong":
         # the same read set on one GPU: same reads per step, same associations
-        r1 = subprocess.run([sys.executable] + base + ["--gpus", "1"], capture_output=True, text=True, cwd=root, timeout=600)
+        r1 = subprocess.run([sys.executable] + base + ["--gpus", "1"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
         assert r1.returncode == 0, r1.stderr[-3000:]
         j1 = json.loads([x for x in r1.stdout.splitlines() if x.startswith("{")][-1])
+        assert j1["n_gpus"] == 1 and j1["ranks_seen"] == 1
         assert j["config"]["reads_per_step"] == j1["config"]["reads_per_step"] == 2 * 1000000
         assert j["config"]["assoc_per_step"] == j1["config"]["assoc_per_step"]
+        assert j["config"]["gene_count_checksum"] == j1["config"]["gene_count_checksum"]
         assert j1["config"]["launches_per_step_per_gpu"] == 2 * j["config"]["launches_per_step_per_gpu"]
     else:
         assert j["config"]["reads_per_step"] == 2 * 2 * 250000
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    """`n_gpus` on the line is what --gpus asked for or the run fails: a launcher with another number of ranks, or more
+    RCCL ranks than the node has GPUs, is an error (round 2 printed a warning and measured one GPU)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SHARK_DIST_BACKEND")}
+    n_dev = torch.cuda.device_count()
+    r = subprocess.run(["python3", os.path.join(root, "bench.py"), "--gpus", str(n_dev + 1), "--steps", "1", "--no-configs", "--no-boundary",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode != 0 and "GPU(s)" in r.stderr and not r.stdout.strip()
 
 
 def test_cli_block_reader_handover_on_irregular_records(oracle, tmp_path):
