@@ -165,7 +165,10 @@ inline void locate_batches(BatchTable &t, const std::vector<uint64_t> &cnt, uint
 
 // One batch of a strict four-line file, parsed by ONE thread: the bytes [b, e) of the file are read into `buf`,
 // the newlines are indexed and every record is checked with the block reader's rules.  Returns the number of
-// leading regular records (== want when the whole batch is regular).
+// leading regular records (== want when the whole batch is regular).  The range has to hold EXACTLY `want` records: when
+// the want-th record does not end at `e` (offsets derived arithmetically from a fixed-width guess that does not hold
+// inside this range -- say two half-length records -- leave surplus bytes), nothing of the batch is accepted and the
+// serial reader takes over from its first byte.
 struct ParsedBatch {
   std::vector<char, NoInitAlloc<char>> buf;
   std::vector<uint64_t, NoInitAlloc<uint64_t>> nl;     // 4 per record, offsets into buf
@@ -210,6 +213,7 @@ inline size_t parse_strict_batch(int fd, uint64_t b, uint64_t e, size_t want, Pa
     pb.id_len[r] = (uint32_t)(p - (h0 + 1));
     pb.seq_len[r] = (uint32_t)(s1 - s0);
   }
+  if (r == want && want && pb.nl[4 * want - 1] + 1 != len) r = 0;   // surplus bytes behind the last record: not this batch's range
   pb.n = r;
   return r;
 }

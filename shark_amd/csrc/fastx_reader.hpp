@@ -86,6 +86,7 @@ class InflateAhead {
   bool start(uint64_t off)
   {
     done_ = false; quit_ = false; have_ = false; cons_ = 0;
+    fallback_gz_ = false;   // (a restart reads the file from `off` again: whatever made the last pass fall back is met again)
     full_[0] = full_[1] = false;
     if (bgzf_ && off == 0) {
       raw_ = fopen(path_.c_str(), "rb");

@@ -616,6 +616,18 @@ int main(int argc, char *argv[])
               << "GB gpus=" << opt.gpus << "\n" << std::endl;
   }
 
+  // the reference opens its inputs unchecked (main.cpp:88-106) and then reads nothing from a file that is not there; here a
+  // sample that cannot be opened is reported before any work is done
+  for (const std::string *path : {&opt.sample1_path, &opt.sample2_path}) {
+    if (path->empty()) continue;
+    FILE *f = fopen(path->c_str(), "rb");
+    if (!f) {
+      std::cerr << "shark: cannot open the sample " << *path << std::endl;
+      return EXIT_FAILURE;
+    }
+    fclose(f);
+  }
+
   // ---- contexts: one per GPU, index replicated by deterministic rebuild -------
   const int n_gpus = opt.gpus;
   std::vector<shk_ctx *> ctxs((size_t)n_gpus, nullptr);
@@ -751,6 +763,11 @@ int main(int argc, char *argv[])
     // a reader must not run ahead of the drain without bound: at most `window` batches beyond the one being written
     const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2);
     uint64_t drained = 0;                                // guarded by done_m
+    // Batch j may only leave a reader once every batch before it is KNOWN to be strict four-line FASTQ: an irregular batch
+    // i < j that keeps the four-line alignment (an empty read, a sequence/quality length mismatch, a lone CR, a NUL) lets
+    // batch j validate, yet everything from i on belongs to the serial reader -- which numbers its batches from i again
+    // and may cut the records differently.  `validated` = number of leading batches known to be strict (guarded by done_m).
+    uint64_t validated = 0;
     std::vector<std::thread> readers;
     for (unsigned r = 0; r < n_readers; ++r) {
       readers.emplace_back([&, r] {
@@ -781,7 +798,14 @@ int main(int argc, char *argv[])
           shk::fill_soa(p1, want, b->id1, b->seq1, b->qual1);
           if (opt.paired_flag) shk::fill_soa(p2, want, b->id2, b->seq2, b->qual2);
           t_reader[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-          if (i >= irregular_at.load()) { pool.release(std::move(b)); break; }
+          {
+            // (batch indices are handed out in increasing order, so the reader of the smallest outstanding one never waits here)
+            std::unique_lock<std::mutex> l(done_m);
+            done_cv.wait(l, [&] { return validated == i || i >= irregular_at.load(); });
+            if (i >= irregular_at.load()) { l.unlock(); pool.release(std::move(b)); break; }
+            validated = i + 1;
+          }
+          done_cv.notify_all();
           dispatch(std::move(b));
         }
       });
@@ -809,7 +833,6 @@ int main(int argc, char *argv[])
       for (auto &q : todo) q->close();
       std::lock_guard<std::mutex> l(done_m);
       split_finished = true;
-      if (!serial_ok) n_batches = UINT64_MAX;   // reported below
       done_cv.notify_all();
     });
 

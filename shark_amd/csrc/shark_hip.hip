@@ -555,6 +555,10 @@ void shk_destroy(shk_ctx *ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->prm.device);
+  // tickets that were submitted and never waited for (a caller bailing out) may still have copies in flight on the copy
+  // streams -- into slot buffers that are about to be freed, out of caller memory that may be released right after this call
+  if (ctx->h2d_stream) (void)hipStreamSynchronize(ctx->h2d_stream);
+  if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_index(ctx->idx);
   for (Slot &sl : ctx->slots) slot_free(sl);

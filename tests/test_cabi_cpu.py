@@ -103,3 +103,15 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
     env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_cli_reports_a_sample_that_cannot_be_opened(built, tmp_path):
+    """a typo'd -1 / -2 path is an error message and exit code 1 at once, not a hang behind the index build"""
+    fa = tmp_path / "g.fa"
+    fa.write_text(">g\nACGTACGTACGTACGTACGTACGT\n")
+    fq = tmp_path / "a.fq"
+    fq.write_text("@r\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n")
+    r = subprocess.run([CLI, "-r", str(fa), "-1", str(tmp_path / "nonexistent.fq")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open the sample" in r.stderr
+    r = subprocess.run([CLI, "-r", str(fa), "-1", str(fq), "-2", str(tmp_path / "nonexistent.fq")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open the sample" in r.stderr

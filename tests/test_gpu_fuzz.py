@@ -1,0 +1,26 @@
+"""The randomised differential test (tests/fuzz_parity.py) as part of the `-m gpu` suite: a fixed-seed schedule of random
+configurations, HIP path (host and device-resident entry points) against the CPU oracle, bit-exact, every case also probing
+the reference's own k-mers one by one.  The schedule is biased until every probe structure shk_probe_mode() can report has
+been drawn -- a structure that is never drawn is a structure that is never tested."""
+import collections
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCHEDULE = [("", 20261003, 150), ("uni", 20270000, 90), ("mid", 20280000, 24), ("mod", 20290000, 24)]
+
+
+def test_fuzz_schedule_covers_every_probe_mode():
+    from tests import fuzz_parity
+    modes = collections.Counter()
+    n = 0
+    for bias, seed0, count in SCHEDULE:
+        for it in range(count):
+            ok, mode, desc = fuzz_parity.run_case(seed0 + it, bias)
+            assert ok, "MISMATCH: %s  (replay: python tests/fuzz_parity.py 1 %d %s)" % (desc, seed0 + it, bias)
+            modes[mode] += 1
+            n += 1
+    print("fuzz: %d cases, probe modes %s" % (n, dict(modes)))
+    missing = [m for m in fuzz_parity.ALL_MODES if modes[m] == 0]
+    assert not missing, "probe modes never drawn: %s (histogram %s)" % (missing, dict(modes))

@@ -458,6 +458,96 @@ def test_cli_block_reader_handover_on_irregular_records(oracle, tmp_path):
             assert (tmp_path / "h2.fq").read_bytes() == (tmp_path / "o2.fq").read_bytes()
 
 
+def test_cli_irregular_records_that_keep_the_four_line_alignment(oracle, tmp_path):
+    """irregular records that do NOT shift the four-line rhythm -- an empty read (a trimmer's), a lone CR, a NUL, a
+    sequence/quality length mismatch (which ends kseq's stream) -- in the middle of a file read by many parallel readers
+    with small batches: every batch behind such a record still validates, so a reader that is ahead must not hand its batch
+    to a GPU before the batches in front of it are known to be strict.  ssv, both FASTQ outputs and the per-gene counts must
+    be the serial kseq-rule reader's (the oracle CLI's), run after run."""
+    import subprocess
+    rng = np.random.default_rng(77)
+    genes = synth.make_genes(rng, 4, 600, 1200)
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">g%d\n%s\n" % (i, bytes(g).decode()) for i, g in enumerate(genes)))
+
+    def rec(i, g, L, style):
+        st = int(rng.integers(0, len(g) - L))
+        s = bytes(g[st:st + L]).decode()
+        q = "".join(chr(int(x)) for x in rng.integers(35, 74, size=L))
+        if style == "empty":
+            return "@r%d\n\n+\n\n" % i
+        if style == "cr":
+            return "@r%d\n%s\r\n+\n%s\r\n" % (i, s, q)
+        if style == "nul":
+            return "@r%d\n%s\x00%s\n+\n%s\n" % (i, s[:30], s[31:], q)
+        if style == "mismatch":
+            return "@r%d\n%s\n+\n%s\n" % (i, s, q[:-7])
+        return "@r%d\n%s\n+\n%s\n" % (i, s, q)
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
+    for styles in (["s"] * 700 + ["empty"] + ["s"] * 1500,
+                   ["s"] * 901 + ["cr"] + ["s"] * 1300,
+                   ["s"] * 650 + ["nul"] + ["s"] * 1400,
+                   ["s"] * 1000 + ["mismatch"] + ["s"] * 1200,
+                   ["s"] * 300 + ["empty"] + ["s"] * 400 + ["nul"] + ["s"] * 500 + ["mismatch"] + ["s"] * 900):
+        t1 = "".join(rec(i, genes[i % 4], 100, st) for i, st in enumerate(styles))
+        t2 = "".join(rec(i, genes[i % 4], 100, "s") for i, st in enumerate(styles))
+        f1, f2 = tmp_path / "a.fq", tmp_path / "b.fq"
+        f1.write_bytes(t1.encode("latin-1"))
+        f2.write_bytes(t2.encode("latin-1"))
+        args = ["-r", str(fa), "-1", str(f1), "-2", str(f2), "-k", "15"]
+        ossv = tmp_path / "o.ssv"
+        oracle.run_cli(args + ["-o", str(tmp_path / "o1.fq"), "-p", str(tmp_path / "o2.fq")], str(ossv))
+        want = ossv.read_bytes()
+        assert want.count(b"\n") > 500
+        want_counts = {}
+        for line in want.splitlines():
+            g = line.split()[1]
+            want_counts[g] = want_counts.get(g, 0) + 1
+        for rep in range(3):
+            r = subprocess.run([exe] + args + ["-o", str(tmp_path / "h1.fq"), "-p", str(tmp_path / "h2.fq"), "--batch", "64", "-t", "8",
+                                               "--gene-counts", str(tmp_path / "gc.txt")], capture_output=True, cwd=str(tmp_path), timeout=300)
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            assert r.stdout == want, (styles.index([x for x in styles if x != "s"][0]), rep)
+            assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
+            assert (tmp_path / "h2.fq").read_bytes() == (tmp_path / "o2.fq").read_bytes()
+            got_counts = {ln.split()[0].encode(): int(ln.split()[1]) for ln in (tmp_path / "gc.txt").read_text().splitlines()}
+            assert got_counts == want_counts
+
+
+def test_cli_fixed_width_guess_with_compensating_records(oracle, tmp_path):
+    """a file that passes the fixed-width shortcut's checks (size a multiple of the first record's length, sampled record
+    starts in place) although one batch holds two half-length records: the surplus record must not be dropped"""
+    import subprocess
+    rng = np.random.default_rng(78)
+    genes = synth.make_genes(rng, 3, 600, 1200)
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(">g%d\n%s\n" % (i, bytes(g).decode()) for i, g in enumerate(genes)))
+    L = 100
+
+    def rec(name, g, n):
+        st = int(rng.integers(0, len(g) - n))
+        return "@%s\n%s\n+\n%s\n" % (name, bytes(g[st:st + n]).decode(), "I" * n)
+
+    full = len(rec("r0000", genes[0], L))                       # 11 + 2 L bytes
+    recs = [rec("r%04d" % i, genes[i % 3], L) for i in range(5000)]
+    # record 1234 is replaced by two records that together have its byte length: (11 + 2 h) + (12 + 2 h) = 11 + 2 L  ->  h = (L - 6) / 2
+    h = (L - 6) // 2
+    two = rec("x0001", genes[1], h) + rec("y00002", genes[2], h)
+    assert len(two) == full
+    recs[1234] = two
+    f1 = tmp_path / "a.fq"
+    f1.write_text("".join(recs))
+    args = ["-r", str(fa), "-1", str(f1), "-k", "15"]
+    ossv = tmp_path / "o.ssv"
+    oracle.run_cli(args + ["-o", str(tmp_path / "o1.fq")], str(ossv))
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
+    r = subprocess.run([exe] + args + ["-o", str(tmp_path / "h1.fq"), "--batch", "100", "-t", "4"], capture_output=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert r.stdout == ossv.read_bytes()
+    assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
+
+
 def test_full_size_properties_config2():
     """BASELINE configs[1] at full size (10 M pairs 2x150 bp, 1 gene, k=17, 2^33-bit filter) through
     size-independent properties of the domain:

@@ -1,0 +1,22 @@
+#!/bin/bash
+# round-3 GPU session driver: tools/gpu_r3.sh <tag> <step> [<step> ...]; every step logs to gpurun_out/<tag>/<step>.log
+tag=$1; shift
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+for step in "$@"; do
+  echo "== $step $(date +%T)"
+  case $step in
+    bench_tests) timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -k "bench" -x -q > $out/$step.log 2>&1 ;;
+    cli_tests)   timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -k "cli" -x -q > $out/$step.log 2>&1 ;;
+    fuzz)        timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -x -q -s > $out/$step.log 2>&1 ;;
+    suite)       timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=15 > $out/$step.log 2>&1 ;;
+    bench)       timeout -k 10 600 python3 bench.py --steps 10 --warmup 2 > $out/bench.json 2> $out/$step.log ;;
+    bench_quick) timeout -k 10 600 python3 bench.py --steps 5 --warmup 1 --no-configs --no-boundary --no-cpu-baseline > $out/bench_quick.json 2> $out/$step.log ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+  rc=$?
+  echo "rc=$rc" >> $out/$step.log
+  tail -4 $out/$step.log
+  if [ $rc -ne 0 ]; then echo "step $step failed (rc=$rc): stopping"; exit $rc; fi
+done
