@@ -22,12 +22,16 @@ shk_dist_gene_counts_allreduce.  `--scaling weak` gives every rank its own
 10 M-pair batch instead (round-1 behaviour).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline       algorithmic bytes of the classify kernel / its HIP-event
-                 duration against the 8 TB/s HBM peak (the contract's figure),
-                 plus what actually binds the kernel: `valu` (instruction-issue
-                 occupancy from SQ counters) and `hbm_actual` (FETCH/WRITE
-                 counter bytes), both from profiles/pmc_counters.json, which is
-                 only used when it was taken on the same kernel sources
+  roofline       `achieved`/`peak`/`frac`: algorithmic bytes of the classify
+                 kernel / its HIP-event duration against the 8 TB/s HBM peak
+                 (the contract's figure); `bound` names the resource that
+                 really binds the kernel and `frac_of_binding` how much of THAT
+                 is used.  `valu_from_profile` (instruction-issue occupancy, SQ
+                 counters), `hbm_actual_from_profile` and `traffic`
+                 (FETCH/WRITE counter bytes) come from the committed
+                 profiles/pmc_counters.json -- a separate rocprofv3 --pmc pass,
+                 not this run -- and only when that file was taken on the same
+                 kernel sources (sha256-stamped)
   cpu_baseline   the CPU oracle (a port of the reference path) on this host
   configs        the same measurement on BASELINE configs[2]'s index
                  (60 000 genes, 2^36-bit filter) and on configs[4]'s shape
@@ -51,7 +55,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD = 256 * 4            # 256 CUs x 4 SIMD-32
 CLK_GHZ = 2.4               # max clock; a wave64 VALU instruction issues over 2 cycles
 LAUNCH_PAIRS = 10_000_000
-RANDOM_LOOKUP_CEILING_G = 54.6   # G independent 16-B lookups/s in an 8 GiB table, streaming loads (tools/gather_bench on MI355X)
+L2_LINE_BYTES = 128         # a memory-side request of gfx950's L2 is a 128-byte line (MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B)
 KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]
 
 
@@ -278,26 +282,39 @@ def main():
         dt2, tm2, _, n_assoc2, _ = timed(h2, p2, lp, steps2, 1, False)
         k2 = tm2["total_ms"] / max(tm2["n_launches"], 1)
         w2 = h2.count_work(lp, p2[0]["seq1"], p2[0]["off1"], p2[0]["seq2"], p2[0]["off2"]) if rank == 0 else None
+        tab2_bytes = 16 << 29     # the configs[2] index's position table: 2^29 buckets of 16 bytes = 8 GiB (1.69e8 set bits at load <= 0.3)
         cfg2 = {"workload": "configs[2] index: 60000 genes (1.78e8 bases, lognormal lengths, every 10th gene shares half of its predecessor), "
                             "%d pairs 2x150 bp per GPU per step, k=17 c=0.6 bf=2^36 bits" % lp,
                 "value": round(2 * lp * world * steps2 / dt2, 1), "unit": "reads/s", "n_gpus": world, "steps": steps2,
                 "ms_per_step": round(dt2 / steps2 * 1e3, 3), "kernel_ms": round(k2, 4), "probe_mode": h2.probe_mode(),
                 "index_build_s": round(t_build2, 3), "n_set_bits": int(info2["n_set_bits"]), "tot_idx": int(info2["tot_idx"]),
                 "assoc_per_step": n_assoc2 // steps2, "tie_reads": int(tm2["last_n_tie"])}
-        if w2:
-            # this index is bound by random lookups behind the caches: one 16-byte bucket per k-mer that is looked up (plus list entries
-            # for multi-gene hits); ceiling measured with tools/gather_bench on an 8 GiB table (profiles/r02_gather_ceiling.jsonl).
-            # The bound cut ends an off-target pair after 128 of its 320 slots, so fewer k-mers are looked up than the reads hold:
-            # the requests actually made are the TCC misses of the counter pass (same kernel sources), when that file is usable.
-            rl = {"bound": "random 16-B lookups behind L2 (request rate, not bytes)", "kmers_in_reads": int(w2["n_kmers"]),
-                  "G_kmers_per_s": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1), "ceiling_G_lookups_per_s": RANDOM_LOOKUP_CEILING_G}
+        if rank == 0:
+            # This index is bound by the RATE of random memory-side requests: one 16-byte bucket per k-mer that is looked up, each
+            # a 128-byte line of an 8 GiB table.  The ceiling is measured here, in this run, with the library's own measurement
+            # entry point (same device, same table size, plain and streaming loads, the better of the two); the requests the
+            # classify kernel makes per launch are the L2 misses of the counter pass on the same kernel sources (the bound cut,
+            # the early decision and the anchored extension make fewer lookups than the reads hold k-mers).
+            ceil_plain = h2.measure_random_lookups(tab2_bytes, 1 << 31, False)
+            ceil_nt = h2.measure_random_lookups(tab2_bytes, 1 << 31, True)
+            ceiling = max(ceil_plain, ceil_nt)
+            alg2 = w2["n_bases"] + 8 * w2["n_kmers"] + 16 * w2["n_hits"] + 2 * w2["n_list_ids"] + 8 * (2 * lp)
+            rl = {"bound": "memory-side request rate (random 128-B lines behind L2)", "kmers_in_reads": int(w2["n_kmers"]), "hits": int(w2["n_hits"]),
+                  "algorithmic_bytes_per_launch": int(alg2), "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                  "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                  "G_kmers_per_s": round(w2["n_kmers"] / (k2 * 1e-3) / 1e9, 1),
+                  "ceiling_G_lookups_per_s": round(ceiling, 1), "ceiling_measured": {"table_bytes": tab2_bytes, "plain": round(ceil_plain, 1),
+                                                                                    "streaming": round(ceil_nt, 1), "how": "shk_measure_random_lookups, this run"}}
             pj2, note2 = load_pmc(17, 33)
             e2 = pj2.get("workloads", {}).get("configs2") if pj2 else None
             if e2 and e2.get("TCC_MISS_sum"):
-                rl["memory_side_requests_per_launch"] = int(e2["TCC_MISS_sum"])
-                rl["G_requests_per_s"] = round(e2["TCC_MISS_sum"] / (k2 * 1e-3) / 1e9, 1)
-                rl["frac"] = round(e2["TCC_MISS_sum"] / (k2 * 1e-3) / 1e9 / RANDOM_LOOKUP_CEILING_G, 3)
-                rl["sector_GBps"] = round(64 * e2["TCC_MISS_sum"] / (k2 * 1e-3) / 1e9, 1)
+                req = e2["TCC_MISS_sum"]
+                rl["memory_side_requests_per_launch_from_profile"] = int(req)
+                rl["G_requests_per_s"] = round(req / (k2 * 1e-3) / 1e9, 1)
+                rl["frac_of_binding"] = round(min(1.0, req / (k2 * 1e-3) / 1e9 / ceiling), 3)
+                rl["line_GBps"] = round(L2_LINE_BYTES * req / (k2 * 1e-3) / 1e9, 1)
+                rl["frac_of_hbm_peak"] = round(L2_LINE_BYTES * req / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)
+                rl["frac_of_hbm_peak_at_64B_sectors"] = round(64 * req / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)
             rl["counters"] = note2
             cfg2["roofline"] = rl
         h2.close()
@@ -307,18 +324,30 @@ def main():
         h4 = SharkHip(k=31, c=0.6, bf_bits=1 << 37, min_quality=20, single=True, device=local_rank)
         info4 = h4.build([g.tobytes() for g in g2])
         t_build4 = time.time() - t0
-        b4 = synth.make_pairs_device(lp, g2, dev, seed=synth.SEED + 7 + rank, read_len=L, on_target=0.5, with_qual=True)
-        torch.cuda.synchronize()
-        p4 = [{kk: (v.data_ptr() if v is not None else 0) for kk, v in b4.items()}]
-        dt4, tm4, _, n_assoc4, _ = timed(h4, p4, lp, steps2, 1, False)
-        k4 = tm4["total_ms"] / max(tm4["n_launches"], 1)
-        cfg4 = {"workload": "configs[4] shape: the same 60000 genes, %d pairs 2x150 bp with qualities (90 %% >= Q30) per GPU per step, "
-                            "k=31 c=0.6 -q 20 --single bf=2^37 bits" % lp,
-                "value": round(2 * lp * world * steps2 / dt4, 1), "unit": "reads/s", "n_gpus": world, "steps": steps2,
-                "ms_per_step": round(dt4 / steps2 * 1e3, 3), "kernel_ms": round(k4, 4), "probe_mode": h4.probe_mode(),
-                "index_build_s": round(t_build4, 3), "n_set_bits": int(info4["n_set_bits"]), "assoc_per_step": n_assoc4 // steps2}
+        cfg4 = None
+        for qual_model in ("uniform", "ends"):
+            # "ends": low qualities at the 3' end of the reads (1.2 % of the bases below Q20); "uniform": rounds 1-2's model, 10 % of the
+            # bases Q2-29 anywhere, under which a 31-mer survives -q 20 with 0.13 and the hit path is barely exercised (shark_amd/synth.py)
+            b4 = synth.make_pairs_device(lp, g2, dev, seed=synth.SEED + 7 + rank, read_len=L, on_target=0.5, with_qual=True, qual_model=qual_model)
+            torch.cuda.synchronize()
+            p4 = [{kk: (v.data_ptr() if v is not None else 0) for kk, v in b4.items()}]
+            dt4, tm4, _, n_assoc4, _ = timed(h4, p4, lp, steps2, 1, False)
+            k4 = tm4["total_ms"] / max(tm4["n_launches"], 1)
+            below_q20 = float((b4["qual1"][:1 << 24] < 53).float().mean().item())
+            e4 = {"qualities": qual_model, "frac_bases_below_q20": round(below_q20, 4),
+                  "value": round(2 * lp * world * steps2 / dt4, 1), "unit": "reads/s", "ms_per_step": round(dt4 / steps2 * 1e3, 3),
+                  "kernel_ms": round(k4, 4), "assoc_per_step": n_assoc4 // steps2, "frac_pairs_assigned": round(n_assoc4 / steps2 / lp, 4)}
+            if qual_model == "uniform":
+                old4 = e4
+            else:
+                cfg4 = {"workload": "configs[4] shape: the same 60000 genes, %d pairs 2x150 bp with qualities (Q30-41, low 3' tails: %.1f %% of the bases "
+                                    "below Q20) per GPU per step, k=31 c=0.6 -q 20 --single bf=2^37 bits" % (lp, 100 * below_q20),
+                        "n_gpus": world, "steps": steps2, "probe_mode": h4.probe_mode(), "index_build_s": round(t_build4, 3),
+                        "n_set_bits": int(info4["n_set_bits"])}
+                cfg4.update(e4)
+                cfg4["rounds_1_2_workload"] = old4
+            del b4, p4
         h4.close()
-        del b4
         # the headline context again for the roofline counters / cpu sample below
         h = SharkHip(k=k, c=c, bf_bits=bf_bits, device=local_rank)
         h.build([g.tobytes() for g in genes])
@@ -363,23 +392,23 @@ def main():
                 "cycles_per_valu_inst": round(kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / iv, 2),
                 "frac_of_issue_ceiling": round(iv * 2.0 / (kern_ms * 1e-3 * CLK_GHZ * 1e9 * N_SIMD), 4),
                 "ceiling": "1024 SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction" % CLK_GHZ}
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    lds_mode = h.probe_mode().startswith("lds-")
+    roofline = {"bound": "valu-issue" if lds_mode else "memory-side request rate (random 128-B lines behind L2)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "frac_of_binding": valu["frac_of_issue_ceiling"] if (valu and lds_mode) else None,
+                "what_frac_is": "the contract's figure: SURVEY 8(d) algorithmic bytes (every k-mer of every read, as the reference visits them) / kernel time / 8 TB/s "
+                                "HBM peak -- a model figure, not HBM use: on this index the exact table sits in LDS and the bound cut / early decision (DESIGN.md 3) "
+                                "never make most of those probes.  `bound` names what does bind the kernel, `frac_of_binding` its use "
+                                "(VALU wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time))",
                 "kernel": "classify_uni_kernel" if "table" in h.probe_mode() else "classify_fast_kernel",
                 "kernel_ms": round(kern_ms, 4), "launches": int(tm["n_launches"]),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / (2 * n), 1),
                 "kmers": int(w["n_kmers"]), "hits": int(w["n_hits"]),
-                "algorithmic_bytes": "SURVEY 8(d) per-read figure over every k-mer of every read, as the reference visits them; the kernel's bound "
-                                     "cut and early decision (DESIGN.md 3) prove most probes of an off-target pair and two fifths of an "
-                                     "on-target pair's irrelevant and do not make them",
-                "binding_resource": "VALU issue (the algorithmic bytes above mostly never reach HBM: this index's exact table is held in LDS; "
-                                    "a pair none of whose first 128 slots is in the filter ends there -- the other slots cannot reach c*len --, and "
-                                    "a pair whose best gene after 192 slots cannot be caught up by any other is decided there)"
-                                    if h.probe_mode() == "lds-table" else
-                                    "VALU issue (the algorithmic bytes above mostly never reach HBM: the LDS summary proves clear probes clear, "
-                                    "hits are served by the L2-resident position table)",
-                "valu": valu, "hbm_actual": hbm_actual, "kernel_src_sha": sha, "counters": prof_note}
+                "valu_from_profile": valu, "hbm_actual_from_profile": hbm_actual, "traffic_source": "profiles/pmc_counters.json (a separate rocprofv3 --pmc pass "
+                "on the same kernel sources, not this run)" if traffic is not None else None,
+                "kernel_src_sha": sha, "counters": prof_note}
 
     # ---- PCIe-inclusive rate of the host-buffer entry point (never `value`) ---------
     boundary = None
@@ -430,26 +459,43 @@ def main():
             pass
         model, phys = cpu_info()
         ns = args.cpu_sample_pairs or min(n, threads * 50000)
-        hb = synth.to_host_sample(batch, ns, L)
+        # the sample: half from the head of the batch, half from its middle (the generator works in chunks of 2^20 pairs)
+        n_head = ns - ns // 2 if n >= 2 * ns else ns
+        n_mid, first_mid = ns - n_head, n // 2
+        hb = synth.to_host_sample(batch, n_head, L)
+        if n_mid:
+            hm = synth.to_host_sample(batch, n_mid, L, first=first_mid)
+            for kk in ("seq1", "seq2"):
+                hb[kk] = np.concatenate([hb[kk], hm[kk]])
+            hb["off1"] = np.arange(0, (ns + 1) * L, L, dtype=np.uint64)
+            hb["off2"] = hb["off1"].copy()
         o = pyoracle.Shark(k=k, c=c, bf_bits=bf_bits)
         o.build([g.tobytes() for g in genes])
         t0 = time.perf_counter()
         ogoff, ogids = o.classify(hb["seq1"], hb["off1"], hb["seq2"], hb["off2"], nthreads=threads)
         tc = time.perf_counter() - t0
-        # the sample doubles as an end-of-run parity check against the GPU result
-        goff = np.empty(ns + 1, dtype=np.uint32)
-        hip_memcpy_dtoh(goff, res.gene_off, (ns + 1) * 4)
-        gids = np.empty(max(int(goff[ns]), 1), dtype=np.uint16)
-        hip_memcpy_dtoh(gids, res.gene_ids, int(goff[ns]) * 2)
-        parity = bool(np.array_equal(goff, ogoff) and np.array_equal(gids[:int(goff[ns])], ogids))
+        # the sample doubles as an end-of-run parity check against the GPU result (`res`: the last launch on this batch)
+        parity = True
+        for first, cnt, o_first in ((0, n_head, 0), (first_mid, n_mid, n_head)):
+            if not cnt:
+                continue
+            goff = np.empty(cnt + 1, dtype=np.uint32)
+            hip_memcpy_dtoh(goff, res.gene_off + 4 * first, (cnt + 1) * 4)
+            n_ids = int(goff[cnt]) - int(goff[0])
+            gids = np.empty(max(n_ids, 1), dtype=np.uint16)
+            hip_memcpy_dtoh(gids, res.gene_ids + 2 * int(goff[0]), n_ids * 2)
+            want_off = ogoff[o_first:o_first + cnt + 1].astype(np.int64) - int(ogoff[o_first])
+            parity = parity and bool(np.array_equal(goff.astype(np.int64) - int(goff[0]), want_off)
+                                     and np.array_equal(gids[:n_ids], ogids[int(ogoff[o_first]):int(ogoff[o_first + cnt])]))
         # one thread on one reference chunk (SURVEY 8d asks for -t 1 next to all cores)
-        n1 = min(ns, 50000)
+        n1 = min(n_head, 50000)
         t0 = time.perf_counter()
         o.classify(hb["seq1"][:int(hb["off1"][n1])], hb["off1"][:n1 + 1], hb["seq2"][:int(hb["off2"][n1])], hb["off2"][:n1 + 1], nthreads=1)
         t1 = time.perf_counter() - t0
         cpu = {"value": round(2 * ns / tc, 1), "unit": "reads/s", "cores": threads, "kind": "port",
                "physical_cores": phys or None, "cpu_model": model,
-               "sample": "first %d pairs of the same batch, %d threads x 50 000-read chunks (main.cpp:215), %.1f s" % (ns, threads, tc),
+               "sample": "%d pairs of the same batch (the first %d and %d from its middle), %d threads x 50 000-read chunks (main.cpp:215), %.1f s"
+                         % (ns, n_head, n_mid, threads, tc),
                "parity_with_gpu": parity,
                "one_thread": {"value": round(2 * n1 / t1, 1), "unit": "reads/s", "sample": "first %d pairs, %.1f s" % (n1, t1)}}
         o.close()

@@ -219,6 +219,14 @@ typedef struct shk_work_counters {
 } shk_work_counters;
 int shk_count_work(shk_ctx *ctx, const shk_batch *dev_batch, shk_work_counters *out);
 
+/* The part's ceiling for INDEPENDENT random 16-byte lookups in a table of `table_bytes` (a power of two >= 1 MiB) on the
+ * context's device: the access pattern of the position table, one bucket per k-mer at a hashed address.  On an index far
+ * beyond the caches each lookup is one memory-side request (a 128-byte line of which 16 bytes are used) and the RATE of
+ * those bounds the classify kernel; bench.py measures the ceiling with this call in the run whose fraction of it it
+ * reports.  Allocates the table, performs about `n_lookups` lookups (five in flight per lane, 8 waves per SIMD;
+ * `nontemporal` != 0: streaming loads), frees it again.  On no product path; new (the reference has no counterpart). */
+int shk_measure_random_lookups(shk_ctx *ctx, uint64_t table_bytes, uint64_t n_lookups, int nontemporal, double *g_lookups_per_s);
+
 /* pinned host memory helpers for callers that stream batches */
 void *shk_alloc_pinned(size_t bytes);
 void  shk_free_pinned(void *p);

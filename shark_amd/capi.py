@@ -50,7 +50,7 @@ EXPORTS = [
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
     "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode", "shk_gene_counts_allreduce",
     "shk_classify_submit", "shk_classify_wait", "shk_dist_unique_id", "shk_dist_init", "shk_dist_gene_counts_allreduce",
-    "shk_dist_info",
+    "shk_dist_info", "shk_measure_random_lookups",
 ]
 SHK_PIPE_DEPTH = 3
 SHK_DIST_ID_BYTES = 128
@@ -100,6 +100,8 @@ def load():
     L.shk_dist_init.restype = C.c_int; L.shk_dist_init.argtypes = [p, p, C.c_int, C.c_int]
     L.shk_dist_gene_counts_allreduce.restype = C.c_int; L.shk_dist_gene_counts_allreduce.argtypes = [p, p, C.c_uint32]
     L.shk_dist_info.restype = C.c_int; L.shk_dist_info.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.shk_measure_random_lookups.restype = C.c_int
+    L.shk_measure_random_lookups.argtypes = [p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -287,6 +289,12 @@ class SharkHip:
             td.all_reduce(t)
             a = t.numpy().astype(np.uint64)
         return a
+
+    def measure_random_lookups(self, table_bytes, n_lookups=1 << 31, nontemporal=False):
+        """G independent random 16-byte lookups per second in a table of table_bytes on this context's GPU"""
+        g = C.c_double()
+        self._check(self.L.shk_measure_random_lookups(self.h, table_bytes, n_lookups, int(bool(nontemporal)), C.byref(g)), "shk_measure_random_lookups")
+        return g.value
 
     def timing_enable(self, on=True):
         self._check(self.L.shk_timing_enable(self.h, int(on)), "shk_timing_enable")

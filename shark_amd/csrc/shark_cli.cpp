@@ -250,6 +250,10 @@ struct ReadBatch {
   uint64_t first_read = 0;  // global index of its first read
   Strings id1, id2;
   DevStrings seq1, qual1, seq2, qual2;
+  // records whose quality string does not have the sequence's length as the reference sees them (C strings: a NUL cuts the
+  // sequence short, FastqSplitter.hpp:55,:63; a FASTA-style record has no qualities): the device reads qualities at the
+  // sequence offsets, the output (ReadOutput.hpp:44-47) prints the quality string as it was
+  std::map<size_t, std::string> qual_as_read1, qual_as_read2;
   // result
   std::vector<uint32_t> gene_off;
   std::vector<uint16_t> gene_ids;
@@ -257,6 +261,7 @@ struct ReadBatch {
   void reset()
   {
     id1.reset(); id2.reset(); seq1.reset(); qual1.reset(); seq2.reset(); qual2.reset();
+    qual_as_read1.clear(); qual_as_read2.clear();
     gene_off.clear(); gene_ids.clear();
     rc = 0;
   }
@@ -355,7 +360,7 @@ class BatchSplitter {
       // the two mate files are parsed (and, for .gz, inflated) by two threads at once; the pair
       // stream ends with the shorter file, as in the reference's read loop (FastqSplitter.hpp:60)
       const size_t have = b->seq1.size(), want = (size_t)maxnum_ - have;
-      auto fill_serial = [want](shk::FastxReader &r, Strings &id, DevStrings &seq, DevStrings &qual) {
+      auto fill_serial = [want](shk::FastxReader &r, Strings &id, DevStrings &seq, DevStrings &qual, std::map<size_t, std::string> &qual_as_read) {
         shk::FastxRecord a;
         size_t got = 0;
         while (got < want && r.read(a) >= 0) {
@@ -366,7 +371,9 @@ class BatchSplitter {
           // The device reads qualities at the sequence offsets.  The reference masks position i only for i < qual.length()
           // (FastqSplitter.hpp:104-109 with the C-string lengths of :55,:63): a record without a quality line, or one cut
           // short by a NUL, is not masked behind the end of its quality string -- those positions get the top quality.
-          const size_t ql = std::min(sl, strnlen(a.qual.data(), a.qual.size()));
+          const size_t qfull = strnlen(a.qual.data(), a.qual.size());
+          if (qfull != sl) qual_as_read[seq.size() - 1] = std::string(a.qual.data(), qfull);
+          const size_t ql = std::min(sl, qfull);
           a.qual.resize(ql);
           a.qual.resize(sl, '\x7f');
           qual.push(a.qual.data(), sl);
@@ -376,8 +383,8 @@ class BatchSplitter {
       };
       size_t got1 = 0, got2 = 0;
       if (paired_) {
-        std::thread t2([&] { got2 = fill_serial(*r2_, b->id2, b->seq2, b->qual2); });
-        got1 = fill_serial(r1_, b->id1, b->seq1, b->qual1);
+        std::thread t2([&] { got2 = fill_serial(*r2_, b->id2, b->seq2, b->qual2, b->qual_as_read2); });
+        got1 = fill_serial(r1_, b->id1, b->seq1, b->qual1, b->qual_as_read1);
         t2.join();
         const size_t keep = have + std::min(got1, got2);
         if (got1 != got2) {   // one file ended: drop the unpaired surplus, nothing more will be read
@@ -386,7 +393,7 @@ class BatchSplitter {
           done_ = true;
         }
       } else {
-        got1 = fill_serial(r1_, b->id1, b->seq1, b->qual1);
+        got1 = fill_serial(r1_, b->id1, b->seq1, b->qual1, b->qual_as_read1);
       }
       if (got1 < want) done_ = true;
       t_serial += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
@@ -520,8 +527,8 @@ class ReadOutput {
             ssv[si].push_back('\n');
             const bool same = previd.size() == b.id1.len(i) && memcmp(previd.data(), b.id1.at(i), previd.size()) == 0;
             if (!same) {
-              if (out1_) record(fq1[si], b.id1, b.seq1, b.qual1, i);
-              if (out2_) record(fq2[si], b.id2, b.seq2, b.qual2, i);
+              if (out1_) record(fq1[si], b.id1, b.seq1, b.qual1, b.qual_as_read1, i);
+              if (out2_) record(fq2[si], b.id2, b.seq2, b.qual2, b.qual_as_read2, i);
             }
             previd.assign(b.id1.at(i), b.id1.len(i));
             have = true;
@@ -541,14 +548,16 @@ class ReadOutput {
   }
 
  private:
-  static void record(std::string &f, const Strings &id, const DevStrings &seq, const DevStrings &qual, size_t i)
+  static void record(std::string &f, const Strings &id, const DevStrings &seq, const DevStrings &qual, const std::map<size_t, std::string> &qual_as_read, size_t i)
   {
     f.push_back('@');
     if (i < id.size()) f.append(id.at(i), id.len(i));
     f.push_back('\n');
     if (i < seq.size()) f.append(seq.at(i), seq.len(i));
     f.append("\n+\n");
-    if (i < qual.size()) f.append(qual.at(i), qual.len(i));
+    const auto odd = qual_as_read.empty() ? qual_as_read.end() : qual_as_read.find(i);
+    if (odd != qual_as_read.end()) f.append(odd->second);
+    else if (i < qual.size()) f.append(qual.at(i), qual.len(i));
     f.push_back('\n');
   }
   FILE *out1_, *out2_;

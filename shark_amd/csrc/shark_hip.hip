@@ -487,8 +487,6 @@ static void dist_release(Ctx *ctx)
 
 using namespace shk;
 
-struct shk_ctx : public shk::Ctx {};
-
 extern "C" {
 
 const char *shk_version(void) { return "sharkhip 0.1 (gfx950)"; }

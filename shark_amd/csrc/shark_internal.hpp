@@ -280,3 +280,6 @@ int ensure_capacity(Ctx *ctx, T **ptr, size_t *cap, size_t need)
 }
 
 }  // namespace shk
+
+// the opaque context of the C ABI
+struct shk_ctx : public shk::Ctx {};

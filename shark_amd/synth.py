@@ -32,8 +32,28 @@ def make_gencode_like_reference(n_genes=60000, seed=SEED):
     return genes
 
 
+def _qualities(m, L, g, device, model):
+    """Phred+33 qualities of m reads of length L.
+    "ends" (skewed high, so that -q 20 leaves valid k-mers): Q30-41 everywhere except a low-quality tail at the
+      3' end -- its length floor(Exp(mean 2)), at most 30 bases -- and 0.2 % isolated low bases, both Q2-19: about 1.2 % of the
+      bases fall below Q20, and a 31-mer away from the tail survives -q 20 with 0.94;
+    "uniform" (rounds 1-2): 10 % of the bases Q2-29 anywhere -- 6.4 % below Q20, a 31-mer survives with 0.13, which left the
+      k = 31 quality-mask HIT path almost unexercised (1.3 % of the pairs assigned)."""
+    hi = torch.randint(30, 42, (m, L), generator=g, device=device)
+    if model == "uniform":
+        lo = torch.randint(2, 30, (m, L), generator=g, device=device)
+        q = torch.where(torch.rand(m, L, generator=g, device=device) < 0.9, hi, lo)
+    else:
+        lo = torch.randint(2, 20, (m, L), generator=g, device=device)
+        tail = torch.clamp((-2.0 * torch.log(torch.rand(m, generator=g, device=device).clamp_min(1e-12))).floor(), max=30).to(torch.int64)
+        low = torch.arange(L, device=device)[None, :] >= (L - tail)[:, None]
+        low |= torch.rand(m, L, generator=g, device=device) < 0.002
+        q = torch.where(low, lo, hi)
+    return (q + 33).to(torch.uint8)
+
+
 def make_pairs_device(n, genes, device, seed=SEED, read_len=150, on_target=0.5, sub_rate=0.01, n_rate=0.002,
-                      with_qual=False, chunk=1 << 20):
+                      with_qual=False, chunk=1 << 20, qual_model="ends"):
     """n pairs of fixed-length mates resident on `device`.
     returns dict(seq1, off1, seq2, off2, qual1, qual2) of torch tensors (uint8 / int64)."""
     g = torch.Generator(device=device)
@@ -77,21 +97,18 @@ def make_pairs_device(n, genes, device, seed=SEED, read_len=150, on_target=0.5, 
         seq2[b0 * L:(b0 + m) * L] = m2.reshape(-1)
         if with_qual:
             for qq in (qual1, qual2):
-                hi = torch.randint(30, 42, (m, L), generator=g, device=device)
-                lo = torch.randint(2, 30, (m, L), generator=g, device=device)
-                q = torch.where(torch.rand(m, L, generator=g, device=device) < 0.9, hi, lo) + 33
-                qq[b0 * L:(b0 + m) * L] = q.to(torch.uint8).reshape(-1)
+                qq[b0 * L:(b0 + m) * L] = _qualities(m, L, g, device, qual_model).reshape(-1)
     off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=device)
     return {"seq1": seq1, "off1": off, "seq2": seq2, "off2": off.clone(), "qual1": qual1, "qual2": qual2}
 
 
-def to_host_sample(batch, n_sample, read_len=150):
-    """first n_sample pairs as numpy arrays (same bytes the GPU classified)"""
+def to_host_sample(batch, n_sample, read_len=150, first=0):
+    """pairs [first, first + n_sample) as numpy arrays (same bytes the GPU classified)"""
     L = read_len
     out = {}
     for key in ("seq1", "seq2", "qual1", "qual2"):
         t = batch.get(key)
-        out[key] = t[:n_sample * L].cpu().numpy() if t is not None else None
+        out[key] = t[first * L:(first + n_sample) * L].cpu().numpy() if t is not None else None
     off = np.arange(0, (n_sample + 1) * L, L, dtype=np.uint64)
     out["off1"] = off
     out["off2"] = off.copy() if batch.get("seq2") is not None else None

@@ -18,17 +18,22 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "bitvector", "no-lds-table"])
+@pytest.fixture(params=["auto", "bitvector", "no-lds-table", "force-generic"])
 def probe(request, monkeypatch):
     """run a test once with the index's automatic probe structure (position table where possible; tiny indices: the exact
-    table in LDS for uniform batches), once forced onto the plain filter words (+rank directory), and once without the
-    LDS-resident table (so that tiny indices also exercise the LDS-summary + position-table chain on uniform batches)"""
+    table in LDS for uniform batches), once forced onto the plain filter words (+rank directory), once without the
+    LDS-resident table (so that tiny indices also exercise the LDS-summary + position-table chain on uniform batches), and
+    once with SHK_FORCE_GENERIC=1: every batch through classify_fast_kernel / process_read, whose table-mode instantiations
+    otherwise only see batches with reads of more than 512 bases"""
     monkeypatch.delenv("SHK_PROBE", raising=False)
     monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
+    monkeypatch.delenv("SHK_FORCE_GENERIC", raising=False)
     if request.param == "bitvector":
         monkeypatch.setenv("SHK_PROBE", "bitvector")
     elif request.param == "no-lds-table":
         monkeypatch.setenv("SHK_NO_LDS_TABLE", "1")
+    elif request.param == "force-generic":
+        monkeypatch.setenv("SHK_FORCE_GENERIC", "1")
     return request.param
 
 
