@@ -94,6 +94,10 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_NO_TOL
 #define SHK_NO_TOL 0
 #endif
+// (-DSHK_NO_ANCHOR=1: a build without the anchored extension, for A/B timing; at run time SHK_NO_ANCHOR=1 when the index is built)
+#ifndef SHK_NO_ANCHOR
+#define SHK_NO_ANCHOR 0
+#endif
 // MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
 // probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
 // only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
@@ -130,6 +134,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool CUT = !SUM && !SHK_NO_CUT;
   constexpr bool TOL = CUT && !pm_lds(MODE) && !SHK_NO_TOL;   // table modes: matches are counted, and there is a second cut point
   constexpr bool ACCEPT = !SHK_NO_ACCEPT;                      // the early decision (vote<J> with J < U)
+  constexpr bool ANCH = !pm_lds(MODE) && !SHK_NO_ANCHOR;        // table modes: the anchored extension (when the index carries ref2 / refpay / anchor)
   using UG = UniGeom<U, MODE, LSL>;
   constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
@@ -309,8 +314,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
     }
 
-    // ---- everything behind the staging, for a compile-time E (rounds [0, E) first; E == U: all at once, no cut) ----
-    auto classify_staged = [&](auto e_const) {
+    // ---- everything behind the staging, for a compile-time E: rounds [0, E) first; E == U: all at once, no cut; E < 0: the anchored
+    // extension (table modes), which returns false when the read has to take one of the other sequences after all.
+    // (State and steps are declared INSIDE the lambda: shared between its instantiations from outside, hipcc 7.2 stops with
+    //  "illegal VGPR to SGPR copy" on the ragged U = 6 / 8 table kernels; unused steps cost an instantiation nothing.) ----
+    auto classify_staged = [&](auto e_const) -> bool {
     constexpr int E = decltype(e_const)::value;
     uint64_t pos[U];
     uint32_t okm[U];   // all ones where the slot's probe has to be made, else 0
@@ -319,49 +327,65 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     bool mt[U];
     uint32_t slo[U];
     bool lane_any = false;
-    // ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) reduce a bucket to that word right
-    // away and walk all their probes per round; the 64-VGPR ones keep the buckets until the hit path and walk probe by probe
+    // REP: a bucket is reduced to that word right away (LDS-summary modes; table modes since the anchored extension fills mt / slo
+    // from the reference as well).  WALK_ROUNDS: the instantiations with registers to spare (LDS-summary modes, 80+ VGPRs) walk all
+    // their probes per round; the table modes walk probe by probe (the per-round form spilled there: 5-18 % slower on large indices)
 #ifndef SHK_ROUNDS_ALL
 #define SHK_ROUNDS_ALL 0
 #endif
-    constexpr bool ROUNDS = LSUM || SHK_ROUNDS_ALL;
+    constexpr bool WALK_ROUNDS = LSUM || SHK_ROUNDS_ALL;
+    constexpr bool ROUNDS = LSUM || ANCH || SHK_ROUNDS_ALL;
     const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
     const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
     const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
     const uint32_t spare = 1u << P.tab_lg;
     // the word a slot's high word is compared with (0 = empty slot): tag | valid | displacement 0
-    auto want_of = [&](const int j) -> uint32_t {
-      const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(pos[j] >> 32), (uint32_t)pos[j], P.tab_lg) & tagmask;
+    auto want_for = [&](const uint64_t ps) -> uint32_t {
+      const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(ps >> 32), (uint32_t)ps, P.tab_lg) & tagmask;
       return (tag << 8) | 0x80u;
     };
+    auto want_of = [&](const int j) -> uint32_t { return want_for(pos[j]); };
     auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
+    // both orientations of the k-mer of slot (lane, j): x = its bases first-base-low (the fw stream's window), y = first-base-high
+    // (the rv stream's window = the k-mer as kmer_utils.hpp:67-69 packs it); ~x is the reverse complement (kmer_utils.hpp:47-55)
+    auto windows = [&](const int j, uint64_t &x, uint64_t &y) {
+      const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
+      const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
+      const uint32_t *f = fw + ((uint32_t)lane >> 4) + 4 * j;
+      const uint32_t *r = rv + (qU >> 4) + 4 * (U - 1 - j);
+      const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+      const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+      x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
+      y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
+    };
+    // slot pp exists and all its k characters are valid (process_read, slot_ok)
+    const uint64_t kmask0 = (1ull << k) - 1ull;
+    auto slot_valid = [&](const uint32_t pp) -> bool {
+      const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+      const uint32_t V = pp >> 6, vs = pp & 63u;
+      const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
+      const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+      return exists & ((win & kmask0) == kmask0);
+    };
     // ---- canonical k-mers, hashes, summary probes, table probes of the rounds [JLO, JHI) ----
     // (returns false when nothing of these rounds can have matched: no probe passed its summary / no slot is a valid k-mer)
-    auto probe_rounds = [&](auto lo_const, auto hi_const) -> bool {
+    // known (table modes, anchored extension): bit j set = slot (lane, j) is settled already -- mt[j] / slo[j] stay, no probe is made
+    auto probe_rounds = [&](auto lo_const, auto hi_const, const uint32_t known) -> bool {
       constexpr int JLO = decltype(lo_const)::value, JHI = decltype(hi_const)::value;
       constexpr bool ALL = JLO == 0 && JHI == U;   // the only phase: its caller ends the read when nothing can have matched
-      {
-        const uint32_t qU = rcap - k - ((uint32_t)lane + 64u * (U - 1));
-        const uint32_t sf = ((uint32_t)lane & 15u) << 1, sr = (qU & 15u) << 1;
 #pragma unroll
-        for (int j = JLO; j < JHI; ++j) {
-          const uint32_t *f = fw + ((uint32_t)lane >> 4) + 4 * j;
-          const uint32_t *r = rv + (qU >> 4) + 4 * (U - 1 - j);
-          const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
-          const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
-          const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sf) << 32) | __builtin_amdgcn_alignbit(d1, d0, sf);
-          const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
-          const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
-          const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
-          const uint64_t hsh = xxh64_u64(canon);
-          // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
-          pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
-        }
+      for (int j = JLO; j < JHI; ++j) {
+        uint64_t x, y;
+        windows(j, x, y);
+        const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+        const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
+        const uint64_t hsh = xxh64_u64(canon);
+        // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
+        pos[j] = POW2 ? (LSUM ? hsh : (hsh & P.bf_mask)) : bf_pos_np(hsh, P);
       }
       bool something = false;
       if (!LSUM) {
-        // slot pp exists and all its k characters are valid (process_read, slot_ok); then the L2-resident summary
-        const uint64_t kmask0 = (1ull << k) - 1ull;
+        // slot pp exists and all its k characters are valid; then the L2-resident summary
         bool ok[U];
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) {
@@ -371,6 +395,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
           const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
           ok[j] = exists & ((win & kmask0) == kmask0);
+          if (ANCH) ok[j] = ok[j] & (((known >> j) & 1u) == 0u);
         }
         if (SUM) {
           uint32_t sw[U];
@@ -447,8 +472,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           const uint32_t want = want_of(j);
           const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
           if (ROUNDS) {
-            mt[j] = m0 | m1;
-            slo[j] = m0 ? bk[j].x : bk[j].z;
+            const bool kn = ANCH && ((known >> j) & 1u) != 0u;   // (a settled slot read the spare bucket: nothing matched)
+            mt[j] = kn ? mt[j] : (m0 | m1);
+            slo[j] = kn ? slo[j] : (m0 ? bk[j].x : bk[j].z);
           }
           lane_any |= m0 | m1;
           more[j] = !(m0 | m1) & ((bk[j].x & TAB_OVERFLOW) != 0u);   // some key of this home bucket lives further down the path
@@ -456,7 +482,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         }
         if (__ballot(lane_more) && !SHK_ABL(P, 8u)) {   // (ablation 8: no walks)
           // rare: the key may sit behind its (full) home bucket
-          if (ROUNDS) {
+          if (WALK_ROUNDS) {
             // round d looks at bucket home+d of every probe that is still searching, all loads in flight together (the
             // others read the spare bucket: one line for the wave) -- a memory round trip per displacement, not per probe
             uint32_t d = 0;
@@ -479,7 +505,18 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
               }
             } while (__ballot(lane_more));
           } else {
+            bool walked[U];
+#pragma unroll
+            for (int j = JLO; j < JHI; ++j) walked[j] = more[j];
             walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
+            if (ROUNDS) {
+#pragma unroll
+              for (int j = JLO; j < JHI; ++j) {
+                const bool f = walked[j] & (bk[j].y == want_of(j));
+                mt[j] |= f;
+                slo[j] = f ? bk[j].x : slo[j];
+              }
+            }
           }
         }
       } else if (!LX && !ALL) {
@@ -525,10 +562,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       uint32_t gid[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        const uint32_t want = want_of(j);
-        const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
-        const uint32_t lo = ROUNDS ? slo[j] : (m0 ? bk[j].x : bk[j].z);
-        const bool m = ROUNDS ? mt[j] : (m0 | m1), multi = (lo >> 31) != 0u;
+        uint32_t lo;
+        bool m;
+        if (ROUNDS) { lo = slo[j]; m = mt[j]; }
+        else {
+          const uint32_t want = want_of(j);
+          const bool m0 = bk[j].y == want, m1 = bk[j].w == want;
+          lo = m0 ? bk[j].x : bk[j].z;
+          m = m0 | m1;
+        }
+        const bool multi = (lo >> 31) != 0u;
         gid[j] = lo & 0xFFFFu;
         H[j] = __ballot(m & !multi);
         W[j] = __ballot(m & multi);
@@ -569,14 +612,14 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       return best;
     };
     // ---- the vote over the matches of the rounds [0, J) (ReadAnalyzer.hpp:56-62, :79-108) ------------------------------------
-    // J == U: every slot is probed, the result is final and written.  J < U (the early decision): the slots not probed yet cover
+    // FINAL: every slot is settled, the result is final and written.  Else (the early decision): the slots not settled yet cover
     // `ub_rest` bases, so every gene's final coverage is at most (its coverage now) + ub_rest, and the best gene's is at least
     // what it is now.  If that gene alone is best, passes c * len already, and leads every other gene -- those without a match so
     // far included -- by more than ub_rest, the remaining probes cannot change the outcome: it is the read's only association
     // (whatever its final coverage and k-mer count, which the reference does not output).  Returns true when the read is settled.
-    auto vote = [&](auto j_const, const uint32_t ub_rest) -> bool {
+    auto vote = [&](auto j_const, auto final_const, const uint32_t ub_rest) -> bool {
       constexpr int J = decltype(j_const)::value;
-      constexpr bool FINAL = J == U;
+      constexpr bool FINAL = decltype(final_const)::value;
       if (!__ballot(lane_any) || SHK_ABL(P, 16u)) return FINAL;   // nothing matched (ablation 16: no hit path)
       {
         // ================= something matched in the table: the hit path =================
@@ -701,8 +744,135 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
     };
     using I0 = std::integral_constant<int, 0>;
-    using IE = std::integral_constant<int, E>;
     using IU = std::integral_constant<int, U>;
+    // ---- the anchored extension (table modes) ---------------------------------------------------------------------
+    // A k-mer that is in the table knows where it occurs in the reference (`anchor`, one occurrence per table slot).  A read
+    // drawn from a gene matches the reference base for base around such a place, so most of its k-mers are the reference's k-mers
+    // at the neighbouring positions -- and what a probe of those returns is stored per reference position (`refpay`), contiguously:
+    // 64 slots of a round read 256 bytes of it and 24 bytes of the packed reference instead of 64 buckets at 64 hashed addresses.
+    //  (1) sample: eight slots spread over each mate, one per lane, probed through the table as ever (one hash per lane);
+    //  (2) the first match of each mate gives that mate's anchor: reference position + relative orientation;
+    //  (3) every slot of an anchored mate is compared with the reference k-mer at its implied position, as a 2k-bit compare of the
+    //      read's window with the reference's.  Equal k-mers have equal filter positions, hence equal table slots: the slot is
+    //      settled with EXACTLY what a probe would have returned.  Unequal: the slot stays open -- nothing is assumed;
+    //  (4) the early decision over everything settled, the open slots counting as "could all be this gene's": decided reads
+    //      never probe their open slots (typically the k-mers around a sequencing error);
+    //  (5) otherwise the open slots are probed as ever and the final vote runs.
+    // A read whose sample matches nothing, or whose anchors do not hold (fewer than 4 slots confirmed: a chance match), takes the
+    // usual path below.  Results are the reference's for every read (tests: test_anchored_extension_*, the fuzzer, the scale tests).
+    auto anchored = [&]() -> bool {
+      KernargParams H = kernarg_params();
+      const uint32_t ref_total = H->ref_total;
+      if (!ref_total) return false;
+      // (1)
+      const uint32_t st1 = nk1 > 8u ? nk1 >> 3 : 1u, st2 = nk2 > 8u ? nk2 >> 3 : 1u;
+      const bool sm2 = ((uint32_t)lane & 8u) != 0u;
+      const uint32_t in_mate = ((uint32_t)lane & 7u) * (sm2 ? st2 : st1);
+      const bool s_exists = ((uint32_t)lane < 16u) & (in_mate < (sm2 ? nk2 : nk1));
+      const uint32_t ss = s_exists ? (sm2 ? P2 + in_mate : in_mate) : 0u;
+      uint64_t s_fwd, s_rc;
+      {
+        const uint32_t q = rcap - k - ss;
+        const uint32_t *f = fw + (ss >> 4);
+        const uint32_t *r = rv + (q >> 4);
+        const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+        const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+        const uint32_t af = (ss & 15u) << 1, ar = (q & 15u) << 1;
+        const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, af) << 32) | __builtin_amdgcn_alignbit(d1, d0, af);
+        const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, ar) << 32) | __builtin_amdgcn_alignbit(e1, e0, ar);
+        s_fwd = y & kmer_mask;
+        s_rc = ~x & kmer_mask;
+      }
+      bool s_ok = s_exists && slot_valid(ss);
+      const bool s_isrc = !(s_fwd < s_rc);
+      const uint64_t s_hash = xxh64_u64(s_isrc ? s_rc : s_fwd);
+      const uint64_t s_pos = POW2 ? (s_hash & P.bf_mask) : bf_pos_np(s_hash, P);
+      if (SUM) {
+        const uint32_t sw = s_ok ? P.sum32[(s_pos >> P.sum_shift) >> 5] : 0u;
+        s_ok = (sw >> ((uint32_t)(s_pos >> P.sum_shift) & 31u)) & 1u;
+      }
+      if (!__ballot(s_ok)) return false;
+      const uint32_t sb = s_ok ? ((uint32_t)s_pos & bmask) : spare;
+      uint4 sbk;
+      if (P.tab_nt) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + sb);
+        sbk = make_uint4(v.x, v.y, v.z, v.w);
+      } else {
+        sbk = tab16[sb];
+      }
+      const uint32_t s_want = want_for(s_pos);
+      const bool sm0 = sbk.y == s_want, sm1 = sbk.w == s_want;       // (home bucket only: a displaced key gives no anchor)
+      const uint64_t SH = __ballot(s_ok & (sm0 | sm1));
+      if (!SH) return false;
+      // (2)
+      const uint32_t s_slot = 2u * sb + (sm0 ? 0u : 1u);
+      uint32_t ax[2] = {0u, 0u}, as0[2] = {0u, 0u};
+      bool aopp[2] = {false, false}, ahave[2] = {false, false};
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(SH >> (8 * m)) & 0xFFu);
+        if (mask) {
+          const int ln = __builtin_amdgcn_readfirstlane(__builtin_ctz(mask) + 8 * m);
+          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)s_slot, ln);
+          const uint32_t a = H->anchor[slot];
+          ahave[m] = a != 0xFFFFFFFFu;
+          ax[m] = a & 0x7FFFFFFFu;
+          aopp[m] = ((a >> 31) != 0u) != (__builtin_amdgcn_readlane((int)(s_isrc ? 1u : 0u), ln) != 0);
+          as0[m] = (uint32_t)__builtin_amdgcn_readlane((int)ss, ln);
+        }
+      }
+      if (!(ahave[0] | ahave[1])) return false;
+      // (3)
+      uint32_t known = 0u, n_match = 0u, ub = 0u;
+      uint64_t Uprev = 0ull;
+      const uint32_t *refpay = H->refpay;
+      const uint32_t *ref2 = H->ref2;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t pp = (uint32_t)lane + 64u * j;
+        const bool in2 = (pp - P2) < nk2;
+        const bool okv = slot_valid(pp);
+        const bool have = in2 ? ahave[1] : ahave[0];
+        const bool opp = in2 ? aopp[1] : aopp[0];
+        const uint32_t x0 = in2 ? ax[1] : ax[0];
+        const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
+        const uint32_t xr = opp ? x0 - dd : x0 + dd;
+        const bool inb = okv & have & (xr < ref_total);
+        const uint32_t xs = inb ? xr : 0u;
+        const uint32_t rp = refpay[xs];
+        const uint32_t *rw = ref2 + (xs >> 4);
+        const uint32_t g0 = rw[0], g1 = rw[1], g2 = rw[2];
+        uint64_t x, y;
+        windows(j, x, y);
+        const uint32_t sg = (xs & 15u) << 1;
+        const uint64_t W = ((uint64_t)__builtin_amdgcn_alignbit(g2, g1, sg) << 32) | __builtin_amdgcn_alignbit(g1, g0, sg);
+        const bool eq = opp ? ((y & kmer_mask) == (~W & kmer_mask)) : ((x & kmer_mask) == (W & kmer_mask));
+        const bool mm = inb & (rp != REFPAY_NONE) & eq;
+        mt[j] = mm;
+        slo[j] = rp;
+        known |= (mm | !okv) ? (1u << j) : 0u;                      // (a slot that does not exist or is no valid k-mer needs no probe either)
+        lane_any |= mm;
+        n_match += (uint32_t)__builtin_popcountll(__ballot(mm));
+        const uint64_t Uc = __ballot(okv & !mm);                    // open slots
+        ub += cover(Uc, Uprev);
+        Uprev = Uc;
+      }
+      ub += cover(0ull, Uprev);
+      if (n_match < 4u) { lane_any = false; return false; }
+      // (4)
+      if (vote(IU{}, std::false_type{}, ub)) return true;
+      // (5)
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+        if (!((known >> j) & 1u)) { mt[j] = false; slo[j] = 0u; }
+      probe_rounds(I0{}, IU{}, known);
+      vote(IU{}, std::true_type{}, 0u);
+      return true;
+    };
+    if constexpr (E < 0) {
+      return anchored();
+    } else {
+    using IE = std::integral_constant<int, E>;
     // JA: the stop at which the early decision is tried (one round behind the usual first stop), and where the table modes
     // try the cut a second time
     constexpr int JA = JA_ROUNDS;
@@ -722,33 +892,39 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if constexpr (JA >= U) {
       // nothing to decide early (two rounds): the cut's first stop at most
       if constexpr (E < U) {
-        probe_rounds(I0{}, IE{});
-        if (ruled_out(IE{}, cutUb, false)) return;
-        probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, IU{});
+        probe_rounds(I0{}, IE{}, 0u);
+        if (ruled_out(IE{}, cutUb, false)) return true;
+        probe_rounds(std::integral_constant<int, (E < U ? E : 0)>{}, IU{}, 0u);
       } else {
-        if (!probe_rounds(I0{}, IU{})) return;
+        if (!probe_rounds(I0{}, IU{}, 0u)) return true;
       }
     } else {
       if constexpr (E < JA) {
-        probe_rounds(I0{}, IE{});
-        if (ruled_out(IE{}, cutUb, false)) return;
-        probe_rounds(std::integral_constant<int, (E < JA ? E : 0)>{}, IA{});
-        if (ruled_out(IA{}, ubJA, true)) return;
+        probe_rounds(I0{}, IE{}, 0u);
+        if (ruled_out(IE{}, cutUb, false)) return true;
+        probe_rounds(std::integral_constant<int, (E < JA ? E : 0)>{}, IA{}, 0u);
+        if (ruled_out(IA{}, ubJA, true)) return true;
       } else {
         // (E == JA: the cut's first stop.  E == U: no stop was planned -- c is small, or the index sits behind the L2 summary,
         //  where a stop of its own cost more than it saved -- but this one exists anyway, so the cut is tried at it)
-        probe_rounds(I0{}, IA{});
-        if (ruled_out(IA{}, ubJA, true)) return;
+        probe_rounds(I0{}, IA{}, 0u);
+        if (ruled_out(IA{}, ubJA, true)) return true;
       }
-      if (vote(IA{}, ubJA)) return;
-      probe_rounds(std::integral_constant<int, (JA < U ? JA : 0)>{}, IU{});
+      if (vote(IA{}, std::false_type{}, ubJA)) return true;
+      probe_rounds(std::integral_constant<int, (JA < U ? JA : 0)>{}, IU{}, 0u);
     }
-    vote(IU{}, 0u);
+    vote(IU{}, std::true_type{}, 0u);
+    return true;
+    }
     };   // classify_staged
-    // the first-round counts this specialisation is compiled for (CutPlan<U>): cutE is one of them, or U
-    if (CUT && cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E0 : U)>{});
-    else if (CUT && CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E1 : U)>{});
-    else classify_staged(std::integral_constant<int, U>{});
+    bool settled = false;
+    if constexpr (ANCH) settled = classify_staged(std::integral_constant<int, -1>{});
+    if (!settled) {
+      // the first-round counts this specialisation is compiled for (CutPlan<U>): cutE is one of them, or U
+      if (CUT && cutE == (uint32_t)CutPlan<U>::E0) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E0 : U)>{});
+      else if (CUT && CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E1 : U)>{});
+      else classify_staged(std::integral_constant<int, U>{});
+    }
     }   // !skip
     if (!have_nxt) break;
     retire_loads(w_nxt);

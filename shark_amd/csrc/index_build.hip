@@ -206,6 +206,81 @@ __global__ __launch_bounds__(256) void table_build_kernel(const uint64_t *__rest
   }
 }
 
+// ---- the reference as the table kernels' second way to a k-mer's list (anchored extension, classify_uni.hpp) ----
+// 2-bit codes of the concatenated records, 16 bases per dword, first base in the low bits (one thread per dword)
+__global__ __launch_bounds__(256) void ref_pack2_kernel(const uint8_t *__restrict__ bytes, uint64_t total, uint32_t *__restrict__ ref2, uint64_t n_dwords)
+{
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_dwords) return;
+  uint32_t v = 0;
+  const uint64_t b = w << 4;
+  for (uint32_t j = 0; j < 16; ++j) {
+    const uint64_t i = b + j;
+    const uint32_t c = i < total ? base_code(bytes[i]) : 0u;
+    v |= (c & 3u) << (2 * j);
+  }
+  ref2[w] = v;
+}
+
+// one thread per base position x: the k-mer starting there is looked up in the position table exactly as the classify kernels
+// look it up (home bucket, then its probe path); refpay[x] = the slot's low word, and the slot learns x as an occurrence of its
+// key (the smallest x | strand << 31 over the occurrences, so the index is the same whatever order the threads run in)
+__global__ __launch_bounds__(RK_THREADS) void ref_anchor_kernel(const uint8_t *__restrict__ bytes, uint64_t total, const uint64_t *__restrict__ rec_off,
+                                                                uint32_t n_rec, uint32_t k, uint64_t bf_bits, uint64_t bf_mask, int pow2,
+                                                                const uint64_t *__restrict__ tab, uint32_t tab_lg, uint32_t *__restrict__ refpay,
+                                                                uint32_t *__restrict__ anchor, uint32_t *__restrict__ lost)
+{
+  __shared__ uint8_t codes[RK_THREADS + 32];
+  const uint64_t b0 = (uint64_t)blockIdx.x * RK_THREADS;
+  const uint64_t i = b0 + threadIdx.x;
+  if (i < total) codes[threadIdx.x] = (uint8_t)base_code(bytes[i]);
+  if (threadIdx.x < k - 1) {
+    const uint64_t j = b0 + RK_THREADS + threadIdx.x;
+    codes[RK_THREADS + threadIdx.x] = j < total ? (uint8_t)base_code(bytes[j]) : (uint8_t)4;
+  }
+  __syncthreads();
+  if (i >= total) return;
+  uint32_t lo = 0, hi = n_rec;  // invariant: rec_off[lo] <= i < rec_off[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (rec_off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const uint64_t s = i - rec_off[lo];
+  const uint64_t len = rec_off[lo + 1] - rec_off[lo];
+  bool valid = s + k <= len;
+  uint64_t fw = 0;
+  if (valid) {
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+      const uint32_t c = codes[threadIdx.x + j];
+      bad |= c >> 2;
+      fw = (fw << 2) | (c & 3u);
+    }
+    valid = bad == 0;
+  }
+  if (!valid) { refpay[i] = REFPAY_NONE; return; }
+  const uint64_t rc = revcomp_left_aligned(fw << (64 - 2 * k), k);
+  const bool stored_rc = !(fw < rc);                  // canonical = fw < rc ? fw : rc (KmerBuilder.hpp:49)
+  const uint64_t h = xxh64_u64(stored_rc ? rc : fw);
+  const uint64_t pos = pow2 ? (h & bf_mask) : (h % bf_bits);
+  const uint64_t bmask = (1ull << tab_lg) - 1ull;
+  const uint32_t want = ((uint32_t)(pos >> tab_lg) << 8) | 0x80u;
+  uint64_t bkt = pos & bmask;
+  for (uint32_t d = 0; d < 64; ++d) {
+    for (uint32_t sidx = 0; sidx < 2; ++sidx) {
+      const uint64_t e = tab[2 * bkt + sidx];
+      if ((uint32_t)(e >> 32) == (want | d)) {
+        refpay[i] = (uint32_t)e & ~TAB_OVERFLOW;
+        atomicMin(&anchor[2 * bkt + sidx], (uint32_t)i | (stored_rc ? 0x80000000u : 0u));
+        return;
+      }
+    }
+    bkt = (bkt + 1) & bmask;
+  }
+  refpay[i] = REFPAY_NONE;   // (cannot happen: every set bit is a key of the table)
+  atomicAdd(lost, 1u);
+}
+
 // LDS-resident exact table of a tiny index (lds_table.hpp): the keys are read back from the position table just built.
 // false = no displacement fits some group (the caller keeps the LDS-summary chain).
 static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, std::vector<uint32_t> &img, uint32_t *mul)
@@ -460,6 +535,34 @@ int build_index(Ctx *ctx)
           }
         }
         table_bytes = slots * sizeof(uint64_t);
+        // the reference itself, for the anchored extension of the table kernels (SHK_NO_ANCHOR=1: not built; the tests run both)
+        ix.ref_total = 0;
+        if (!wrap && total > 0 && total < (1ull << 31) && !getenv("SHK_NO_ANCHOR")) {
+          const uint64_t n_dw = (total + 15) / 16;
+          uint32_t *d_lost = nullptr;
+          BI_HIP(hipMalloc((void **)&ix.ref2, (n_dw + 4) * sizeof(uint32_t)));
+          BI_HIP(hipMemsetAsync(ix.ref2 + n_dw, 0, 4 * sizeof(uint32_t), st));
+          BI_HIP(hipMalloc((void **)&ix.refpay, (total + 1) * sizeof(uint32_t)));
+          BI_HIP(hipMalloc((void **)&ix.anchor, (slots + 2) * sizeof(uint32_t)));
+          BI_HIP(hipMemsetAsync(ix.anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
+          BI_HIP(hipMalloc((void **)&d_lost, sizeof(uint32_t)));
+          BI_HIP(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), st));
+          hipLaunchKernelGGL(ref_pack2_kernel, dim3(grid_for(n_dw, 256)), dim3(256), 0, st, d_bytes, total, ix.ref2, n_dw);
+          BI_HIP(hipGetLastError());
+          hipLaunchKernelGGL(ref_anchor_kernel, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st, d_bytes, total, d_rec_off, n_rec, k, ix.bf_bits,
+                             ix.bf_bits - 1, ix.pow2 ? 1 : 0, (const uint64_t *)ix.tab, lg, ix.refpay, ix.anchor, d_lost);
+          BI_HIP(hipGetLastError());
+          uint32_t h_lost = 0;
+          BI_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+          BI_HIP(hipStreamSynchronize(st));
+          (void)hipFree(d_lost);
+          if (h_lost == 0) {
+            ix.ref_total = (uint32_t)total;
+          } else {   // (a key the table does not hold: leave the extension out rather than trust it)
+            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.anchor);
+            ix.ref2 = ix.refpay = ix.anchor = nullptr;
+          }
+        }
       } else {
         (void)hipFree(ix.tab);   // displacement overflow: keep the bit-vector path
         ix.tab = nullptr;

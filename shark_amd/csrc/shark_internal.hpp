@@ -72,7 +72,17 @@ struct DeviceIndex {
   uint64_t n_set = 0;
   uint64_t tot_idx = 0;
   bool wrap = false;         // more than 65 536 genes: lists sorted by 16-bit id WITH duplicates (index_build.hip), WRAP kernels
+  // ---- the reference itself, for the anchored extension of the table kernels (classify_uni.hpp) ----
+  //   ref2   : all records back to back as 2-bit codes, base p in bits [2 (p & 15), +2) of dword p >> 4 (LSB first, invalid
+  //            characters as 0), padded by four dwords
+  //   refpay : per base position x the low word of the position-table slot of the k-mer STARTING at x (multi | payload; what a
+  //            probe of that k-mer returns), REFPAY_NONE where no valid k-mer starts (record end, invalid character)
+  //   anchor : per table slot (2 per bucket) one occurrence of its key in the reference: x | strand << 31, strand = 1 when the
+  //            k-mer at x is stored reverse-complemented (its canonical form is the reverse complement); 0xFFFFFFFF = unset
+  uint32_t *ref2 = nullptr, *refpay = nullptr, *anchor = nullptr;
+  uint32_t ref_total = 0;    // bases in ref2 / entries in refpay; 0 = not built
 };
+constexpr uint32_t REFPAY_NONE = 0xFFFFFFFFu;   // (multi with payload 2^30-1: not a rank, n_set <= 2^30-1 entries have ranks below that)
 
 // per-wave staging area of a read for a slot capacity S (layout: classify.hip)
 __host__ __device__ constexpr uint32_t stage_cap_bases(uint32_t S) { return S + 96; }                  // S = slot capacity, multiple of 64
@@ -124,6 +134,11 @@ struct ClassifyParams {
   const uint64_t *off2;
   const uint8_t *qual1;
   const uint8_t *qual2;
+  // anchored extension (table modes): DeviceIndex::ref2 / refpay / anchor; ref_total = 0: not available
+  const uint32_t *ref2;
+  const uint32_t *refpay;
+  const uint32_t *anchor;
+  uint32_t ref_total;
   // batches whose reads all have one length per mate (the usual sequencer output) take classify_uni_kernel:
   // uni_flag == nullptr: the host knows (uni_L1, uni_L2); else {1 = uniform and fits, L1, L2} written by uniform_check_kernel
   uint32_t uni_L1, uni_L2;

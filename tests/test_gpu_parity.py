@@ -1133,6 +1133,106 @@ def test_bound_cut_chimeric_reads(oracle, monkeypatch, env, L1, L2, k):
 
 
 # ---------------------------------------------------------------------------
+# the anchored extension of the table kernels (classify_uni.hpp: sample -> anchor -> compare with the reference -> early decision)
+# ---------------------------------------------------------------------------
+def _sequenced_pairs(rng, genes, n, L1, L2, ragged, qual, sub_rate, indel_rate, n_rate):
+    """pairs as a sequencer would give them: a fragment of the concatenated reference (so some cross into the next gene), mate 2
+    from its far end reverse-complemented, substitutions, small insertions / deletions, N, some mates replaced by noise or by
+    another gene, either strand"""
+    cat = np.concatenate(genes)
+    m1s, m2s, q1s, q2s = [], [], [], []
+    for _ in range(n):
+        l1 = int(rng.integers(max(1, (2 * L1) // 3), L1 + 1)) if ragged else L1
+        l2 = (int(rng.integers(max(1, (2 * L2) // 3), L2 + 1)) if ragged else L2) if L2 else 0
+        frag = int(rng.integers(max(l1, l2), max(l1, l2) * 3 + 1))
+        st = int(rng.integers(0, len(cat) - frag - 8))
+        f = cat[st:st + frag + 8].copy()
+
+        def damage(m, want):
+            m = list(m)
+            i = 0
+            out = []
+            while i < len(m):
+                u = rng.random()
+                if u < indel_rate / 2:
+                    i += int(rng.integers(1, 4))                     # deletion
+                    continue
+                if u < indel_rate:
+                    out.extend(synth.random_seq(rng, int(rng.integers(1, 4))))   # insertion
+                out.append(m[i])
+                i += 1
+            m = np.array(out[:want], dtype=np.uint8)
+            if len(m) < want:
+                m = np.concatenate([m, synth.random_seq(rng, want - len(m))])
+            sub = rng.random(want) < sub_rate
+            m[sub] = synth.ACGT[rng.integers(0, 4, size=int(sub.sum()))]
+            m[rng.random(want) < n_rate] = ord("N")
+            return m
+        a = damage(f[:l1 + 6], l1)
+        b = damage(synth.revcomp(f[:frag])[:l2 + 6], l2) if L2 else None
+        if rng.random() < 0.5 and L2:                                  # the other strand of the fragment
+            a, b = b[:l1] if len(b) >= l1 else np.concatenate([b, synth.random_seq(rng, l1 - len(b))]), \
+                   a[:l2] if len(a) >= l2 else np.concatenate([a, synth.random_seq(rng, l2 - len(a))])
+        u = rng.random()
+        if u < 0.08:
+            a = synth.random_seq(rng, l1)                              # mate 1 is noise
+        elif u < 0.16 and L2:
+            b = synth.random_seq(rng, l2)
+        elif u < 0.22 and L2:
+            g = genes[int(rng.integers(0, len(genes)))]
+            if len(g) > l2:
+                st2 = int(rng.integers(0, len(g) - l2))
+                b = g[st2:st2 + l2].copy()                            # mate 2 from another gene
+        m1s.append(a)
+        if L2:
+            m2s.append(b)
+        if qual:
+            for lst, m in zip((q1s, q2s), (a, b) if L2 else (a,)):
+                q = np.where(rng.random(len(m)) < 0.95, rng.integers(25, 42, size=len(m)), rng.integers(2, 20, size=len(m)))
+                lst.append((q + 33).astype(np.uint8))
+    return synth.batch_from_lists(m1s, m2s if L2 else None, q1s if qual else None, q2s if (qual and L2) else None)
+
+
+@pytest.mark.parametrize("env", [{"SHK_NO_LDS_SUMMARY": "1"}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"},
+                                 {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1", "BF": str(3 << 24)}])
+@pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (100, 100, 16), (150, 0, 20), (76, 76, 11), (250, 250, 21), (300, 300, 17)])
+def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
+    """table modes with the reference arrays (anchor / refpay / ref2): reads that match the reference with substitutions, indels,
+    N, on either strand, across gene boundaries, from shared gene halves (multi-gene lists, ties), with one mate off-target or
+    from another gene; even k (palindromic k-mers); genes with N and genes shorter than k in the reference.  Every result equals
+    the oracle's with the extension and without it (SHK_NO_ANCHOR=1 at index build time)."""
+    bf_bits = 1 << 26
+    for name, v in env.items():
+        if name == "BF":
+            bf_bits = int(v)
+        else:
+            monkeypatch.setenv(name, v)
+    rng = np.random.default_rng(4100 + L1 + 3 * L2 + k)
+    genes = synth.make_genes(rng, 24, 900, 3500, share_every=3)
+    genes[5][100:103] = ord("N")                                      # invalid characters inside a gene
+    genes[7] = synth.random_seq(rng, max(1, k - 3))                   # a record shorter than k
+    pal = np.frombuffer(b"ACGT" * 16, dtype=np.uint8)                 # its own reverse complement at every even k
+    genes[9][200:200 + len(pal)] = pal
+    genes[11][50:50 + len(pal)] = pal
+    for anchor in (True, False):
+        if anchor:
+            monkeypatch.delenv("SHK_NO_ANCHOR", raising=False)
+        else:
+            monkeypatch.setenv("SHK_NO_ANCHOR", "1")
+        for c, single, q in ((0.6, False, 0), (0.3, True, 0), (0.9, False, 20)):
+            o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits, c=c, min_quality=q, single=single)
+            assert h.probe_mode() in ("table", "summary+table", "table-mod"), h.probe_mode()
+            for ragged in (False, True):
+                for sub_rate, indel_rate in ((0.0, 0.0), (0.01, 0.0), (0.03, 0.004)):
+                    batch = _sequenced_pairs(rng, genes, 400, L1, L2, ragged, q > 0, sub_rate, indel_rate, 0.002)
+                    goff, _ = _compare_classify(o, h, batch)
+                    assert goff[-1] > 0 or c > 0.6
+            if q == 0:
+                _probe_every_kmer(o, h, genes, k, stride=7)
+            h.close()
+
+
+# ---------------------------------------------------------------------------
 # tiny indices: the exact table held in LDS (classify_uni_kernel LSL = 21, shark_internal.hpp LTAB_*)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("k,bf_bits,n_genes,gene_len,share", [
