@@ -98,6 +98,10 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_NO_ANCHOR
 #define SHK_NO_ANCHOR 0
 #endif
+// (-DSHK_ANCH_CUT=n: timing-only ablation, results are wrong: the anchored path ends behind its step n)
+#ifndef SHK_ANCH_CUT
+#define SHK_ANCH_CUT 0
+#endif
 // MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
 // probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
 // only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
@@ -804,6 +808,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       const bool sm0 = sbk.y == s_want, sm1 = sbk.w == s_want;       // (home bucket only: a displaced key gives no anchor)
       const uint64_t SH = __ballot(s_ok & (sm0 | sm1));
       if (!SH) return false;
+#if SHK_ANCH_CUT == 1
+      return true;
+#endif
       // (2)
       const uint32_t s_slot = 2u * sb + (sm0 ? 0u : 1u);
       uint32_t ax[2] = {0u, 0u}, as0[2] = {0u, 0u};
@@ -822,6 +829,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         }
       }
       if (!(ahave[0] | ahave[1])) return false;
+#if SHK_ANCH_CUT == 2
+      return ax[0] + ax[1] != 12345u;
+#endif
       // (3)
       uint32_t known = 0u, n_match = 0u, ub = 0u;
       uint64_t Uprev = 0ull;
@@ -859,9 +869,23 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
       ub += cover(0ull, Uprev);
       if (n_match < 4u) { lane_any = false; return false; }
+#if SHK_ANCH_CUT == 3
+      return n_match != 12345u;
+#endif
       // (4)
-      if (vote(IU{}, std::false_type{}, ub)) return true;
+      if (vote(IU{}, std::false_type{}, ub)) {
+#ifdef SHK_ANCH_STATS
+        if (lane == 0) atomicAdd(&H->out->counters[CTR_UNUSED3], 1u);
+#endif
+        return true;
+      }
+#if SHK_ANCH_CUT == 4
+      return true;
+#endif
       // (5)
+#ifdef SHK_ANCH_STATS
+      if (lane == 0) atomicAdd(&H->out->counters[CTR_UNUSED5], 1u);
+#endif
 #pragma unroll
       for (int j = 0; j < U; ++j)
         if (!((known >> j) & 1u)) { mt[j] = false; slo[j] = 0u; }

@@ -281,6 +281,54 @@ __global__ __launch_bounds__(RK_THREADS) void ref_anchor_kernel(const uint8_t *_
   atomicAdd(lost, 1u);
 }
 
+// Multi-gene lists in REFERENCE order.  A probe that matches a multi-gene list gets its rank r and then reads ent[r] and ids[...] at
+// addresses that have nothing to do with each other from one k-mer of a read to the next.  For the slots the anchored extension
+// settles, the same lists are kept a second time, laid out along the reference: entry n_set + 1 + x of `ent` belongs to the k-mer at
+// reference position x (its `start` indexes the copy of its list behind ids[tot_idx)), and refpay[x] carries that entry's index as
+// its payload -- the vote's loads of consecutive slots then fall on consecutive addresses.
+// pass 1: list length per position (0 unless the k-mer at x has a multi-gene list)
+__global__ __launch_bounds__(256) void ref_multi_len_kernel(const uint32_t *__restrict__ refpay, uint64_t total, const ListEntry *__restrict__ ent,
+                                                            uint32_t *__restrict__ lens)
+{
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x > total) return;
+  uint32_t len = 0;
+  if (x < total) {
+    const uint32_t lp = refpay[x];
+    if (lp != REFPAY_NONE && (lp >> 31)) {
+      const uint32_t r = lp & TAB_PAYLOAD;
+      const ListEntry e = ent[r];
+      len = e.len != 0xFFFFu ? (uint32_t)e.len : ent[r + 1].start - e.start;
+    }
+  }
+  lens[x] = len;
+}
+
+// pass 2: the per-position entries and the copies of the lists; refpay[x] of a multi-gene k-mer now names its per-position entry
+__global__ __launch_bounds__(256) void ref_multi_write_kernel(uint32_t *__restrict__ refpay, uint64_t total, ListEntry *__restrict__ ent, uint64_t n_set,
+                                                              uint16_t *__restrict__ ids, uint32_t tot_idx, const uint32_t *__restrict__ offs)
+{
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x > total) return;
+  ListEntry out;
+  out.start = tot_idx + offs[x];
+  out.len = 0;
+  out.gene0 = 0;
+  if (x < total) {
+    const uint32_t lp = refpay[x];
+    if (lp != REFPAY_NONE && (lp >> 31)) {
+      const uint32_t r = lp & TAB_PAYLOAD;
+      const ListEntry e = ent[r];
+      const uint32_t len = e.len != 0xFFFFu ? (uint32_t)e.len : ent[r + 1].start - e.start;
+      for (uint32_t i = 0; i < len; ++i) ids[out.start + i] = ids[e.start + i];
+      out.len = (uint16_t)(len > 0xFFFFu ? 0xFFFFu : len);
+      out.gene0 = e.gene0;
+      refpay[x] = 0x80000000u | (uint32_t)(n_set + 1 + x);
+    }
+  }
+  ent[n_set + 1 + x] = out;
+}
+
 // LDS-resident exact table of a tiny index (lds_table.hpp): the keys are read back from the position table just built.
 // false = no displacement fits some group (the caller keeps the LDS-summary chain).
 static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, std::vector<uint32_t> &img, uint32_t *mul)
@@ -556,6 +604,39 @@ int build_index(Ctx *ctx)
           BI_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
           BI_HIP(hipStreamSynchronize(st));
           (void)hipFree(d_lost);
+          // multi-gene lists along the reference (see ref_multi_len_kernel); left out -- the lists then stay where the ranks point --
+          // when the copies would not fit the 32-bit list offsets or the 30-bit payload
+          bool ref_lists = false;
+          if (h_lost == 0 && n_set + 1 + total + 1 <= TAB_PAYLOAD) {
+            uint32_t *d_lens = nullptr;
+            uint64_t *d_stmp = nullptr;
+            BI_HIP(hipMalloc((void **)&d_lens, (total + 1) * sizeof(uint32_t)));
+            BI_HIP(hipMalloc((void **)&d_stmp, scan_temp_words(total + 1) * sizeof(uint64_t)));
+            hipLaunchKernelGGL(ref_multi_len_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, (const uint32_t *)ix.refpay, total, (const ListEntry *)ix.ent, d_lens);
+            BI_HIP(hipGetLastError());
+            const uint64_t *d_R = exclusive_scan_u32(d_lens, d_lens, total + 1, d_stmp, st);
+            uint64_t R = 0;
+            BI_HIP(hipMemcpyAsync(&R, d_R, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            BI_HIP(hipStreamSynchronize(st));
+            if (tot_idx + R + 8 < (1ull << 32) && R <= 16 * total) {
+              ListEntry *ent_all = nullptr;
+              uint16_t *ids_all = nullptr;
+              BI_HIP(hipMalloc((void **)&ent_all, (n_set + 1 + total + 1) * sizeof(ListEntry)));
+              BI_HIP(hipMalloc((void **)&ids_all, (tot_idx + R + 8) * sizeof(uint16_t)));
+              BI_HIP(hipMemcpyAsync(ent_all, ix.ent, (n_set + 1) * sizeof(ListEntry), hipMemcpyDeviceToDevice, st));
+              BI_HIP(hipMemcpyAsync(ids_all, ix.ids, (tot_idx + 8) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+              BI_HIP(hipStreamSynchronize(st));
+              (void)hipFree(ix.ent); (void)hipFree(ix.ids);
+              ix.ent = ent_all; ix.ids = ids_all;
+              hipLaunchKernelGGL(ref_multi_write_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, ix.refpay, total, ix.ent, n_set, ix.ids, (uint32_t)tot_idx,
+                                 (const uint32_t *)d_lens);
+              BI_HIP(hipGetLastError());
+              BI_HIP(hipStreamSynchronize(st));
+              ref_lists = true;
+            }
+            (void)hipFree(d_lens); (void)hipFree(d_stmp);
+          }
+          (void)ref_lists;
           if (h_lost == 0) {
             ix.ref_total = (uint32_t)total;
           } else {   // (a key the table does not hold: leave the extension out rather than trust it)

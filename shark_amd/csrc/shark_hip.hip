@@ -412,6 +412,10 @@ static int classify_resident(Ctx *ctx, const shk_batch *b, uint32_t max_read_len
   ctx->last.last_n_reads = n;
   ctx->last.last_n_long = s.h_counters[CTR_LONG];
   ctx->last.last_n_tie = s.h_counters[CTR_TIE];
+#ifdef SHK_ANCH_STATS   // (experiments: reads the anchored extension settled early / settled after probing its open slots)
+  ctx->last.last_n_long = s.h_counters[CTR_UNUSED3];
+  ctx->last.last_n_tie = s.h_counters[CTR_UNUSED5];
+#endif
   ctx->last.last_n_assoc = n_assoc;
   res->n = n;
   res->gene_off = s.d_gene_off;

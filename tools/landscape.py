@@ -44,7 +44,8 @@ for ng in [int(x) for x in a.genes.split(",")]:
             gids = np.empty(max(int(r.n_assoc), 1), np.uint16); hip_memcpy_dtoh(gids, r.gene_ids, int(r.n_assoc) * 2)
             res[anchor] = (goff, gids[:int(r.n_assoc)])
             print(json.dumps({"genes": ng, "bf_log2": bf_log2, "k": a.k, "q": a.q, "on_target": ot, "pairs": a.pairs, "anchored": anchor, "mode": h.probe_mode(),
-                              "n_set_bits": info["n_set_bits"], "kernel_ms": round(tm["total_ms"] / tm["n_launches"], 3), "n_assoc": int(r.n_assoc)}), flush=True)
+                              "n_set_bits": info["n_set_bits"], "kernel_ms": round(tm["total_ms"] / tm["n_launches"], 3), "n_assoc": int(r.n_assoc),
+                              "last_n_long": tm["last_n_long"], "last_n_tie": tm["last_n_tie"]}), flush=True)
             h.close()
         if a.ab:
             same = np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
