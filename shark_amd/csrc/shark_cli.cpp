@@ -193,6 +193,25 @@ class Progress {
 };
 const Progress pelapsed;
 
+// -v: a millisecond timeline of the run's phases on stderr (stderr is not part of the contract)
+class Timeline {
+ public:
+  void on() { on_ = true; }
+  void operator()(const char *what)
+  {
+    if (!on_) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+    std::lock_guard<std::mutex> l(m_);
+    std::cerr << "[shark/ms] " << what << " " << ms << std::endl;
+  }
+
+ private:
+  std::chrono::steady_clock::time_point t0_ = std::chrono::steady_clock::now();
+  bool on_ = false;
+  std::mutex m_;
+};
+Timeline timeline;
+
 // ---- one batch of reads, structure of arrays ---------------------------------
 // allocator that leaves chars uninitialised on resize (the fillers overwrite every byte); large blocks on huge pages
 template <typename T>
@@ -617,6 +636,8 @@ class BoundedQueue {
 int main(int argc, char *argv[])
 {
   const Options opt = parse_arguments(argc, argv);
+  if (opt.verbose) timeline.on();
+  timeline("arguments parsed");
 
   if (opt.verbose) {
     std::cerr << "shark (MI355X): reference " << opt.fasta_path << ", sample " << opt.sample1_path;
@@ -650,6 +671,7 @@ int main(int argc, char *argv[])
     }
   }
 
+  timeline("contexts created");
   // ---- 1+2. reference: legend in file order (FastaSplitter.hpp:48) + index ----
   std::vector<std::string> legend_ID;
   {
@@ -672,6 +694,7 @@ int main(int argc, char *argv[])
     }
   }
   pelapsed("Transcript file processed");
+  timeline("reference read");
   {
     std::vector<std::thread> th;
     std::vector<int> rcs((size_t)n_gpus, 0);
@@ -683,6 +706,7 @@ int main(int argc, char *argv[])
         return EXIT_FAILURE;
       }
   }
+  timeline("index built");
   pelapsed("First switch performed");
   shk_index_info info{};
   shk_index_info_get(ctxs[0], &info);
@@ -764,6 +788,7 @@ int main(int argc, char *argv[])
         }
       }
     }
+    timeline("sample partitioned");
     const uint64_t n_par_batches = (n_par_records + opt.batch - 1) / opt.batch;
     std::atomic<uint64_t> next_batch{0};
     std::atomic<uint64_t> irregular_at{UINT64_MAX};     // first batch a reader found not to be strict four-line FASTQ
@@ -824,6 +849,7 @@ int main(int argc, char *argv[])
     std::unique_ptr<BatchSplitter> fs;
     std::thread splitter([&] {
       for (auto &t : readers) t.join();
+      timeline("parallel readers done");
       const uint64_t stop = std::min<uint64_t>(irregular_at.load(), n_par_batches);   // batches [0, stop) came from the readers
       fs.reset(new BatchSplitter(opt, io_threads, pool));
       bool serial_ok = fs->ok();
@@ -840,6 +866,7 @@ int main(int argc, char *argv[])
         }
       }
       for (auto &q : todo) q->close();
+      timeline("serial reader done");
       std::lock_guard<std::mutex> l(done_m);
       split_finished = true;
       done_cv.notify_all();
@@ -906,6 +933,7 @@ int main(int argc, char *argv[])
       }
       done_cv.notify_all();
     }
+    timeline("drain done");
     splitter.join();
     for (auto &t : analyzers) t.join();
     fflush(stdout);
@@ -927,6 +955,7 @@ int main(int argc, char *argv[])
       return EXIT_FAILURE;
     }
   }
+  timeline("outputs closed");
   pelapsed("Sample completed");
 
   // per-gene assigned-read counts: the one exchange step of the sharded run (RCCL all-reduce over xGMI)
@@ -954,6 +983,7 @@ int main(int argc, char *argv[])
   }
 
   for (auto *ctx : ctxs) shk_destroy(ctx);
+  timeline("contexts destroyed");
   pelapsed("Association done");
   return 0;
 }

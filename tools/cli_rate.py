@@ -64,5 +64,5 @@ for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
     dt = time.time() - t0
     print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
                       "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "headers": "var" if VAR else "fixed",
-                      "stderr_tail": r.stderr.decode()[-500:]}), flush=True)
+                      "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
 subprocess.run(["rm", "-rf", td])
