@@ -96,7 +96,13 @@ class InflateAhead {
       gz_ = gzopen(path_.c_str(), "r");
       if (!gz_) return false;
       gzbuffer(gz_, 1 << 18);
-      if (off && gzseek(gz_, (z_off_t)off, SEEK_SET) < 0) return false;
+      if (off) {
+        // (zlib seeks a plain file with lseek only once it has LOOKED at it -- right after gzopen it would skip by reading
+        //  everything in front of `off`, a quarter of a second per 5 GB; one byte read settles that)
+        char c;
+        (void)gzread(gz_, &c, 1);
+        if (gzseek(gz_, (z_off_t)off, SEEK_SET) < 0) return false;
+      }
     }
     for (auto &b : buf_) if (b.size() < CHUNK + (1u << 16)) b.resize(CHUNK + (1u << 16));
     th_ = std::thread([this] { produce(); });

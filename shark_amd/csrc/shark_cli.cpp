@@ -35,6 +35,7 @@
 
 #include "../../include/shark_hip.h"
 #include "fastq_block_reader.hpp"
+#include "fastq_lean_reader.hpp"
 #include "fastq_partition.hpp"
 #include "fastx_reader.hpp"
 
@@ -273,6 +274,10 @@ struct ReadBatch {
   // sequence short, FastqSplitter.hpp:55,:63; a FASTA-style record has no qualities): the device reads qualities at the
   // sequence offsets, the output (ReadOutput.hpp:44-47) prints the quality string as it was
   std::map<size_t, std::string> qual_as_read1, qual_as_read2;
+  // lean batches (the parallel readers', fastq_lean_reader.hpp): only what the GPU reads was copied; names and qualities of the
+  // associated reads are fetched from the files again by the output stage
+  bool lean = false;
+  shk::BatchFilePart part1, part2;
   // result
   std::vector<uint32_t> gene_off;
   std::vector<uint16_t> gene_ids;
@@ -281,6 +286,7 @@ struct ReadBatch {
   {
     id1.reset(); id2.reset(); seq1.reset(); qual1.reset(); seq2.reset(); qual2.reset();
     qual_as_read1.clear(); qual_as_read2.clear();
+    lean = false;
     gene_off.clear(); gene_ids.clear();
     rc = 0;
   }
@@ -471,7 +477,7 @@ class ReadAnalyzer {
     in.n = b->seq1.size();
     in.seq1 = b->seq1.bytes.data();
     in.off1 = b->seq1.off.data();
-    if (b->seq2.size() == in.n && b->id2.size() == in.n && in.n) {
+    if (b->seq2.size() == in.n && (b->lean || b->id2.size() == in.n) && in.n) {
       in.seq2 = b->seq2.bytes.data();
       in.off2 = b->seq2.off.data();
     }
@@ -518,6 +524,7 @@ class ReadOutput {
  public:
   ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend, unsigned threads)
       : out1_(out1), out2_(out2), legend_(legend), threads_(threads) {}
+  bool failed() const { return failed_.load(); }
   void operator()(const ReadBatch &b)
   {
     const size_t n = b.seq1.size();
@@ -532,24 +539,54 @@ class ReadOutput {
     std::vector<std::string> ssv(segs.size()), fq1(segs.size()), fq2(segs.size()), last_id(segs.size());
     std::vector<char> any(segs.size(), 0);
     shk::parallel_for(threads_, segs.size(), [&](size_t sb, size_t se, unsigned) {
+      shk::RecordFetcher f1, f2;
       for (size_t si = sb; si < se; ++si) {
         std::string previd;
         bool have = false;
         const bool carries = (b.first_read + segs[si].first) % 50000 != 0;   // continues the previous batch's chunk
         if (carries) { previd = carry_; have = true; }
+        if (b.lean) {
+          // many associated reads in this segment: its byte range in one read; few: one read per record
+          const size_t n_assoc = b.gene_off[segs[si].second] - b.gene_off[segs[si].first];
+          const bool dense = n_assoc * 10 > segs[si].second - segs[si].first;
+          if (dense) {
+            f1.load_dense(b.part1, segs[si].first, segs[si].second);
+            if (out2_) f2.load_dense(b.part2, segs[si].first, segs[si].second);
+          } else {
+            f1.unload();
+            f2.unload();
+          }
+        }
         for (size_t i = segs[si].first; i < segs[si].second; ++i) {
+          if (b.gene_off[i] == b.gene_off[i + 1]) continue;
+          shk::RecordFetcher::View v1{nullptr, 0, nullptr, 0, nullptr}, v2{nullptr, 0, nullptr, 0, nullptr};
+          const char *id;
+          size_t id_len;
+          if (b.lean) {
+            if (!f1.get(b.part1, i, v1) || (out2_ && !f2.get(b.part2, i, v2))) { failed_ = true; continue; }
+            id = v1.id;
+            id_len = v1.id_len;
+          } else {
+            id = b.id1.at(i);
+            id_len = b.id1.len(i);
+          }
           for (uint32_t j = b.gene_off[i]; j < b.gene_off[i + 1]; ++j) {
             const std::string &gene = legend_[b.gene_ids[j]];
-            ssv[si].append(b.id1.at(i), b.id1.len(i));
+            ssv[si].append(id, id_len);
             ssv[si].push_back(' ');
             ssv[si].append(gene);
             ssv[si].push_back('\n');
-            const bool same = previd.size() == b.id1.len(i) && memcmp(previd.data(), b.id1.at(i), previd.size()) == 0;
+            const bool same = previd.size() == id_len && memcmp(previd.data(), id, id_len) == 0;
             if (!same) {
-              if (out1_) record(fq1[si], b.id1, b.seq1, b.qual1, b.qual_as_read1, i);
-              if (out2_) record(fq2[si], b.id2, b.seq2, b.qual2, b.qual_as_read2, i);
+              if (b.lean) {
+                if (out1_) record_view(fq1[si], v1);
+                if (out2_) record_view(fq2[si], v2);
+              } else {
+                if (out1_) record(fq1[si], b.id1, b.seq1, b.qual1, b.qual_as_read1, i);
+                if (out2_) record(fq2[si], b.id2, b.seq2, b.qual2, b.qual_as_read2, i);
+              }
             }
-            previd.assign(b.id1.at(i), b.id1.len(i));
+            previd.assign(id, id_len);
             have = true;
           }
         }
@@ -567,6 +604,16 @@ class ReadOutput {
   }
 
  private:
+  static void record_view(std::string &f, const shk::RecordFetcher::View &v)
+  {
+    f.push_back('@');
+    f.append(v.id, v.id_len);
+    f.push_back('\n');
+    f.append(v.seq, v.seq_len);
+    f.append("\n+\n");
+    f.append(v.qual, v.seq_len);
+    f.push_back('\n');
+  }
   static void record(std::string &f, const Strings &id, const DevStrings &seq, const DevStrings &qual, const std::map<size_t, std::string> &qual_as_read, size_t i)
   {
     f.push_back('@');
@@ -582,6 +629,7 @@ class ReadOutput {
   FILE *out1_, *out2_;
   const std::vector<std::string> &legend_;
   unsigned threads_;
+  std::atomic<bool> failed_{false};   // a record could not be read back from its file (I/O error)
   std::string carry_;   // previd at the end of the previous batch (only used when a batch starts mid-chunk)
 };
 
@@ -658,61 +706,26 @@ int main(int argc, char *argv[])
     fclose(f);
   }
 
-  // ---- contexts: one per GPU, index replicated by deterministic rebuild -------
+  // ---- contexts: one per GPU, index replicated by deterministic rebuild.  Creating the first context initialises the HIP runtime
+  // (a few hundred milliseconds); that happens on a thread of its own while this one reads the reference and the readers
+  // (which need no GPU) already parse the sample -------
   const int n_gpus = opt.gpus;
   std::vector<shk_ctx *> ctxs((size_t)n_gpus, nullptr);
-  for (int g = 0; g < n_gpus; ++g) {
-    shk_params p{};
-    p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single; p.device = g;
-    const int rc = shk_create(&p, &ctxs[(size_t)g]);
-    if (rc != SHK_OK) {
-      std::cerr << "shark: cannot create a context on GPU " << g << ": " << shk_strerror(rc) << std::endl;
-      return EXIT_FAILURE;
+  int ctx_rc = SHK_OK, ctx_bad = -1;
+  std::thread ctx_thread([&] {
+    for (int g = 0; g < n_gpus; ++g) {
+      shk_params p{};
+      p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single; p.device = g;
+      const int rc = shk_create(&p, &ctxs[(size_t)g]);
+      if (rc != SHK_OK) { ctx_rc = rc; ctx_bad = g; return; }
     }
-  }
-
-  timeline("contexts created");
-  // ---- 1+2. reference: legend in file order (FastaSplitter.hpp:48) + index ----
-  std::vector<std::string> legend_ID;
-  {
-    shk::FastxReader fa(opt.fasta_path);
-    if (!fa.ok()) {
-      std::cerr << "shark: cannot open " << opt.fasta_path << std::endl;
-      return EXIT_FAILURE;
-    }
-    shk::FastxRecord rec;
-    while (fa.read(rec) >= 0) {
-      legend_ID.push_back(rec.name.c_str());
-      const size_t len = strnlen(rec.seq.data(), rec.seq.size());  // C-string semantics (main.cpp:164)
-      for (auto *ctx : ctxs) {
-        const int rc = shk_ref_add(ctx, rec.seq.data(), len);
-        if (rc != SHK_OK) {
-          std::cerr << "shark: " << shk_strerror(rc) << std::endl;
-          return EXIT_FAILURE;
-        }
-      }
-    }
-  }
-  pelapsed("Transcript file processed");
-  timeline("reference read");
-  {
-    std::vector<std::thread> th;
-    std::vector<int> rcs((size_t)n_gpus, 0);
-    for (int g = 0; g < n_gpus; ++g) th.emplace_back([&, g] { rcs[(size_t)g] = shk_ref_finalize(ctxs[(size_t)g]); });
-    for (auto &t : th) t.join();
-    for (int g = 0; g < n_gpus; ++g)
-      if (rcs[(size_t)g] != SHK_OK) {
-        std::cerr << "shark: index build failed on GPU " << g << ": " << shk_strerror(rcs[(size_t)g]) << " " << shk_last_error(ctxs[(size_t)g]) << std::endl;
-        return EXIT_FAILURE;
-      }
-  }
-  timeline("index built");
-  pelapsed("First switch performed");
-  shk_index_info info{};
-  shk_index_info_get(ctxs[0], &info);
-  pelapsed("BF created from transcripts (" + std::to_string(info.nidx) + " genes)");
-  pelapsed("Second switch performed");
-
+    timeline("contexts created");
+  });
+  struct CtxJoin {   // (every early return below has to wait for that thread)
+    std::thread &t;
+    ~CtxJoin() { if (t.joinable()) t.join(); }
+  } ctx_join{ctx_thread};
+  std::vector<std::string> legend_ID;   // gene names in file order (FastaSplitter.hpp:48); filled below, read by the output stage
   // ---- 3. sample ---------------------------------------------------------------
   // Three roles, as in main.cpp:66-77 (split / analyze / output), decoupled by queues:
   //   readers   plain four-line FASTQ: a parallel newline count gives the byte range of every batch of each mate file
@@ -735,7 +748,7 @@ int main(int argc, char *argv[])
 
     // per-GPU input queues; batch i goes to GPU i mod N
     std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<ReadBatch>>>> todo;
-    for (int g = 0; g < n_gpus; ++g) todo.emplace_back(new BoundedQueue<std::unique_ptr<ReadBatch>>(SHK_PIPE_DEPTH + 1));
+    for (int g = 0; g < n_gpus; ++g) todo.emplace_back(new BoundedQueue<std::unique_ptr<ReadBatch>>(1u << 20));   // (the readers' window bounds what is in flight)
     std::mutex done_m;
     std::condition_variable done_cv;
     std::map<uint64_t, std::unique_ptr<ReadBatch>> done;
@@ -795,17 +808,29 @@ int main(int argc, char *argv[])
     const unsigned n_readers = parallel_feed ? (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(io_threads, n_par_batches)) : 0;
     std::vector<double> t_reader(n_readers, 0.0);
     // a reader must not run ahead of the drain without bound: at most `window` batches beyond the one being written
-    const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2);
+    // (generous: the readers start before the GPU is initialised and the index built, and run ahead meanwhile -- about 3 GiB of bases)
+    const uint64_t batch_bytes = std::max<uint64_t>(1, opt.batch * (opt.paired_flag ? 2 : 1) * 160);
+    const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + (3ull << 30) / batch_bytes;
     uint64_t drained = 0;                                // guarded by done_m
     // Batch j may only leave a reader once every batch before it is KNOWN to be strict four-line FASTQ: an irregular batch
     // i < j that keeps the four-line alignment (an empty read, a sequence/quality length mismatch, a lone CR, a NUL) lets
     // batch j validate, yet everything from i on belongs to the serial reader -- which numbers its batches from i again
     // and may cut the records differently.  `validated` = number of leading batches known to be strict (guarded by done_m).
     uint64_t validated = 0;
+    const bool need_qual = static_cast<char>(opt.min_quality) != 0;   // the device reads qualities only with -q (the reference's char, argument_parser.hpp:144)
+    shk::RecordLayout lay1, lay2;                                     // the layout of each file's first record: the readers' fast check
+    if (parallel_feed) {
+      std::vector<char> head(1u << 16);
+      for (int m = 0; m < (opt.paired_flag ? 2 : 1); ++m) {
+        shk::BatchTable &t = m ? tab2 : tab1;
+        const size_t got = (size_t)std::min<uint64_t>(head.size(), t.file_size);
+        if (got && shk::pread_all(t.fd, head.data(), 0, got)) shk::layout_of(head.data(), got, m ? lay2 : lay1);
+      }
+    }
     std::vector<std::thread> readers;
     for (unsigned r = 0; r < n_readers; ++r) {
       readers.emplace_back([&, r] {
-        shk::ParsedBatch p1, p2;
+        shk::LeanScratch sc;
         for (;;) {
           const uint64_t i = next_batch.fetch_add(1);
           if (i >= n_par_batches || i >= irregular_at.load()) break;
@@ -816,21 +841,22 @@ int main(int argc, char *argv[])
           if (i >= irregular_at.load()) break;
           auto t0 = std::chrono::steady_clock::now();
           const size_t want = (size_t)std::min<uint64_t>(opt.batch, n_par_records - i * opt.batch);
-          size_t ok1 = shk::parse_strict_batch(tab1.fd, tab1.off[i], tab1.off[i + 1], want, p1);
+          std::unique_ptr<ReadBatch> b = pool.acquire();
+          b->index = i;
+          b->first_read = i * opt.batch;
+          b->lean = true;
+          size_t ok1 = shk::lean_parse_range(tab1.fd, tab1.off[i], tab1.off[i + 1], want, lay1, need_qual, sc, b->seq1.bytes, b->seq1.off, b->qual1.bytes, b->part1);
           size_t ok2 = want;
-          if (opt.paired_flag) ok2 = shk::parse_strict_batch(tab2.fd, tab2.off[i], tab2.off[i + 1], want, p2);
+          if (opt.paired_flag && ok1 == want)
+            ok2 = shk::lean_parse_range(tab2.fd, tab2.off[i], tab2.off[i + 1], want, lay2, need_qual, sc, b->seq2.bytes, b->seq2.off, b->qual2.bytes, b->part2);
           if (ok1 < want || ok2 < want) {
             // not strict here: this batch and everything behind it belongs to the serial reader
+            pool.release(std::move(b));
             uint64_t cur = irregular_at.load();
             while (i < cur && !irregular_at.compare_exchange_weak(cur, i)) {}
             done_cv.notify_all();
             break;
           }
-          std::unique_ptr<ReadBatch> b = pool.acquire();
-          b->index = i;
-          b->first_read = i * opt.batch;
-          shk::fill_soa(p1, want, b->id1, b->seq1, b->qual1);
-          if (opt.paired_flag) shk::fill_soa(p2, want, b->id2, b->seq2, b->qual2);
           t_reader[r] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           {
             // (batch indices are handed out in increasing order, so the reader of the smallest outstanding one never waits here)
@@ -845,20 +871,94 @@ int main(int argc, char *argv[])
       });
     }
 
+    // ---- 1+2. reference: legend in file order (FastaSplitter.hpp:48) + index -- while the readers above already parse the sample ----
+    auto stop_feed = [&] {
+      // a failure before the analyzers exist: end the readers (they stop at an irregular batch 0) and take their batches back
+      uint64_t cur = irregular_at.load();
+      while (0 < cur && !irregular_at.compare_exchange_weak(cur, 0)) {}
+      for (auto &q : todo) q->close();
+      done_cv.notify_all();
+      std::thread drain_q([&] {
+        for (auto &q : todo) {
+          std::unique_ptr<ReadBatch> b;
+          while (q->pop(b)) {}
+        }
+      });
+      for (auto &t : readers) t.join();
+      drain_q.join();
+    };
+    {
+      shk::FastxReader fa(opt.fasta_path);
+      if (!fa.ok()) {
+        stop_feed();
+        std::cerr << "shark: cannot open " << opt.fasta_path << std::endl;
+        return EXIT_FAILURE;
+      }
+      ctx_thread.join();
+      if (ctx_rc != SHK_OK) {
+        stop_feed();
+        std::cerr << "shark: cannot create a context on GPU " << ctx_bad << ": " << shk_strerror(ctx_rc) << std::endl;
+        return EXIT_FAILURE;
+      }
+      shk::FastxRecord rec;
+      while (fa.read(rec) >= 0) {
+        legend_ID.push_back(rec.name.c_str());
+        const size_t len = strnlen(rec.seq.data(), rec.seq.size());  // C-string semantics (main.cpp:164)
+        for (auto *ctx : ctxs) {
+          const int rc = shk_ref_add(ctx, rec.seq.data(), len);
+          if (rc != SHK_OK) {
+            stop_feed();
+            std::cerr << "shark: " << shk_strerror(rc) << std::endl;
+            return EXIT_FAILURE;
+          }
+        }
+      }
+    }
+    pelapsed("Transcript file processed");
+    timeline("reference read");
+    {
+      std::vector<std::thread> th;
+      std::vector<int> rcs((size_t)n_gpus, 0);
+      for (int g = 0; g < n_gpus; ++g) th.emplace_back([&, g] { rcs[(size_t)g] = shk_ref_finalize(ctxs[(size_t)g]); });
+      for (auto &t : th) t.join();
+      for (int g = 0; g < n_gpus; ++g)
+        if (rcs[(size_t)g] != SHK_OK) {
+          stop_feed();
+          std::cerr << "shark: index build failed on GPU " << g << ": " << shk_strerror(rcs[(size_t)g]) << " " << shk_last_error(ctxs[(size_t)g]) << std::endl;
+          return EXIT_FAILURE;
+        }
+    }
+    timeline("index built");
+    pelapsed("First switch performed");
+    {
+      shk_index_info info{};
+      shk_index_info_get(ctxs[0], &info);
+      pelapsed("BF created from transcripts (" + std::to_string(info.nidx) + " genes)");
+    }
+    pelapsed("Second switch performed");
+
     // ---- the serial feed: everything the parallel readers did not (or could not) deliver ---------
     std::unique_ptr<BatchSplitter> fs;
+    bool serial_needed = false, serial_failed = false;
     std::thread splitter([&] {
       for (auto &t : readers) t.join();
       timeline("parallel readers done");
       const uint64_t stop = std::min<uint64_t>(irregular_at.load(), n_par_batches);   // batches [0, stop) came from the readers
-      fs.reset(new BatchSplitter(opt, io_threads, pool));
-      bool serial_ok = fs->ok();
-      if (serial_ok && parallel_feed) {
+      // nothing left when the readers delivered every batch and a mate file ends exactly there (the pair stream ends with the
+      // shorter file, FastqSplitter.hpp:60)
+      serial_needed = !parallel_feed || stop < n_par_batches || !(tab1.off[stop] >= tab1.file_size || (opt.paired_flag && tab2.off[stop] >= tab2.file_size));
+      bool serial_ok = true;
+      if (serial_needed) {
+        fs.reset(new BatchSplitter(opt, io_threads, pool));
+        serial_ok = fs->ok();
+      }
+      serial_failed = !serial_ok;
+      if (serial_needed && serial_ok && parallel_feed) {
         const uint64_t o1 = tab1.off[stop];
         const uint64_t o2 = opt.paired_flag ? tab2.off[stop] : 0;
         fs->resume_serial(o1, o2, stop, std::min<uint64_t>(stop * opt.batch, n_par_records));
       }
-      if (serial_ok) {
+      if (serial_needed && serial_ok) {
         for (;;) {
           auto b = (*fs)();
           if (!b) break;
@@ -937,16 +1037,20 @@ int main(int argc, char *argv[])
     splitter.join();
     for (auto &t : analyzers) t.join();
     fflush(stdout);
-    if (!fs || !fs->ok()) {
+    if (serial_failed) {
       std::cerr << "shark: cannot open the sample" << std::endl;
+      return EXIT_FAILURE;
+    }
+    if (ro.failed()) {
+      std::cerr << "shark: cannot read the sample again for the output" << std::endl;
       return EXIT_FAILURE;
     }
     if (opt.verbose) {
       double tr = 0;
       for (double x : t_reader) tr += x;
       std::cerr << "[shark/io] threads " << io_threads << ", parallel readers " << n_readers << (fixed_width ? " fixed-width records (" : " (") << std::min<uint64_t>(irregular_at.load(), n_par_batches)
-                << " batches, " << tr << " thread-seconds), serial reader: index " << fs->t_index << " s (" << fs->stage_report() << "), fill "
-                << fs->t_fill << " s, serial " << fs->t_serial << " s; classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
+                << " batches, " << tr << " thread-seconds), serial reader: " << (fs ? "index " + std::to_string(fs->t_index) + " s (" + fs->stage_report() + "), fill " + std::to_string(fs->t_fill) + " s, serial " + std::to_string(fs->t_serial) + " s" : std::string("not needed"))
+                << "; classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
     }
     if (out1) fclose(out1);
     if (out2) fclose(out2);

@@ -147,3 +147,97 @@ def test_reader_delivers_the_same_records_from_plain_gzip_and_bgzf(tool, tmp_pat
     raw[len(raw) // 2] ^= 0xFF
     open(tmp_path / "t.bad.gz", "wb").write(bytes(raw))
     assert rec(tmp_path / "t.bad.gz")["records"] < 30000
+
+
+# ---------------------------------------------------------------------------
+# the lean reader (fastq_lean_reader.hpp): what the CLI's reader threads copy and what its output stage reads back
+# ---------------------------------------------------------------------------
+def lean(tool, batch, path, qual=False):
+    r = subprocess.run([tool, "--lean", str(batch), str(path)] + (["qual"] if qual else []), capture_output=True, text=True, check=True)
+    return json.loads(r.stdout)
+
+
+def serial(tool, path):
+    r = subprocess.run([tool, "--records", str(path)], capture_output=True, text=True, check=True)
+    return json.loads(r.stdout)
+
+
+def write_fixed(path, n, rng, L=100, name_digits=6, plus_name=False):
+    with open(path, "wb") as f:
+        for i in range(n):
+            seq = bytes(rng.choice(list(b"ACGTN"), size=L).astype(np.uint8))
+            qual = bytes(rng.integers(33, 74, size=L).astype(np.uint8))     # includes '@', '+', '>' inside the line
+            rid = b"r%0*d/1" % (name_digits, i)
+            f.write(b"@" + rid + b" x\n" + seq + b"\n+" + (rid if plus_name else b"") + b"\n" + qual + b"\n")
+
+
+@pytest.mark.parametrize("batch", [1, 7, 64, 1000, 100000])
+@pytest.mark.parametrize("kind", ["fixed", "fixed_plus_name", "variable", "long_records"])
+def test_lean_reader_delivers_what_the_serial_reader_delivers(tool, tmp_path, batch, kind):
+    """strict four-line files of one layout (the 32-bytes-at-a-time check), of many layouts (line by line), with records longer
+    than the reader's 1 MiB buffer: names, sequences and qualities equal the serial kseq-rule reader's, whether the output
+    stage fetches a record alone or a run of records at once"""
+    rng = np.random.default_rng(11 + batch)
+    p = tmp_path / "a.fq"
+    if kind == "fixed":
+        write_fixed(p, 3000, rng)
+    elif kind == "fixed_plus_name":
+        write_fixed(p, 3000, rng, L=31, plus_name=True)
+    elif kind == "variable":
+        write_fastq(p, 3000, rng, 1)
+    else:
+        write_fastq(p, 40, rng, 1, min_len=200_000, max_len=700_000, id_extra=False)
+    want = serial(tool, p)
+    for qual in (False, True):
+        got = lean(tool, batch, p, qual)
+        assert got["ok"] and got["first_irregular_batch"] == -1, got
+        assert (got["records"], got["bases"], got["fnv"]) == (want["records"], want["bases"], want["fnv"])
+        if kind.startswith("fixed"):
+            assert got["fixed_width_file"] and got["fixed_width_batches"] == got["batches"]
+
+
+@pytest.mark.parametrize("damage", ["empty_read", "length_mismatch", "lone_cr", "nul_in_seq", "nul_in_name", "seq_starts_with_at", "extra_line",
+                                    "missing_plus", "two_half_records"])
+def test_lean_reader_stops_at_the_first_irregular_batch(tool, tmp_path, damage):
+    """every irregular record -- also those that keep the four-line rhythm or the file's fixed width -- makes its batch (and
+    nothing before it) irregular, with the fast layout check exactly as with the line-by-line path"""
+    rng = np.random.default_rng(5)
+    L, n, bad = 60, 2000, 1234
+    recs = []
+    for i in range(n):
+        seq = bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8))
+        qual = bytes(rng.integers(35, 74, size=L).astype(np.uint8))
+        recs.append([b"@r%05d" % i, seq, b"+", qual])
+    r = recs[bad]
+    if damage == "empty_read":
+        r[1], r[3] = b"", b""
+    elif damage == "length_mismatch":
+        r[3] = r[3][:-5] + b"\n" + r[3][-4:]           # same bytes, one more line: the width stays
+        r[3] = r[3].replace(b"\n", b"")[:-3]
+    elif damage == "lone_cr":
+        r[1] = r[1][:-1] + b"\r"
+    elif damage == "nul_in_seq":
+        r[1] = r[1][:10] + b"\x00" + r[1][11:]
+    elif damage == "nul_in_name":
+        r[0] = b"@r\x00" + r[0][3:]
+    elif damage == "seq_starts_with_at":
+        r[1] = b"@" + r[1][1:]
+    elif damage == "extra_line":
+        r[1] = r[1][:30] + b"\n" + r[1][31:]            # a newline inside the sequence: same width, five lines
+    elif damage == "missing_plus":
+        r[2] = b"-"
+    elif damage == "two_half_records":
+        W = len(b"\n".join(r)) + 1                      # two records in the width of one: 2 * (8 + 2 h + 4) + pad = W
+        h = (W - 24) // 4
+        a = [b"@r%05d" % bad, r[1][:h], b"+", r[3][:h]]
+        b = [b"@x%05d" % bad + b"y" * (W - 24 - 4 * h), r[1][h:2 * h], b"+", r[3][h:2 * h]]
+        recs[bad] = a + b
+        assert len(b"\n".join(recs[bad])) + 1 == W
+    p = tmp_path / "a.fq"
+    p.write_bytes(b"".join(b"\n".join(x) + b"\n" for x in recs))
+    for batch in (1, 100, 5000):
+        got = lean(tool, batch, p)
+        if damage == "two_half_records" and not got["fixed_width_file"]:
+            continue
+        assert got["ok"] and got["first_irregular_batch"] == bad // batch, (damage, batch, got)
+        assert got["records"] == (bad // batch) * batch
