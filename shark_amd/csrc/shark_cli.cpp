@@ -202,8 +202,9 @@ class Timeline {
   {
     if (!on_) return;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+    const double epoch = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     std::lock_guard<std::mutex> l(m_);
-    std::cerr << "[shark/ms] " << what << " " << ms << std::endl;
+    std::cerr << "[shark/ms] " << what << " " << ms << " (epoch " << std::fixed << epoch << std::defaultfloat << ")" << std::endl;
   }
 
  private:
@@ -218,9 +219,8 @@ Timeline timeline;
 template <typename T>
 using default_init_allocator = shk::NoInitAlloc<T>;
 
-// Page-locking costs about as much per byte as parsing does (measured: 21 batches of 160 MB took 12 thread-seconds to
-// pin), and the copies from ordinary memory run at 300 M reads/s -- several times what the parsers deliver -- so batches
-// are pinned only for samples large enough to pay that back (or when SHARK_PINNED=1 / 0 says so).
+// Batch buffers are page-locked once the HIP runtime is up (shk_alloc_pinned: 0.07 s per GB, tools/pin_cost.py; a recycled batch
+// keeps its buffers); those allocated earlier -- the readers start while the runtime initialises -- are ordinary memory.
 std::atomic<bool> g_pin_batches{false};
 
 template <typename T>
@@ -278,6 +278,7 @@ struct ReadBatch {
   // associated reads are fetched from the files again by the output stage
   bool lean = false;
   shk::BatchFilePart part1, part2;
+  std::shared_ptr<struct FormattedBatch> text;   // what the output stage will write for this batch (filled by a formatter thread)
   // result
   std::vector<uint32_t> gene_off;
   std::vector<uint16_t> gene_ids;
@@ -287,33 +288,78 @@ struct ReadBatch {
     id1.reset(); id2.reset(); seq1.reset(); qual1.reset(); seq2.reset(); qual2.reset();
     qual_as_read1.clear(); qual_as_read2.clear();
     lean = false;
+    text.reset();
     gene_off.clear(); gene_ids.clear();
     rc = 0;
   }
 };
 
-// Batches are recycled: a drained batch goes back to the splitter with its buffers' capacity, so
-// the ~0.6 GB a batch holds is faulted in once per pipeline slot instead of once per batch.
+// Batches are recycled.  Once the HIP runtime is up the pool becomes a RING of `limit` batches whose bases live in page-locked
+// memory: filled once (0.07 s per GB to lock, tools/pin_cost.py), handed round for the whole sample -- their copies to the device
+// are DMA at the link's rate, where a copy from ordinary memory makes the runtime lock and unlock the pages every time (which is
+// what bounded the CLI's GPU phase: 4.8 GB of bases took 0.3 s on the submitting thread).  A small ring also means a small
+// process: leaving it costs the kernel a few milliseconds instead of the 0.15 s it took to free gigabytes of parsed batches.
 class BatchPool {
  public:
+  // nullptr after shutdown()
   std::unique_ptr<ReadBatch> acquire()
   {
-    std::lock_guard<std::mutex> l(m_);
-    if (free_.empty()) return std::unique_ptr<ReadBatch>(new ReadBatch());
-    std::unique_ptr<ReadBatch> b = std::move(free_.back());
-    free_.pop_back();
-    return b;
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return stop_ || !free_.empty() || limit_ == 0 || made_ < limit_; });
+    if (stop_) return nullptr;
+    if (!free_.empty()) {
+      std::unique_ptr<ReadBatch> b = std::move(free_.back());
+      free_.pop_back();
+      return b;
+    }
+    ++made_;
+    l.unlock();
+    return std::unique_ptr<ReadBatch>(new ReadBatch());
   }
   void release(std::unique_ptr<ReadBatch> b)
   {
     b->reset();
     std::lock_guard<std::mutex> l(m_);
-    if (free_.size() < 64) free_.push_back(std::move(b));
+    if (limit_ || free_.size() < 64) free_.push_back(std::move(b));
+    else --made_;
+    cv_.notify_one();
+  }
+  // from now on at most `limit` batches exist; `reserve_bytes` per mate are page-locked for each right away (by the caller's thread:
+  // concurrent page-locking from many threads is several times slower than one thread doing it all)
+  void make_ring(size_t limit, size_t reserve_bytes, size_t reserve_reads, bool paired, bool with_qual)
+  {
+    std::vector<std::unique_ptr<ReadBatch>> fresh;
+    for (size_t i = 0; i < limit; ++i) {
+      std::unique_ptr<ReadBatch> b(new ReadBatch());
+      b->seq1.bytes.reserve(reserve_bytes);
+      b->seq1.off.reserve(reserve_reads + 1);
+      if (with_qual) b->qual1.bytes.reserve(reserve_bytes);
+      if (paired) {
+        b->seq2.bytes.reserve(reserve_bytes);
+        b->seq2.off.reserve(reserve_reads + 1);
+        if (with_qual) b->qual2.bytes.reserve(reserve_bytes);
+      }
+      fresh.push_back(std::move(b));
+    }
+    std::lock_guard<std::mutex> l(m_);
+    for (auto &b : fresh) free_.push_back(std::move(b));
+    made_ += limit;
+    limit_ = made_;
+    cv_.notify_all();
+  }
+  void shutdown()
+  {
+    std::lock_guard<std::mutex> l(m_);
+    stop_ = true;
+    cv_.notify_all();
   }
 
  private:
   std::mutex m_;
+  std::condition_variable cv_;
   std::vector<std::unique_ptr<ReadBatch>> free_;
+  size_t made_ = 0, limit_ = 0;   // limit_ == 0: unbounded
+  bool stop_ = false;
 };
 
 // FastqSplitter role (FastqSplitter.hpp:47-93): batches of reads in input order.
@@ -350,6 +396,7 @@ class BatchSplitter {
   std::unique_ptr<ReadBatch> operator()()
   {
     std::unique_ptr<ReadBatch> b = pool_.acquire();
+    if (!b) return nullptr;
     b->index = next_index_++;
     b->first_read = n_reads_;
     if (fast_) {
@@ -520,87 +567,107 @@ class ReadAnalyzer {
 // call -- and clears previd -- every 50 000 input reads (main.cpp:215,
 // ReadOutput.hpp:39), so 50 000-read chunks are independent and are formatted
 // in parallel; the text is then written in input order.
+// The text is produced per batch by any thread, in any order (format); the batches are then written in input order
+// (emit), which is also where the one thing that crosses a batch boundary is settled: whether the first associated read
+// of a batch that starts in the middle of a 50 000-read chunk repeats the previous batch's last read name.
+struct FormattedSegment {
+  std::string ssv, fq1, fq2;        // fq: the FASTQ records behind the segment's first one
+  std::string head1, head2;         // the first associated read's FASTQ records, printed unless its name equals the carried one
+  std::string head_id, last_id;
+  bool has_assoc = false, carries = false;
+};
+struct FormattedBatch {
+  std::vector<FormattedSegment> segs;
+};
+
 class ReadOutput {
  public:
-  ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend, unsigned threads)
-      : out1_(out1), out2_(out2), legend_(legend), threads_(threads) {}
+  ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend) : out1_(out1), out2_(out2), legend_(legend) {}
   bool failed() const { return failed_.load(); }
-  void operator()(const ReadBatch &b)
+
+  // thread-safe; nothing is written
+  void format(const ReadBatch &b, FormattedBatch &out) const
   {
     const size_t n = b.seq1.size();
+    out.segs.clear();
+    shk::RecordFetcher f1, f2;
     // segments: [first, last) read ranges that do not cross a 50 000 boundary
-    std::vector<std::pair<size_t, size_t>> segs;
-    for (size_t i = 0; i < n;) {
-      const uint64_t g = b.first_read + i;
-      const size_t e = (size_t)std::min<uint64_t>(n, i + (50000 - g % 50000));
-      segs.emplace_back(i, e);
-      i = e;
-    }
-    std::vector<std::string> ssv(segs.size()), fq1(segs.size()), fq2(segs.size()), last_id(segs.size());
-    std::vector<char> any(segs.size(), 0);
-    shk::parallel_for(threads_, segs.size(), [&](size_t sb, size_t se, unsigned) {
-      shk::RecordFetcher f1, f2;
-      for (size_t si = sb; si < se; ++si) {
-        std::string previd;
-        bool have = false;
-        const bool carries = (b.first_read + segs[si].first) % 50000 != 0;   // continues the previous batch's chunk
-        if (carries) { previd = carry_; have = true; }
-        if (b.lean) {
-          // many associated reads in this segment: its byte range in one read; few: one read per record
-          const size_t n_assoc = b.gene_off[segs[si].second] - b.gene_off[segs[si].first];
-          const bool dense = n_assoc * 10 > segs[si].second - segs[si].first;
-          if (dense) {
-            f1.load_dense(b.part1, segs[si].first, segs[si].second);
-            if (out2_) f2.load_dense(b.part2, segs[si].first, segs[si].second);
-          } else {
-            f1.unload();
-            f2.unload();
-          }
+    for (size_t first = 0; first < n;) {
+      const uint64_t g = b.first_read + first;
+      const size_t last = (size_t)std::min<uint64_t>(n, first + (50000 - g % 50000));
+      out.segs.emplace_back();
+      FormattedSegment &sg = out.segs.back();
+      sg.carries = g % 50000 != 0;                  // continues the previous batch's chunk: previd is known only when the batches are written
+      std::string previd;
+      if (b.lean) {
+        // many associated reads in this segment: its byte range in one read; few: one read per record
+        const size_t n_assoc = b.gene_off[last] - b.gene_off[first];
+        if (n_assoc * 10 > last - first) {
+          f1.load_dense(b.part1, first, last);
+          if (out2_) f2.load_dense(b.part2, first, last);
+        } else {
+          f1.unload();
+          f2.unload();
         }
-        for (size_t i = segs[si].first; i < segs[si].second; ++i) {
-          if (b.gene_off[i] == b.gene_off[i + 1]) continue;
-          shk::RecordFetcher::View v1{nullptr, 0, nullptr, 0, nullptr}, v2{nullptr, 0, nullptr, 0, nullptr};
-          const char *id;
-          size_t id_len;
-          if (b.lean) {
-            if (!f1.get(b.part1, i, v1) || (out2_ && !f2.get(b.part2, i, v2))) { failed_ = true; continue; }
-            id = v1.id;
-            id_len = v1.id_len;
-          } else {
-            id = b.id1.at(i);
-            id_len = b.id1.len(i);
-          }
-          for (uint32_t j = b.gene_off[i]; j < b.gene_off[i + 1]; ++j) {
-            const std::string &gene = legend_[b.gene_ids[j]];
-            ssv[si].append(id, id_len);
-            ssv[si].push_back(' ');
-            ssv[si].append(gene);
-            ssv[si].push_back('\n');
-            const bool same = previd.size() == id_len && memcmp(previd.data(), id, id_len) == 0;
-            if (!same) {
-              if (b.lean) {
-                if (out1_) record_view(fq1[si], v1);
-                if (out2_) record_view(fq2[si], v2);
-              } else {
-                if (out1_) record(fq1[si], b.id1, b.seq1, b.qual1, b.qual_as_read1, i);
-                if (out2_) record(fq2[si], b.id2, b.seq2, b.qual2, b.qual_as_read2, i);
-              }
-            }
-            previd.assign(id, id_len);
-            have = true;
-          }
-        }
-        (void)have;
-        last_id[si] = previd;
-        any[si] = 1;
       }
-    });
-    for (size_t si = 0; si < segs.size(); ++si) {
-      fwrite(ssv[si].data(), 1, ssv[si].size(), stdout);
-      if (out1_) fwrite(fq1[si].data(), 1, fq1[si].size(), out1_);
-      if (out2_) fwrite(fq2[si].data(), 1, fq2[si].size(), out2_);
+      for (size_t i = first; i < last; ++i) {
+        if (b.gene_off[i] == b.gene_off[i + 1]) continue;
+        shk::RecordFetcher::View v1{nullptr, 0, nullptr, 0, nullptr}, v2{nullptr, 0, nullptr, 0, nullptr};
+        const char *id;
+        size_t id_len;
+        if (b.lean) {
+          if (!f1.get(b.part1, i, v1) || (out2_ && !f2.get(b.part2, i, v2))) { failed_ = true; continue; }
+          id = v1.id;
+          id_len = v1.id_len;
+        } else {
+          id = b.id1.at(i);
+          id_len = b.id1.len(i);
+        }
+        for (uint32_t j = b.gene_off[i]; j < b.gene_off[i + 1]; ++j) {
+          const std::string &gene = legend_[b.gene_ids[j]];
+          sg.ssv.append(id, id_len);
+          sg.ssv.push_back(' ');
+          sg.ssv.append(gene);
+          sg.ssv.push_back('\n');
+          const bool head = !sg.has_assoc;            // the segment's first association
+          const bool same = !(head && sg.carries) && previd.size() == id_len && memcmp(previd.data(), id, id_len) == 0;
+          if (!same) {
+            std::string &o1 = (head && sg.carries) ? sg.head1 : sg.fq1, &o2 = (head && sg.carries) ? sg.head2 : sg.fq2;
+            if (b.lean) {
+              if (out1_) record_view(o1, v1);
+              if (out2_) record_view(o2, v2);
+            } else {
+              if (out1_) record(o1, b.id1, b.seq1, b.qual1, b.qual_as_read1, i);
+              if (out2_) record(o2, b.id2, b.seq2, b.qual2, b.qual_as_read2, i);
+            }
+          }
+          if (head) sg.head_id.assign(id, id_len);
+          previd.assign(id, id_len);
+          sg.has_assoc = true;
+        }
+      }
+      sg.last_id = previd;
+      first = last;
     }
-    if (!segs.empty()) carry_ = last_id.back();
+  }
+
+  // in input order, one thread
+  void emit(const FormattedBatch &f)
+  {
+    for (const FormattedSegment &sg : f.segs) {
+      fwrite(sg.ssv.data(), 1, sg.ssv.size(), stdout);
+      // (ReadOutput.hpp:44-48: a read's FASTQ records are printed unless its name equals the one printed just before it)
+      const bool head_repeats = sg.carries && sg.has_assoc && sg.head_id == carry_;
+      if (out1_) {
+        if (!head_repeats) fwrite(sg.head1.data(), 1, sg.head1.size(), out1_);
+        fwrite(sg.fq1.data(), 1, sg.fq1.size(), out1_);
+      }
+      if (out2_) {
+        if (!head_repeats) fwrite(sg.head2.data(), 1, sg.head2.size(), out2_);
+        fwrite(sg.fq2.data(), 1, sg.fq2.size(), out2_);
+      }
+      carry_ = sg.has_assoc ? sg.last_id : (sg.carries ? carry_ : std::string());
+    }
   }
 
  private:
@@ -628,8 +695,7 @@ class ReadOutput {
   }
   FILE *out1_, *out2_;
   const std::vector<std::string> &legend_;
-  unsigned threads_;
-  std::atomic<bool> failed_{false};   // a record could not be read back from its file (I/O error)
+  mutable std::atomic<bool> failed_{false};   // a record could not be read back from its file (I/O error)
   std::string carry_;   // previd at the end of the previous batch (only used when a batch starts mid-chunk)
 };
 
@@ -712,14 +778,40 @@ int main(int argc, char *argv[])
   const int n_gpus = opt.gpus;
   std::vector<shk_ctx *> ctxs((size_t)n_gpus, nullptr);
   int ctx_rc = SHK_OK, ctx_bad = -1;
+  std::mutex ctx_m;
+  std::condition_variable ctx_cv;
+  bool ctx_done = false, ctx_created = false;
+  BatchPool &pool = *new BatchPool;   // (never destroyed: the process leaves through _exit)
+  // what the ring of page-locked batches has to hold; known once the sample is partitioned (this thread), used by the context
+  // thread, which builds the ring as soon as the HIP runtime is up
+  struct RingPlan { bool known = false; size_t limit = 0, bytes = 0, reads = 0; bool paired = false, with_qual = false; } ring_plan;
+  // The ring lives in ordinary memory by default: its buffers are handed round, so the runtime's registration of them is paid once
+  // per buffer (measured: the same rate as page-locked buffers at what the readers deliver), it exists before the HIP runtime does --
+  // the readers fill it while the runtime initialises -- and it costs nothing to set up.  SHARK_PINNED=1: page-locked.
+  const bool pin_ring = getenv("SHARK_PINNED") && getenv("SHARK_PINNED")[0] == '1';
   std::thread ctx_thread([&] {
     for (int g = 0; g < n_gpus; ++g) {
       shk_params p{};
       p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single; p.device = g;
       const int rc = shk_create(&p, &ctxs[(size_t)g]);
-      if (rc != SHK_OK) { ctx_rc = rc; ctx_bad = g; return; }
+      if (rc != SHK_OK) { ctx_rc = rc; ctx_bad = g; break; }
     }
     timeline("contexts created");
+    std::unique_lock<std::mutex> l(ctx_m);
+    ctx_created = true;
+    ctx_cv.notify_all();
+    if (pin_ring) {
+      // SHARK_PINNED=1: the ring in page-locked memory, which only exists once the HIP runtime is up
+      ctx_cv.wait(l, [&] { return ring_plan.known; });
+      const RingPlan plan = ring_plan;
+      l.unlock();
+      if (ctx_rc == SHK_OK) g_pin_batches = true;
+      pool.make_ring(plan.limit, plan.bytes, plan.reads, plan.paired, plan.with_qual);
+      timeline("batch ring ready");
+      l.lock();
+      ctx_done = true;
+      ctx_cv.notify_all();
+    }
   });
   struct CtxJoin {   // (every early return below has to wait for that thread)
     std::thread &t;
@@ -738,10 +830,9 @@ int main(int argc, char *argv[])
   {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, hw);
-    BatchPool pool;
     FILE *out1 = fopen(opt.out1_path.c_str(), "w");
     FILE *out2 = (opt.paired_flag && opt.out2_path != "") ? fopen(opt.out2_path.c_str(), "w") : nullptr;
-    ReadOutput ro(out1, out2, legend_ID, io_threads);
+    ReadOutput ro(out1, out2, legend_ID);
     if (out1) setvbuf(out1, nullptr, _IOFBF, 1 << 22);
     if (out2) setvbuf(out2, nullptr, _IOFBF, 1 << 22);
     setvbuf(stdout, nullptr, _IOFBF, 1 << 22);
@@ -762,13 +853,6 @@ int main(int argc, char *argv[])
       todo[(size_t)(b->index % (uint64_t)n_gpus)]->push(std::move(b));
     };
 
-    {
-      // pinned batches for samples of 8 GiB and more (the pinning is then a few percent of the run)
-      struct stat st1;
-      const bool big = stat(opt.sample1_path.c_str(), &st1) == 0 && (uint64_t)st1.st_size >= (8ull << 30);
-      const char *pe = getenv("SHARK_PINNED");
-      g_pin_batches = pe ? pe[0] == '1' : big;
-    }
     // ---- the parallel feed -------------------------------------------------------
     shk::BatchTable tab1, tab2;
     bool parallel_feed = !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");
@@ -808,9 +892,30 @@ int main(int argc, char *argv[])
     const unsigned n_readers = parallel_feed ? (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(io_threads, n_par_batches)) : 0;
     std::vector<double> t_reader(n_readers, 0.0);
     // a reader must not run ahead of the drain without bound: at most `window` batches beyond the one being written
-    // (generous: the readers start before the GPU is initialised and the index built, and run ahead meanwhile -- about 3 GiB of bases)
-    const uint64_t batch_bytes = std::max<uint64_t>(1, opt.batch * (opt.paired_flag ? 2 : 1) * 160);
-    const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + (3ull << 30) / batch_bytes;
+    // the ring: a batch per reader, what the GPUs hold in flight, and a few being turned into text or waiting for their turn to be written
+    const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 6;
+    {
+      uint64_t widest = 0;
+      for (uint64_t i = 0; i < n_par_batches; ++i) {
+        widest = std::max(widest, tab1.off[i + 1] - tab1.off[i]);
+        if (opt.paired_flag) widest = std::max(widest, tab2.off[i + 1] - tab2.off[i]);
+      }
+      std::lock_guard<std::mutex> l(ctx_m);
+      ring_plan.known = true;
+      ring_plan.limit = (size_t)window;
+      ring_plan.bytes = n_par_batches ? (size_t)(widest / 2 + 64) : 0;
+      ring_plan.reads = n_par_batches ? (size_t)opt.batch : 0;
+      ring_plan.paired = opt.paired_flag;
+      ring_plan.with_qual = static_cast<char>(opt.min_quality) != 0;
+      ctx_cv.notify_all();
+    }
+    if (!pin_ring) {
+      pool.make_ring(ring_plan.limit, ring_plan.bytes, ring_plan.reads, ring_plan.paired, ring_plan.with_qual);
+      timeline("batch ring ready");
+      std::lock_guard<std::mutex> l(ctx_m);
+      ctx_done = true;
+      ctx_cv.notify_all();
+    }
     uint64_t drained = 0;                                // guarded by done_m
     // Batch j may only leave a reader once every batch before it is KNOWN to be strict four-line FASTQ: an irregular batch
     // i < j that keeps the four-line alignment (an empty read, a sequence/quality length mismatch, a lone CR, a NUL) lets
@@ -831,6 +936,10 @@ int main(int argc, char *argv[])
     for (unsigned r = 0; r < n_readers; ++r) {
       readers.emplace_back([&, r] {
         shk::LeanScratch sc;
+        {
+          std::unique_lock<std::mutex> l(ctx_m);   // the ring of batches exists (at once; page-locked: once the HIP runtime is up)
+          ctx_cv.wait(l, [&] { return ctx_done; });
+        }
         for (;;) {
           const uint64_t i = next_batch.fetch_add(1);
           if (i >= n_par_batches || i >= irregular_at.load()) break;
@@ -842,6 +951,7 @@ int main(int argc, char *argv[])
           auto t0 = std::chrono::steady_clock::now();
           const size_t want = (size_t)std::min<uint64_t>(opt.batch, n_par_records - i * opt.batch);
           std::unique_ptr<ReadBatch> b = pool.acquire();
+          if (!b) break;
           b->index = i;
           b->first_read = i * opt.batch;
           b->lean = true;
@@ -877,6 +987,7 @@ int main(int argc, char *argv[])
       uint64_t cur = irregular_at.load();
       while (0 < cur && !irregular_at.compare_exchange_weak(cur, 0)) {}
       for (auto &q : todo) q->close();
+      pool.shutdown();
       done_cv.notify_all();
       std::thread drain_q([&] {
         for (auto &q : todo) {
@@ -894,7 +1005,10 @@ int main(int argc, char *argv[])
         std::cerr << "shark: cannot open " << opt.fasta_path << std::endl;
         return EXIT_FAILURE;
       }
-      ctx_thread.join();
+      {
+        std::unique_lock<std::mutex> l(ctx_m);   // (the contexts; that thread goes on to build the batch ring)
+        ctx_cv.wait(l, [&] { return ctx_created; });
+      }
       if (ctx_rc != SHK_OK) {
         stop_feed();
         std::cerr << "shark: cannot create a context on GPU " << ctx_bad << ": " << shk_strerror(ctx_rc) << std::endl;
@@ -973,15 +1087,31 @@ int main(int argc, char *argv[])
     });
 
     std::vector<double> t_gpu((size_t)n_gpus, 0.0);
+    // classified batches are turned into text by `formatters` threads, in any order (ReadOutput::format: names and qualities of
+    // the associated reads are fetched from the sample files there); the drain below writes the text in input order
+    BoundedQueue<std::unique_ptr<ReadBatch>> to_format(1u << 20);
+    auto hand_over = [&](std::unique_ptr<ReadBatch> b) {
+      std::lock_guard<std::mutex> l(done_m);
+      done[b->index] = std::move(b);
+      done_cv.notify_all();
+    };
+    std::vector<std::thread> formatters;
+    for (unsigned f = 0; f < std::max(2u, io_threads); ++f) {
+      formatters.emplace_back([&] {
+        std::unique_ptr<ReadBatch> b;
+        while (to_format.pop(b)) {
+          if (b->rc == SHK_OK) {
+            b->text = std::make_shared<FormattedBatch>();
+            ro.format(*b, *b->text);
+          }
+          hand_over(std::move(b));
+        }
+      });
+    }
     std::vector<std::thread> analyzers;
     for (int g = 0; g < n_gpus; ++g) {
       analyzers.emplace_back([&, g] {
-        ReadAnalyzer ra(ctxs[(size_t)g], static_cast<char>(opt.min_quality) != 0);
-        auto hand_over = [&](std::unique_ptr<ReadBatch> b) {
-          std::lock_guard<std::mutex> l(done_m);
-          done[b->index] = std::move(b);
-          done_cv.notify_all();
-        };
+        ReadAnalyzer ra(ctxs[(size_t)g], need_qual);
         bool open = true;
         while (open || ra.in_flight()) {
           // keep the pipeline full; block for input only when nothing is in flight
@@ -993,14 +1123,14 @@ int main(int argc, char *argv[])
             if (got < 0) { open = false; break; }
             if (got == 0) break;
             auto t0 = std::chrono::steady_clock::now();
-            if (!ra.submit(std::move(b))) hand_over(ra.take_failed());
+            if (!ra.submit(std::move(b))) to_format.push(ra.take_failed());
             t_gpu[(size_t)g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           }
           if (ra.in_flight()) {
             auto t0 = std::chrono::steady_clock::now();
             std::unique_ptr<ReadBatch> b = ra.wait();
             t_gpu[(size_t)g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            hand_over(std::move(b));
+            to_format.push(std::move(b));
           }
         }
       });
@@ -1022,7 +1152,7 @@ int main(int argc, char *argv[])
         failed = b->rc;
       } else {
         auto t0 = std::chrono::steady_clock::now();
-        ro(*b);
+        ro.emit(*b->text);
         t_out += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       pool.release(std::move(b));
@@ -1036,6 +1166,8 @@ int main(int argc, char *argv[])
     timeline("drain done");
     splitter.join();
     for (auto &t : analyzers) t.join();
+    to_format.close();
+    for (auto &t : formatters) t.join();
     fflush(stdout);
     if (serial_failed) {
       std::cerr << "shark: cannot open the sample" << std::endl;
@@ -1086,8 +1218,13 @@ int main(int argc, char *argv[])
     }
   }
 
+  if (ctx_thread.joinable()) ctx_thread.join();
   for (auto *ctx : ctxs) shk_destroy(ctx);
   timeline("contexts destroyed");
   pelapsed("Association done");
-  return 0;
+  // everything is written and closed; leaving through _exit skips the teardown of the HIP runtime and of the worker threads'
+  // statics, which costs more than a tenth of a second and changes nothing
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

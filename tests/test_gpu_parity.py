@@ -373,7 +373,7 @@ def test_bench_two_ranks_dry_run(tmp_path, launcher, scaling):
     for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     base = [os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "250000", "--total-pairs", "1000000",
-            "--scaling", scaling, "--no-configs", "--no-boundary", "--no-cpu-baseline"]
+            "--scaling", scaling, "--no-configs", "--no-boundary", "--no-cpu-baseline", "--no-cli"]
     if launcher == "self":
         cmd = ["python3"] + base + ["--gpus", "2"]
     else:
@@ -412,7 +412,7 @@ def test_bench_refuses_a_rank_count_that_is_not_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SHARK_DIST_BACKEND")}
     n_dev = torch.cuda.device_count()
     r = subprocess.run(["python3", os.path.join(root, "bench.py"), "--gpus", str(n_dev + 1), "--steps", "1", "--no-configs", "--no-boundary",
-                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+                        "--no-cpu-baseline", "--no-cli"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert r.returncode != 0 and "GPU(s)" in r.stderr and not r.stdout.strip()
 
 

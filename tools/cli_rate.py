@@ -53,6 +53,9 @@ t0 = time.time()
 write_fastq(os.path.join(td, "r1.fq"), 1)
 write_fastq(os.path.join(td, "r2.fq"), 2)
 gen_s = time.time() - t0
+if os.environ.get('WARM', '1') == '1':      # read the files once, untimed: the first read of freshly written tmpfs pages pays for their LRU activation
+    for f in ('r1.fq', 'r2.fq'):
+        subprocess.run(['cat', os.path.join(td, f)], stdout=subprocess.DEVNULL)
 # CLI_T=16,64 runs the same files once per thread count
 for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
     args = extra + (["-t", t] if t else [])
@@ -61,8 +64,11 @@ for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
         r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"),
                             "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-v"] + args,
                            stdout=so, stderr=subprocess.PIPE)
-    dt = time.time() - t0
-    print(json.dumps({"pairs": n, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
+    t1 = time.time()
+    dt = t1 - t0
+    ep = [float(l.split("(epoch ")[1].rstrip(")")) for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]") and "(epoch " in l]
+    gaps = {"before_main_ms": round((ep[0] - t0) * 1e3, 1), "after_last_ms": round((t1 - ep[-1]) * 1e3, 1)} if ep else {}
+    print(json.dumps({"pairs": n, "gaps": gaps, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
                       "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "headers": "var" if VAR else "fixed",
-                      "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
+                      "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:].split(" (epoch")[0] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
 subprocess.run(["rm", "-rf", td])

@@ -2,7 +2,7 @@
 # one SQ counter pass of the bench workload at on-target fraction $1 (environment passes through, e.g. SHK_LIB_PATH)
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_one; rm -rf $OUT; mkdir -p $OUT
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --steps 2 --warmup 1 --total-pairs 10000000 --no-configs --no-cpu-baseline --no-boundary --on-target $1 > $OUT/a.json 2> $OUT/a.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --steps 2 --warmup 1 --total-pairs 10000000 --no-configs --no-cpu-baseline --no-boundary --no-cli --on-target $1 > $OUT/a.json 2> $OUT/a.err
 python3 - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(list)

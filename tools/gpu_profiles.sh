@@ -7,14 +7,14 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles
 rm -rf $OUT; mkdir -p $OUT
-BENCH1="bench.py --steps 2 --warmup 1 --total-pairs 10000000 --no-configs --no-cpu-baseline --no-boundary"
+BENCH1="bench.py --steps 2 --warmup 1 --total-pairs 10000000 --no-configs --no-cpu-baseline --no-boundary --no-cli"
 SQA="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
 SQB="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS"
 pass() { # tag name counters -- program args
   tag=$1; name=$2; ctr=$3; shift 3
   timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$tag/$name -- python3 "$@" > $OUT/$tag/$name.json 2> $OUT/$tag/$name.err
 }
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-boundary > $OUT/kt.json 2> $OUT/kt.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-boundary --no-cli > $OUT/kt.json 2> $OUT/kt.err
 for ot in 0.0 0.5 1.0; do
   tag=configs1_ot$ot; mkdir -p $OUT/$tag
   pass $tag fetch "FETCH_SIZE" $BENCH1 --on-target $ot

@@ -17,7 +17,7 @@ for step in "$@"; do
     scale)       timeout -k 10 1100 python -m pytest tests/test_gpu_scale.py -x -q > $out/$step.log 2>&1 ;;
     suite)       timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=15 > $out/$step.log 2>&1 ;;
     bench)       timeout -k 10 600 python3 bench.py --steps 10 --warmup 2 > $out/bench.json 2> $out/$step.log ;;
-    bench_quick) timeout -k 10 600 python3 bench.py --steps 5 --warmup 1 --no-configs --no-boundary --no-cpu-baseline > $out/bench_quick.json 2> $out/$step.log ;;
+    bench_quick) timeout -k 10 600 python3 bench.py --steps 5 --warmup 1 --no-configs --no-boundary --no-cpu-baseline --no-cli > $out/bench_quick.json 2> $out/$step.log ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
   rc=$?
