@@ -535,11 +535,6 @@ def main():
             boundary[kind] = {"value": round(2 * nb / tb, 1), "unit": "reads/s", "ms_per_batch": round(tb * 1e3, 2),
                               "GBps_h2d": round((hbp["seq1"].nbytes + hbp["seq2"].nbytes) / tb / 1e9, 1), "assoc_per_batch": assoc // boundary["batches"]}
 
-    # ---- the drop-in command itself, end to end (never `value`): FASTQ files in, ssv + FASTQ files out ----------------
-    cli = None
-    if not args.no_cli and world == 1:
-        cli = cli_end_to_end(args, genes, dev, h, L)
-
     # ---- CPU baseline: the oracle (port of the reference path) on this host -------
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bounded sample)
@@ -591,6 +586,11 @@ def main():
                "parity_with_gpu": parity,
                "one_thread": {"value": round(2 * n1 / t1, 1), "unit": "reads/s", "sample": "first %d pairs, %.1f s" % (n1, t1)}}
         o.close()
+
+    # ---- the drop-in command itself, end to end (never `value`): FASTQ files in, ssv + FASTQ files out ----------------
+    cli = None   # (last: it classifies other reads with the same context, which invalidates `res`)
+    if not args.no_cli and world == 1:
+        cli = cli_end_to_end(args, genes, dev, h, L)
 
     out = {
         "metric": "reads/s (paired 2x150 bp, k=%d)" % k,
