@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
       const uint64_t nk1 = L1 >= k ? L1 - k + 1 : 0, nk2 = L2 >= k ? L2 - k + 1 : 0;
       const uint64_t ns = nk2 ? ((L1 + 7) & ~7ull) + nk2 : nk1;
       const uint64_t groups = ((L1 + 7) >> 3) + ((L2 + 7) >> 3);
-      const bool ok = n && !any_bad && ns <= slot_cap && groups <= 64 && L1 < (1ull << 31) && L2 < (1ull << 31);
+      const bool ok = n && !any_bad && ns <= slot_cap && groups <= (slot_cap > 512u ? 128u : 64u) && L1 < (1ull << 31) && L2 < (1ull << 31);
       flag[1] = (uint32_t)L1;
       flag[2] = (uint32_t)L2;
       __threadfence();
@@ -792,15 +792,19 @@ __global__ void fill_offsets_kernel(uint64_t *__restrict__ off, uint64_t n_plus_
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-uint32_t fast_kernel_max_slots() { return 64 * 8; }
+uint32_t fast_kernel_max_slots() { return 64 * 10; }
 
 uint32_t fast_kernel_unroll(uint32_t max_slots)
 {
   const uint32_t u = max_slots == 0 ? 5 : (max_slots + 63) / 64;
   if (u <= 2) return 2;
   if (u <= 6) return u;
-  return 8;
+  return u <= 8 ? 8 : 10;
 }
+
+// staging groups (8 bases each) per pair that classify_uni_kernel's specialisation for `max_slots` slots can stage: one per lane
+// up to 512 slots, two beyond (classify_uni.hpp, G)
+uint32_t uni_kernel_max_groups(uint32_t max_slots) { return fast_kernel_unroll(max_slots) > 8 ? 128u : 64u; }
 
 static int probe_mode(const DeviceIndex &ix)
 {
@@ -844,7 +848,7 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   // persistent workgroups; the LDS-summary mode runs 2 x 1024-thread workgroups per CU
   const uint64_t wpb = pm_lds(mode) ? 8 : CF_WAVES;
   const uint32_t u = fast_kernel_unroll(max_slots);
-  const uint64_t cap = pm_lds(mode) ? (u <= 5 ? 1024 : 768) : 4096;   // LDS mode: exactly the resident workgroups
+  const uint64_t cap = pm_lds(mode) ? (u <= 5 ? 1024 : 768) : 4096;   // (u = 10 likewise 768: six waves per SIMD at most)   // LDS mode: exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   if (u == 2) launch_fast_u<2>(p, mode, hasq, grid, stream);
@@ -852,7 +856,8 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   else if (u == 4) launch_fast_u<4>(p, mode, hasq, grid, stream);
   else if (u == 5) launch_fast_u<5>(p, mode, hasq, grid, stream);
   else if (u == 6) launch_fast_u<6>(p, mode, hasq, grid, stream);
-  else launch_fast_u<8>(p, mode, hasq, grid, stream);
+  else if (u == 8) launch_fast_u<8>(p, mode, hasq, grid, stream);
+  else launch_fast_u<10>(p, mode, hasq, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }
@@ -871,6 +876,7 @@ void launch_uni_u4(const ClassifyParams &p, int mode, bool hasq, bool big, bool 
 void launch_uni_u5(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
 void launch_uni_u6(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
 void launch_uni_u8(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
+void launch_uni_u10(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
 
 // the table kernel (every index with a position table), for uniform batches (`uni`) or ragged ones; with p.uni_flag set each
 // of the two launches decides on the device whether it is the one that runs
@@ -883,7 +889,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint32_t u = fast_kernel_unroll(max_slots);
   // indices too dense for the 32 KiB LDS summary may still have the 128 KiB one (index_build.hip): uniform batches then
   // run in LDS-summary mode with it, whatever chain ragged batches use on this index
-  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && u <= 5;
+  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10);
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
     p.lsum32 = ctx->idx.lbig32;
@@ -891,13 +897,13 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   }
   // tiny indices: the exact table in LDS (uniform batches; power-of-two filters).  Trimmed reads stay on the LDS-summary chain:
   // measured 9.8 ms per 10 M pairs with the table in LDS (4 waves per SIMD) against 9.7 ms (6 waves per SIMD)
-  const bool lx = uni && mode == PM_LDS_TAB && ctx->idx.ltab != nullptr && u <= 5;
+  const bool lx = uni && mode == PM_LDS_TAB && ctx->idx.ltab != nullptr && (u <= 5 || u == 10);
   if (lx) {
     p.lsum32 = ctx->idx.ltab;
     p.lsum_shift = ctx->idx.ltab_mul;   // (no summary in this mode: the field carries the table's slot multiplier)
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
-  const int min_waves = wg16 ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
+  const int min_waves = wg16 ? 4 : (u > 8 ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));
   const uint64_t wpb = lx ? SHK_LX_WAVES : (wg16 ? 16 : 8);
   const uint64_t cap = wg16 ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
@@ -907,7 +913,8 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   else if (u == 4) launch_uni_u4(p, mode, hasq, big, lx, uni, grid, stream);
   else if (u == 5) launch_uni_u5(p, mode, hasq, big, lx, uni, grid, stream);
   else if (u == 6) launch_uni_u6(p, mode, hasq, false, false, uni, grid, stream);
-  else launch_uni_u8(p, mode, hasq, false, false, uni, grid, stream);
+  else if (u == 8) launch_uni_u8(p, mode, hasq, false, false, uni, grid, stream);
+  else launch_uni_u10(p, mode, hasq, big, lx, uni, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   return SHK_OK;
 }

@@ -117,7 +117,7 @@ struct UniGeom {
   static constexpr int WAVES = (pm_lds(MODE) && LSL >= 20) ? (LSL == 21 ? SHK_LX_WAVES : 16) : 8;
   static constexpr int THREADS = WAVES * 64;
   // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes likewise (SHK_TAB_WAVES, classify_common.hpp)
-  static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES));
+  static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : (U > 8 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));   // (U = 10: 128 VGPRs)
   static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (LX ? LTAB_BYTES * 8u : (1u << LSL)) : 0u;   // what the workgroup keeps in LDS
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };
@@ -172,21 +172,28 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
   // ---- geometry: of every read of the batch (UNI) or of the current read ----------
   const uint32_t k = P.k;
-  uint32_t nk1, nk2, P2, g2, n_groups, tail_inv, Lm;
-  bool act, m2;
+  // G: staging groups (8 bases) per lane -- one up to 512 bases per pair, two beyond (U = 10: 2 x 300 bp)
+  constexpr int G = U > 8 ? 2 : 1;
+  uint32_t nk1, nk2, P2, g2, n_groups;
+  uint32_t tail_inv[G], Lm[G], bofs[G];
+  bool act[G], m2[G];
   auto set_geometry = [&](const uint32_t l1, const uint32_t l2) {
     nk1 = l1 >= k ? l1 - k + 1 : 0;
     nk2 = l2 >= k ? l2 - k + 1 : 0;
     P2 = (l1 + 7u) & ~7u;
     g2 = P2 >> 3;
-    n_groups = g2 + ((l2 + 7u) >> 3);                 // <= 64 (UNI: checked before this kernel is chosen; else: per read below)
-    // lane -> the 8 bases it stages
-    act = (uint32_t)lane < n_groups;
-    m2 = (uint32_t)lane >= g2;
-    const uint32_t b = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
-    Lm = m2 ? l2 : l1;
-    const uint32_t rem = act ? Lm - b : 8u;
-    tail_inv = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
+    n_groups = g2 + ((l2 + 7u) >> 3);                 // <= 64 G (UNI: checked before this kernel is chosen; else: per read below)
+    // lane -> the 8 bases it stages (per group)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint32_t gi = (uint32_t)lane + 64u * g;
+      act[g] = gi < n_groups;
+      m2[g] = gi >= g2;
+      bofs[g] = (m2[g] ? gi - g2 : gi) << 3;
+      Lm[g] = m2[g] ? l2 : l1;
+      const uint32_t rem = act[g] ? Lm[g] - bofs[g] : 8u;
+      tail_inv[g] = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;   // positions of the group behind the mate's end
+    }
   };
   set_geometry(L1, L2);
   // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
@@ -208,56 +215,78 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
   };
   if (UNI) plan_cut(L1, L2);
-  const uint32_t b_uni = (m2 ? (uint32_t)lane - g2 : (uint32_t)lane) << 3;
-  const uint8_t *const sbase = (m2 ? P.seq2 : P.seq1) + b_uni;
-  const uint8_t *const qbase = HASQ ? (m2 ? P.qual2 : P.qual1) + b_uni : nullptr;
+  const uint8_t *sbase[G], *qbase[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    sbase[g] = (m2[g] ? P.seq2 : P.seq1) + bofs[g];
+    qbase[g] = HASQ ? (m2[g] ? P.qual2 : P.qual1) + bofs[g] : nullptr;
+  }
   // the unguarded loads read up to 11 bytes behind a group's first byte: fine while that stays inside the mate's buffer
   const uint32_t n32 = (uint32_t)P.n, stride = gridDim.x * WAVES;
   const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
   const uint32_t guard_reads = Lmin >= 12u ? 1u : (Lmin ? (12u + Lmin - 1u) / Lmin : n32);   // trailing reads with guarded loads
 
   // UNI: read r of a mate is at r * L
-  auto issue = [&](const uint32_t r, Raw8 &w, Raw8 &q) {
-    w = Raw8{0u, 0u, 0u, 0u};
-    q = Raw8{0u, 0u, 0u, 0u};
-    if (act) {
-      const uint64_t o = (uint64_t)r * Lm;
-      if (n32 - r > guard_reads) {
-        w = load8_issue_all(sbase + o, 8u);
-        if (HASQ) q = load8_issue_all(qbase + o, 8u);
-      } else {
-        const uint32_t rem = Lm - b_uni;   // (the last reads of the batch: what is left of the mate decides which dwords exist)
-        w = load8_issue(sbase + o, rem);
-        if (HASQ) q = load8_issue(qbase + o, rem);
+  auto issue = [&](const uint32_t r, Raw8 (&w)[G], Raw8 (&q)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      w[g] = Raw8{0u, 0u, 0u, 0u};
+      q[g] = Raw8{0u, 0u, 0u, 0u};
+      if (act[g]) {
+        const uint64_t o = (uint64_t)r * Lm[g];
+        if (n32 - r > guard_reads) {
+          w[g] = load8_issue_all(sbase[g] + o, 8u);
+          if (HASQ) q[g] = load8_issue_all(qbase[g] + o, 8u);
+        } else {
+          const uint32_t rem = Lm[g] - bofs[g];   // (the last reads of the batch: what is left of the mate decides which dwords exist)
+          w[g] = load8_issue(sbase[g] + o, rem);
+          if (HASQ) q[g] = load8_issue(qbase[g] + o, rem);
+        }
       }
     }
+  };
+  auto fetch_groups = [&](const ReadMeta &m, Raw8 (&w)[G], Raw8 (&q)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) fetch_group<HASQ>(P, m, (uint32_t)lane + 64u * g, w[g], q[g]);
+  };
+  auto retire = [&](Raw8 (&w)[G], Raw8 (&q)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) { retire_loads(w[g]); retire_loads(q[g]); }
+  };
+  // valid characters among the bases this lane staged (their sum over the wave is the read's len, ReadAnalyzer.hpp:46-49)
+  auto lane_valid_bases = [&]() -> uint32_t {
+    uint32_t c = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) c += act[g] ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[(uint32_t)lane + 64u * g]) : 0u;
+    return c;
   };
 
   uint32_t read = blockIdx.x * WAVES + wave;
   if (read >= n32) return;
-  Raw8 w_cur, q_cur;
+  Raw8 w_cur[G], q_cur[G];
   ReadMeta m_cur{}, m_nxt{};
   if (UNI) {
     issue(read, w_cur, q_cur);
   } else {
     m_cur = fetch_meta(P, read);
-    fetch_group<HASQ>(P, m_cur, (uint32_t)lane, w_cur, q_cur);
+    fetch_groups(m_cur, w_cur, q_cur);
     const uint32_t n1 = n32 - read > stride ? read + stride : n32;
     m_nxt = fetch_meta(P, n1 < n32 ? n1 : read);
   }
-  retire_loads(w_cur);
-  retire_loads(q_cur);
+  retire(w_cur, q_cur);
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
   for (;;) {
     const uint32_t nxt = n32 - read > stride ? read + stride : n32;   // saturates at n32
     const bool have_nxt = nxt < n32;
-    Raw8 w_nxt = Raw8{0u, 0u, 0u, 0u}, q_nxt = Raw8{0u, 0u, 0u, 0u};
+    Raw8 w_nxt[G], q_nxt[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { w_nxt[g] = Raw8{0u, 0u, 0u, 0u}; q_nxt[g] = Raw8{0u, 0u, 0u, 0u}; }
     ReadMetaRaw r_nn{};
     uint32_t nn = n32;
     if (UNI) {
       if (have_nxt) issue(nxt, w_nxt, q_nxt);
     } else {
-      if (have_nxt) fetch_group<HASQ>(P, m_nxt, (uint32_t)lane, w_nxt, q_nxt);
+      if (have_nxt) fetch_groups(m_nxt, w_nxt, q_nxt);
       nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
       r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
       set_geometry(m_cur.L1, m_cur.L2);
@@ -265,7 +294,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     bool skip = false;
     if (!UNI) {
       const uint32_t ns = nk2 ? P2 + nk2 : nk1;
-      if (ns > S || n_groups > 64u) {   // does not fit this specialisation: the general kernel's queue (as process_read does)
+      if (ns > S || n_groups > 64u * G) {   // does not fit this specialisation: the general kernel's queue (as process_read does)
         if (lane == 0) {
           const ClassifyOut *O = out_ptrs(P);
           const uint32_t qi = atomicAdd(&O->counters[CTR_LONG], 1u);
@@ -279,29 +308,33 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
     // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
     uint32_t inv_real = 0u;   // invalid characters among the lane's bases that belong to the read
-    if (act) {
-      const uint32_t sh = w_cur.shn & 3u;
-      const uint32_t lo = __builtin_amdgcn_alignbyte(w_cur.d1, w_cur.d0, sh);
-      const uint32_t hi = __builtin_amdgcn_alignbyte(w_cur.d2, w_cur.d1, sh);
-      uint32_t c_lo, c_hi, i_lo, i_hi;
-      classify4(lo, c_lo, i_lo);
-      classify4(hi, c_hi, i_hi);
-      const uint32_t msb16 = (pack4(c_lo) << 8) | pack4(c_hi);           // first base in bits 15:14
-      // (bytes behind the mate's end are whatever follows in the buffer: their codes land at packed positions that no
-      // existing slot's window covers, and tail_inv marks them invalid)
-      uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4) | tail_inv;
-      if (HASQ) {
-        const uint32_t qs = q_cur.shn & 3u;
-        const uint32_t qlo = __builtin_amdgcn_alignbyte(q_cur.d1, q_cur.d0, qs);
-        const uint32_t qhi = __builtin_amdgcn_alignbyte(q_cur.d2, q_cur.d1, qs);
-        inv8 |= gather4(qmask4(qlo, P.mq)) | (gather4(qmask4(qhi, P.mq)) << 4);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (act[g]) {
+        const uint32_t gi = (uint32_t)lane + 64u * g;
+        const uint32_t sh = w_cur[g].shn & 3u;
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w_cur[g].d1, w_cur[g].d0, sh);
+        const uint32_t hi = __builtin_amdgcn_alignbyte(w_cur[g].d2, w_cur[g].d1, sh);
+        uint32_t c_lo, c_hi, i_lo, i_hi;
+        classify4(lo, c_lo, i_lo);
+        classify4(hi, c_hi, i_hi);
+        const uint32_t msb16 = (pack4(c_lo) << 8) | pack4(c_hi);           // first base in bits 15:14
+        // (bytes behind the mate's end are whatever follows in the buffer: their codes land at packed positions that no
+        // existing slot's window covers, and tail_inv marks them invalid)
+        uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4) | tail_inv[g];
+        if (HASQ) {
+          const uint32_t qs = q_cur[g].shn & 3u;
+          const uint32_t qlo = __builtin_amdgcn_alignbyte(q_cur[g].d1, q_cur[g].d0, qs);
+          const uint32_t qhi = __builtin_amdgcn_alignbyte(q_cur[g].d2, q_cur[g].d1, qs);
+          inv8 |= gather4(qmask4(qlo, P.mq)) | (gather4(qmask4(qhi, P.mq)) << 4);
+        }
+        uint32_t lsb = __builtin_bitreverse32(msb16);                      // lands in the high half
+        lsb = ((lsb >> 1) & 0x55555555u) | ((lsb & 0x55555555u) << 1);
+        reinterpret_cast<uint16_t *>(fw)[gi] = (uint16_t)(lsb >> 16);
+        reinterpret_cast<uint16_t *>(rv)[(rcap >> 3) - 1u - gi] = (uint16_t)msb16;
+        reinterpret_cast<uint8_t *>(vbits)[gi] = (uint8_t)(~inv8 & 0xFFu);
+        inv_real |= inv8 & ~tail_inv[g];
       }
-      uint32_t lsb = __builtin_bitreverse32(msb16);                      // lands in the high half
-      lsb = ((lsb >> 1) & 0x55555555u) | ((lsb & 0x55555555u) << 1);
-      reinterpret_cast<uint16_t *>(fw)[lane] = (uint16_t)(lsb >> 16);
-      reinterpret_cast<uint16_t *>(rv)[(rcap >> 3) - 1u - (uint32_t)lane] = (uint16_t)msb16;
-      reinterpret_cast<uint8_t *>(vbits)[lane] = (uint8_t)(~inv8 & 0xFFu);
-      inv_real = inv8 & ~tail_inv;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -313,7 +346,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (cutE < (uint32_t)U || JA_ROUNDS < U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
       if (__ballot(inv_real != 0u)) {
-        const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
+        const uint32_t len = wave_sum_u32(lane_valid_bases());
         thr_r = cov_threshold(P.c, len);
       }
     }
@@ -677,7 +710,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
             for (int j = 0; j < J; ++j) { rs[j] = 0; re[j] = 0; cur[j] = hit[j] ? (payload[j] & 0xFFFFu) : GENE_INF; }
           }
           // len = number of valid characters of the joined string (ReadAnalyzer.hpp:46-49)
-          const uint32_t len = wave_sum_u32(act ? (uint32_t)__builtin_popcount((uint32_t)reinterpret_cast<const uint8_t *>(vbits)[lane]) : 0u);
+          const uint32_t len = wave_sum_u32(lane_valid_bases());
           uint32_t best_cov = 0, best_nk = 0, n_best = 0, second_cov = 0;
           uint32_t best_id[SHK_INLINE_IDS] = {0, 0, 0, 0};
           // ---- k-way merge over the hit lists, ascending gene id (see process_read for the derivation) ----
@@ -951,14 +984,15 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     }   // !skip
     if (!have_nxt) break;
-    retire_loads(w_nxt);
-    retire_loads(q_nxt);
+    retire(w_nxt, q_nxt);
     if (!UNI) {
       retire_meta(r_nn);
       m_cur = m_nxt;
       m_nxt = meta_finish(r_nn);
     }
-    read = nxt; w_cur = w_nxt; q_cur = q_nxt;
+    read = nxt;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { w_cur[g] = w_nxt[g]; q_cur[g] = q_nxt[g]; }
   }
 }
 
@@ -970,7 +1004,7 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
                         else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
   switch (mode) {
   case PM_LDS_TAB:
-    if (lx) { if constexpr (U <= 5) LU(PM_LDS_TAB, 21); }   // (launch_classify_uni asks for it only where it is compiled)
+    if (lx) { if constexpr (U <= 5 || U == 10) LU(PM_LDS_TAB, 21); }   // (launch_classify_uni asks for it only where it is compiled)
     else if (big) LU(PM_LDS_TAB, 20);
     else LU(PM_LDS_TAB, 18);
     break;

@@ -384,7 +384,7 @@ static int classify_resident(Ctx *ctx, const shk_batch *b, uint32_t max_read_len
   const int long_mode = (max_read_len && max_slots <= fast_kernel_max_slots()) ? LONG_NONE_EXPECTED : LONG_UNKNOWN;
   int rc;
   const uint64_t hint_groups = (((uint64_t)max_read_len + 7) >> 3) * (paired ? 2 : 1);   // (no bound given: the table kernel queues what it cannot stage)
-  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr, UNI_ASK_DEVICE, 0, 0, hint_groups <= 64))) return rc;
+  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr, UNI_ASK_DEVICE, 0, 0, hint_groups <= uni_kernel_max_groups(max_slots)))) return rc;
   SHK_HIP(ctx, hipStreamSynchronize(st));
   bool redone = false;
   if ((rc = finish_classify(ctx, s, long_mode == LONG_NONE_EXPECTED, wc == nullptr, &redone))) return rc;
@@ -722,7 +722,7 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   // kernels' own criterion (classify.hip), so the device never has to be asked.  Only when the bound says there are any.
   uint32_t n_long = 0, long_slots = 0;
   const uint64_t groups_bound = ((max1 + 7) >> 3) + ((max2 + 7) >> 3);
-  const bool groups_fit = groups_bound <= 64;   // else the batch runs on classify_fast_kernel, which stages any number of groups
+  const bool groups_fit = groups_bound <= uni_kernel_max_groups(max_slots);   // else the batch runs on classify_fast_kernel, which stages any number of groups
   if (max_slots > fast_kernel_max_slots()) {
     const uint32_t cap = 64 * fast_kernel_unroll(std::min(max_slots, fast_kernel_max_slots()));
     for (uint64_t i = 0; i < n; ++i) {

@@ -232,6 +232,7 @@ int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *f
 bool uni_kernel_available(const Ctx *ctx);
 uint32_t fast_kernel_max_slots();
 uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
+uint32_t uni_kernel_max_groups(uint32_t max_slots);   // staging groups per pair classify_uni_kernel can take at that specialisation
 
 struct Ctx {
   shk_params prm{};

@@ -646,9 +646,10 @@ def test_gene_counts_allreduce_over_rccl(oracle, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("read_len,paired,q", [(60, True, 0), (100, True, 20), (125, True, 0), (170, True, 0), (200, True, 30),
-                                               (250, True, 0), (300, False, 0), (520, False, 20), (64, False, 0)])
+                                               (250, True, 0), (300, False, 0), (520, False, 20), (64, False, 0),
+                                               (300, True, 0), (300, True, 20), (310, True, 0), (600, False, 0)])
 def test_every_kernel_specialisation(oracle, read_len, paired, q):
-    """fixed-length batches that select each unroll U in {2,3,4,5,6,8} of the fast kernel (paired and single-end,
+    """fixed-length batches that select each unroll U in {2,3,4,5,6,8,10} of the fast kernel (paired and single-end,
     with and without the quality mask); lengths just above a specialisation's capacity go to the general kernel"""
     rng = np.random.default_rng(1000 + read_len)
     genes = synth.make_genes(rng, 12, 800, 3000, share_every=4)
@@ -668,6 +669,45 @@ def test_every_kernel_specialisation(oracle, read_len, paired, q):
         bb = synth.batch_from_lists(m1, None, q1, None)
     _compare_classify(o, h, bb)
     assert h.timing()["last_n_long"] == 1
+
+
+@pytest.mark.parametrize("env,n_genes,bf_bits", [({}, 1, 1 << 33), ({"SHK_NO_LDS_TABLE": "1"}, 1, 1 << 33), ({}, 12, 1 << 26),
+                                                 ({"SHK_NO_LDS_SUMMARY": "1"}, 12, 1 << 26), ({"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"}, 12, 1 << 26),
+                                                 ({"SHK_PROBE": "bitvector"}, 12, 1 << 26), ({"SHK_NO_ANCHOR": "1", "SHK_NO_LDS_SUMMARY": "1"}, 12, 5 << 24)])
+def test_long_pairs_2x300(oracle, monkeypatch, env, n_genes, bf_bits):
+    """2 x 300 bp (MiSeq): 588 slots and 76 staging groups per pair -- the U = 10 specialisation of classify_uni_kernel with two
+    staging groups per lane (round 2 sent such pairs to the general kernel), on every kind of index: the exact table in LDS, the
+    LDS summary, the table modes with the anchored extension, plain filter words; uniform and trimmed batches, host and
+    device-resident entry points, -q; pairs just inside and just outside the specialisation"""
+    for name, v in env.items():
+        monkeypatch.setenv(name, v)
+    rng = np.random.default_rng(300 + n_genes)
+    genes = synth.make_genes(rng, n_genes, 20_000 if n_genes == 1 else 900, 20_000 if n_genes == 1 else 3500, share_every=3)
+    for q in (0, 20):
+        o, h, _ = _build_both(oracle, genes, k=17, bf_bits=bf_bits, min_quality=q)
+        for L, ragged in ((300, False), (300, True), (312, False), (328, False), (329, False), (600, False)):
+            paired = L != 600
+            if ragged:
+                b = _sequenced_pairs(rng, genes, 500, L, L, True, q > 0, 0.01, 0.002, 0.002)
+            else:
+                b = synth.make_reads(rng, genes, 500, read_len=L, paired=paired, on_target=0.7, qual=q > 0, n_rate=0.003)
+            goff, _ = _compare_classify(o, h, b)
+            assert goff[-1] > 0
+            if L == 329:
+                assert h.timing()["last_n_long"] == 500       # 2 x 329: 336 + 313 = 649 slots, beyond the largest specialisation (2 x 328 fills its 640 exactly)
+            elif not ragged:
+                assert h.timing()["last_n_long"] == 0
+            # the same batch resident in HBM (uniformity decided on the device)
+            dev = torch.device("cuda:0")
+            t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in b.items()}
+            pt = {kk: (v.data_ptr() if v is not None else 0) for kk, v in t.items()}
+            n = len(b["off1"]) - 1
+            r = h.classify_device(n, pt["seq1"], pt["off1"], pt["seq2"], pt["off2"], pt["qual1"], pt["qual2"], max_read_len=L)
+            from shark_amd.capi import hip_memcpy_dtoh
+            dg = np.empty(n + 1, np.uint32)
+            hip_memcpy_dtoh(dg, r.gene_off, dg.nbytes)
+            assert np.array_equal(dg, goff)
+        h.close()
 
 
 @pytest.mark.gpu
