@@ -102,6 +102,10 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_ANCH_CUT
 #define SHK_ANCH_CUT 0
 #endif
+// slots per mate that the anchored extension samples through the table (a power of two, at most 16)
+#ifndef SHK_ANCH_SAMPLE
+#define SHK_ANCH_SAMPLE 4
+#endif
 // MODE: PM_LDS_TAB(_MOD) as described above; PM_TAB(_MOD) / PM_TAB_SUM for indices too dense for the LDS summary -- there a
 // probe costs memory traffic, so a slot's existence and validity are settled BEFORE its probe (as in process_read), and
 // only real k-mers (that pass the L2-resident summary, PM_TAB_SUM) read their bucket.
@@ -687,6 +691,61 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           multi[j] = (slo[j] >> 31) != 0u;
         }
         if (!__ballot(any2)) return FINAL;
+        // ---- one gene only, or one gene far ahead?  The usual read: (almost) every k-mer found belongs to a single-gene list of one
+        // and the same gene g.  With nothing else found, ReadAnalyzer's map has the one entry g: its coverage is the union of the
+        // hits' intervals, its k-mer count their number -- no merge, no lists (exact, FINAL or not).  With a few other k-mers found
+        // (a large reference: every fiftieth k-mer of a read is also some other gene's), bounds settle the EARLY decision without
+        // reading a list: g's coverage is at least what its single-gene hits cover, any other gene's at most what all other hits
+        // cover.  If the first passes c * len and exceeds the second by more than the slots not settled yet can still cover, g is
+        // the read's only association whatever the lists say.
+        {
+          uint64_t Sg[J];
+          uint32_t p0 = 0;
+          bool have0 = false;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            Sg[j] = __ballot(hit[j] & !multi[j]);
+            if (!have0 && Sg[j] != 0ull) {
+              p0 = (uint32_t)__builtin_amdgcn_readlane((int)payload[j], (int)__builtin_ctzll(Sg[j]));
+              have0 = true;
+            }
+          }
+          bool lane_other = false;
+#pragma unroll
+          for (int j = 0; j < J; ++j) lane_other |= hit[j] & (multi[j] | (payload[j] != p0));
+          const bool alone = __ballot(lane_other) == 0ull;   // (then Sg[] are g's hits already)
+          if (have0 && (alone || !FINAL)) {
+            uint32_t cov = 0, oth = 0;
+            if (!alone) {
+              uint64_t Op = 0ull;
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                const bool mine = hit[j] & !multi[j] & (payload[j] == p0);
+                Sg[j] = __ballot(mine);
+                const uint64_t Oc = __ballot(hit[j] & !mine);
+                oth += cover(Oc, Op);
+                Op = Oc;
+              }
+              oth += cover(0ull, Op);
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) cov += cover(Sg[j], j ? Sg[j - 1] : 0ull);
+            cov += cover(0ull, Sg[J - 1]);
+            const uint32_t len = wave_sum_u32(lane_valid_bases());
+            const bool pass = (double)cov >= H->c * (double)len;
+            // FINAL (alone): the threshold decides (one gene: --single changes nothing).  Else: g has to lead by more than ub_rest
+            const bool out1 = pass && (FINAL || cov > oth + ub_rest);
+            if (out1 && lane == 0 && !SHK_ABL(P, 64u)) {
+              const ClassifyOut *O = H->out;
+              O->count[read] = 1u;
+              uint2 pk;
+              pk.x = p0 & 0xFFFFu;
+              pk.y = 0u;
+              *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+            }
+            if (alone || out1) return FINAL || out1;
+          }
+        }
         {
           bool lane_multi = false;
 #pragma unroll
@@ -787,7 +846,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // drawn from a gene matches the reference base for base around such a place, so most of its k-mers are the reference's k-mers
     // at the neighbouring positions -- and what a probe of those returns is stored per reference position (`refpay`), contiguously:
     // 64 slots of a round read 256 bytes of it and 24 bytes of the packed reference instead of 64 buckets at 64 hashed addresses.
-    //  (1) sample: eight slots spread over each mate, one per lane, probed through the table as ever (one hash per lane);
+    //  (1) sample: SHK_ANCH_SAMPLE (four) slots spread over each mate, one per lane, probed through the table as ever (one hash per lane;
+    //      measured on the configs[2] index per 10 M pairs at 0 / 50 / 100 % on-target: 8 slots 36.4 / 28.7 / 27.9 ms, 4: 34.5 / 27.5 / 27.8, 2: 33.5 / 26.5 / 28.5);
     //  (2) the first match of each mate gives that mate's anchor: reference position + relative orientation;
     //  (3) every slot of an anchored mate is compared with the reference k-mer at its implied position, as a 2k-bit compare of the
     //      read's window with the reference's.  Equal k-mers have equal filter positions, hence equal table slots: the slot is
@@ -801,11 +861,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       KernargParams H = kernarg_params();
       const uint32_t ref_total = H->ref_total;
       if (!ref_total) return false;
-      // (1)
-      const uint32_t st1 = nk1 > 8u ? nk1 >> 3 : 1u, st2 = nk2 > 8u ? nk2 >> 3 : 1u;
-      const bool sm2 = ((uint32_t)lane & 8u) != 0u;
-      const uint32_t in_mate = ((uint32_t)lane & 7u) * (sm2 ? st2 : st1);
-      const bool s_exists = ((uint32_t)lane < 16u) & (in_mate < (sm2 ? nk2 : nk1));
+      // (1)  (SHK_ANCH_SAMPLE slots per mate, a power of two)
+      constexpr uint32_t NS = SHK_ANCH_SAMPLE;
+      const uint32_t st1 = nk1 > NS ? nk1 / NS : 1u, st2 = nk2 > NS ? nk2 / NS : 1u;
+      const bool sm2 = ((uint32_t)lane & NS) != 0u;
+      const uint32_t in_mate = ((uint32_t)lane & (NS - 1u)) * (sm2 ? st2 : st1);
+      const bool s_exists = ((uint32_t)lane < 2u * NS) & (in_mate < (sm2 ? nk2 : nk1));
       const uint32_t ss = s_exists ? (sm2 ? P2 + in_mate : in_mate) : 0u;
       uint64_t s_fwd, s_rc;
       {
@@ -850,9 +911,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       bool aopp[2] = {false, false}, ahave[2] = {false, false};
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(SH >> (8 * m)) & 0xFFu);
+        const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(SH >> (NS * m)) & ((1u << NS) - 1u));
         if (mask) {
-          const int ln = __builtin_amdgcn_readfirstlane(__builtin_ctz(mask) + 8 * m);
+          const int ln = __builtin_amdgcn_readfirstlane(__builtin_ctz(mask) + (int)NS * m);
           const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)s_slot, ln);
           const uint32_t a = H->anchor[slot];
           ahave[m] = a != 0xFFFFFFFFu;
