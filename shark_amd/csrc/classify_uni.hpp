@@ -94,6 +94,10 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_NO_TOL
 #define SHK_NO_TOL 0
 #endif
+// the bound cut behind the L2-resident summary as well (-DSHK_CUT_SUM=0: not)
+#ifndef SHK_CUT_SUM
+#define SHK_CUT_SUM 1
+#endif
 // (-DSHK_NO_ANCHOR=1: a build without the anchored extension, for A/B timing; at run time SHK_NO_ANCHOR=1 when the index is built)
 #ifndef SHK_NO_ANCHOR
 #define SHK_NO_ANCHOR 0
@@ -121,7 +125,9 @@ struct UniGeom {
   static constexpr int WAVES = (pm_lds(MODE) && LSL >= 20) ? (LSL == 21 ? SHK_LX_WAVES : 16) : 8;
   static constexpr int THREADS = WAVES * 64;
   // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes likewise (SHK_TAB_WAVES, classify_common.hpp)
-  static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : (U > 8 ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));   // (U = 10: 128 VGPRs)
+  // (U = 10, and the table modes beyond U = 5 -- they carry the anchored extension --: 4 waves per SIMD, 128 VGPRs; at 80 the U = 8 table
+  //  kernels spilled 50-130 VGPRs)
+  static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : ((U > 8 || (U > 5 && !pm_lds(MODE))) ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));
   static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (LX ? LTAB_BYTES * 8u : (1u << LSL)) : 0u;   // what the workgroup keeps in LDS
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };
@@ -136,10 +142,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
-  // the bound cut is compiled in except behind the L2-resident summary: there an off-target pair is already cheap (the summary
-  // rejects its probes without memory traffic) and the second dependent step costs on-target pairs more than the cut saves
-  // (250 / 1 000 genes: 29.0 / 33.9 -> 31.8 / 35.1 ms per 10 M pairs with it)
-  constexpr bool CUT = !SUM && !SHK_NO_CUT;
+  // the bound cut.  (Behind the L2-resident summary it used to be left out: an off-target pair is cheap there and the second
+  // dependent step cost on-target pairs more than the cut saved.  Since the anchored extension takes the on-target pairs off this
+  // path it pays: 250 / 1 000 genes at 0 % on-target 10.1 / 12.2 -> 8.2 / 9.8 ms per 10 M pairs, at 50 % 11.5 / 12.6 -> 11.2 / 12.0,
+  // at 100 % 14.3 / 14.8 -> 14.8 / 15.3)
+  constexpr bool CUT = (!SUM || SHK_CUT_SUM) && !SHK_NO_CUT;
   constexpr bool TOL = CUT && !pm_lds(MODE) && !SHK_NO_TOL;   // table modes: matches are counted, and there is a second cut point
   constexpr bool ACCEPT = !SHK_NO_ACCEPT;                      // the early decision (vote<J> with J < U)
   constexpr bool ANCH = !pm_lds(MODE) && !SHK_NO_ANCHOR;        // table modes: the anchored extension (when the index carries ref2 / refpay / anchor)
