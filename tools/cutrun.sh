@@ -1,1 +1,1 @@
-for v in default cutsum; do echo "VARIANT $v"; if [ $v = default ]; then unset SHK_LIB_PATH; else export SHK_LIB_PATH=$PWD/tools/variants/$v.so; fi; python tools/landscape.py --genes 250,1000,5000 --ot 0.0,0.5,1.0 --reps 3 2>/dev/null; done
+python tools/landscape.py --genes 1000,60000 --read-len 250 --ot 0.5 --pairs 5000000 --reps 3 2>/dev/null
