@@ -1,1 +1,2 @@
-python tools/landscape.py --genes 1000,60000 --read-len 250 --ot 0.5 --pairs 5000000 --reps 3 2>/dev/null
+python tools/landscape.py --genes 60,100,150 --ot 0.0,0.5,1.0 --reps 3 --ab 2>/dev/null
+for g in 1 100; do GENES=$g python tools/ragged_rate.py 2>/dev/null | tail -1; done

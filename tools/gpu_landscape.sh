@@ -1,7 +1,14 @@
 #!/bin/bash
-# the landscape table of profiles/README.md: kernel time per 10 M pairs over index sizes (2^33-bit filter), uniform and trimmed reads
+# the landscape tables of profiles/README.md: kernel time per 10 M pairs over index sizes (2^33-bit filter; 60 000 genes: 2^36), on-target rates,
+# with and without the anchored extension, read lengths, trimmed reads
 export TMPDIR=/tmp
-for g in 10 60 100 150 250 1000 10000; do
-  python tests/scale_check.py --genes $g --bf-log2 33 --skip-bitvector --oracle-pairs 0 2>/dev/null | grep kernel_ms | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('uniform', $g, d['info']['n_set_bits'], d['mode'], d['kernel_ms'])"
-done
-for g in 1 100 60000; do GENES=$g python tools/ragged_rate.py 2>/dev/null | tail -1; done
+out=${1:-gpurun_out/landscape}; mkdir -p $out
+python tools/landscape.py --genes 1,10,60,100,150,250,1000,10000,60000 --ot 0.5 > $out/sizes.jsonl 2>/dev/null
+python tools/landscape.py --genes 1,100,1000,60000 --ot 0.0,1.0 > $out/on_target.jsonl 2>/dev/null
+python tools/landscape.py --genes 250,1000,10000,60000 --ot 0.5 --ab > $out/anchor_ab.jsonl 2>/dev/null
+python tools/landscape.py --genes 1,1000,60000 --ot 0.5 --read-len 300 --pairs 5000000 > $out/len300.jsonl 2>/dev/null
+python tools/landscape.py --genes 1,1000,60000 --ot 0.5 --read-len 250 --pairs 5000000 > $out/len250.jsonl 2>/dev/null
+python tools/landscape.py --genes 1,1000,60000 --ot 0.5 --read-len 100 > $out/len100.jsonl 2>/dev/null
+python tools/landscape.py --genes 60000 --ot 0.5 --k 31 --q 20 > $out/k31q20.jsonl 2>/dev/null
+for g in 1 100 1000 60000; do GENES=$g python tools/ragged_rate.py 2>/dev/null | tail -1; done > $out/ragged.jsonl
+cat $out/*.jsonl
