@@ -893,7 +893,9 @@ int main(int argc, char *argv[])
     std::vector<double> t_reader(n_readers, 0.0);
     // a reader must not run ahead of the drain without bound: at most `window` batches beyond the one being written
     // the ring: a batch per reader, what the GPUs hold in flight, and a few being turned into text or waiting for their turn to be written
-    const uint64_t window = (uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 6;
+    // (never more batches than the sample has, plus what the serial reader and the GPU pipelines need: --batch may be large)
+    const uint64_t window = std::min<uint64_t>((uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 6,
+                                               n_par_batches + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 2);
     {
       uint64_t widest = 0;
       for (uint64_t i = 0; i < n_par_batches; ++i) {
