@@ -278,7 +278,7 @@ struct ReadBatch {
   // associated reads are fetched from the files again by the output stage
   bool lean = false;
   shk::BatchFilePart part1, part2;
-  std::shared_ptr<struct FormattedBatch> text;   // what the output stage will write for this batch (filled by a formatter thread)
+  std::shared_ptr<const struct FormattedBatch> text;   // what the output stage will write for this batch (filled by a formatter thread)
   // result
   std::vector<uint32_t> gene_off;
   std::vector<uint16_t> gene_ids;
@@ -567,6 +567,85 @@ class ReadAnalyzer {
 // call -- and clears previd -- every 50 000 input reads (main.cpp:215,
 // ReadOutput.hpp:39), so 50 000-read chunks are independent and are formatted
 // in parallel; the text is then written in input order.
+// An output FASTQ file written at explicit offsets: the thread that emits the batches in order only assigns each piece its
+// place in the file; the bytes are written by a few helper threads (pwrite), so an on-target-heavy sample -- gigabytes of output
+// FASTQ -- is not throttled by one thread's write calls.  Not seekable (a pipe, a terminal): written in place, in order.
+class OffsetWriter {
+ public:
+  OffsetWriter() = default;
+  bool open(const std::string &path, unsigned helpers)
+  {
+    fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd_ < 0) return false;
+    seekable_ = lseek(fd_, 0, SEEK_CUR) != (off_t)-1;
+    if (seekable_)
+      for (unsigned i = 0; i < std::max(1u, helpers); ++i) th_.emplace_back([this] { work(); });
+    return true;
+  }
+  bool is_open() const { return fd_ >= 0; }
+  // `keep` keeps the bytes alive until they are written
+  void append(const char *p, size_t n, const std::shared_ptr<const void> &keep)
+  {
+    if (!n) return;
+    if (!seekable_) { write_all(p, n, (uint64_t)-1); return; }
+    {
+      std::unique_lock<std::mutex> l(m_);
+      space_.wait(l, [&] { return q_.size() < 256; });   // (the text of at most that many pieces waits to be written)
+      q_.push_back(Job{p, n, off_, keep});
+    }
+    off_ += n;
+    cv_.notify_one();
+  }
+  bool close()
+  {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      closing_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+    th_.clear();
+    const bool ok = !failed_.load() && (fd_ < 0 || ::close(fd_) == 0);
+    fd_ = -1;
+    return ok;
+  }
+
+ private:
+  struct Job { const char *p; size_t n; uint64_t off; std::shared_ptr<const void> keep; };
+  void write_all(const char *p, size_t n, uint64_t off)
+  {
+    while (n) {
+      const ssize_t w = off == (uint64_t)-1 ? ::write(fd_, p, n) : ::pwrite(fd_, p, n, (off_t)off);
+      if (w <= 0) { failed_ = true; return; }
+      p += w; n -= (size_t)w;
+      if (off != (uint64_t)-1) off += (uint64_t)w;
+    }
+  }
+  void work()
+  {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !q_.empty() || closing_; });
+        if (q_.empty()) return;
+        j = std::move(q_.front());
+        q_.pop_front();
+        space_.notify_one();
+      }
+      write_all(j.p, j.n, j.off);
+    }
+  }
+  int fd_ = -1;
+  bool seekable_ = false, closing_ = false;
+  uint64_t off_ = 0;
+  std::atomic<bool> failed_{false};
+  std::mutex m_;
+  std::condition_variable cv_, space_;
+  std::deque<Job> q_;
+  std::vector<std::thread> th_;
+};
+
 // The text is produced per batch by any thread, in any order (format); the batches are then written in input order
 // (emit), which is also where the one thing that crosses a batch boundary is settled: whether the first associated read
 // of a batch that starts in the middle of a 50 000-read chunk repeats the previous batch's last read name.
@@ -582,7 +661,7 @@ struct FormattedBatch {
 
 class ReadOutput {
  public:
-  ReadOutput(FILE *out1, FILE *out2, const std::vector<std::string> &legend) : out1_(out1), out2_(out2), legend_(legend) {}
+  ReadOutput(OffsetWriter *out1, OffsetWriter *out2, const std::vector<std::string> &legend) : out1_(out1), out2_(out2), legend_(legend) {}
   bool failed() const { return failed_.load(); }
 
   // thread-safe; nothing is written
@@ -652,19 +731,20 @@ class ReadOutput {
   }
 
   // in input order, one thread
-  void emit(const FormattedBatch &f)
+  void emit(const std::shared_ptr<const FormattedBatch> &fp)
   {
+    const FormattedBatch &f = *fp;
     for (const FormattedSegment &sg : f.segs) {
       fwrite(sg.ssv.data(), 1, sg.ssv.size(), stdout);
       // (ReadOutput.hpp:44-48: a read's FASTQ records are printed unless its name equals the one printed just before it)
       const bool head_repeats = sg.carries && sg.has_assoc && sg.head_id == carry_;
       if (out1_) {
-        if (!head_repeats) fwrite(sg.head1.data(), 1, sg.head1.size(), out1_);
-        fwrite(sg.fq1.data(), 1, sg.fq1.size(), out1_);
+        if (!head_repeats) out1_->append(sg.head1.data(), sg.head1.size(), fp);
+        out1_->append(sg.fq1.data(), sg.fq1.size(), fp);
       }
       if (out2_) {
-        if (!head_repeats) fwrite(sg.head2.data(), 1, sg.head2.size(), out2_);
-        fwrite(sg.fq2.data(), 1, sg.fq2.size(), out2_);
+        if (!head_repeats) out2_->append(sg.head2.data(), sg.head2.size(), fp);
+        out2_->append(sg.fq2.data(), sg.fq2.size(), fp);
       }
       carry_ = sg.has_assoc ? sg.last_id : (sg.carries ? carry_ : std::string());
     }
@@ -693,7 +773,7 @@ class ReadOutput {
     else if (i < qual.size()) f.append(qual.at(i), qual.len(i));
     f.push_back('\n');
   }
-  FILE *out1_, *out2_;
+  OffsetWriter *out1_, *out2_;
   const std::vector<std::string> &legend_;
   mutable std::atomic<bool> failed_{false};   // a record could not be read back from its file (I/O error)
   std::string carry_;   // previd at the end of the previous batch (only used when a batch starts mid-chunk)
@@ -830,11 +910,13 @@ int main(int argc, char *argv[])
   {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, hw);
-    FILE *out1 = fopen(opt.out1_path.c_str(), "w");
-    FILE *out2 = (opt.paired_flag && opt.out2_path != "") ? fopen(opt.out2_path.c_str(), "w") : nullptr;
+    // (the reference opens its outputs unchecked and writes nothing to a file it could not open, main.cpp:99-106: same here)
+    OffsetWriter w1, w2;
+    const unsigned write_helpers = 3;   // (six per file measured slower on a 16-core share: readers, formatters and writers compete)
+    w1.open(opt.out1_path, write_helpers);
+    if (opt.paired_flag && opt.out2_path != "") w2.open(opt.out2_path, write_helpers);
+    OffsetWriter *out1 = w1.is_open() ? &w1 : nullptr, *out2 = w2.is_open() ? &w2 : nullptr;
     ReadOutput ro(out1, out2, legend_ID);
-    if (out1) setvbuf(out1, nullptr, _IOFBF, 1 << 22);
-    if (out2) setvbuf(out2, nullptr, _IOFBF, 1 << 22);
     setvbuf(stdout, nullptr, _IOFBF, 1 << 22);
 
     // per-GPU input queues; batch i goes to GPU i mod N
@@ -1103,8 +1185,9 @@ int main(int argc, char *argv[])
         std::unique_ptr<ReadBatch> b;
         while (to_format.pop(b)) {
           if (b->rc == SHK_OK) {
-            b->text = std::make_shared<FormattedBatch>();
-            ro.format(*b, *b->text);
+            std::shared_ptr<FormattedBatch> text = std::make_shared<FormattedBatch>();
+            ro.format(*b, *text);
+            b->text = text;
           }
           hand_over(std::move(b));
         }
@@ -1154,7 +1237,7 @@ int main(int argc, char *argv[])
         failed = b->rc;
       } else {
         auto t0 = std::chrono::steady_clock::now();
-        ro.emit(*b->text);
+        ro.emit(b->text);
         t_out += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       pool.release(std::move(b));
@@ -1186,8 +1269,13 @@ int main(int argc, char *argv[])
                 << " batches, " << tr << " thread-seconds), serial reader: " << (fs ? "index " + std::to_string(fs->t_index) + " s (" + fs->stage_report() + "), fill " + std::to_string(fs->t_fill) + " s, serial " + std::to_string(fs->t_serial) + " s" : std::string("not needed"))
                 << "; classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
     }
-    if (out1) fclose(out1);
-    if (out2) fclose(out2);
+    bool written = true;
+    if (out1) written = w1.close() && written;
+    if (out2) written = w2.close() && written;
+    if (!written) {
+      std::cerr << "shark: cannot write the output FASTQ" << std::endl;
+      return EXIT_FAILURE;
+    }
     if (failed) {
       std::cerr << "shark: classification failed: " << shk_strerror(failed) << std::endl;
       return EXIT_FAILURE;
