@@ -1,4 +1,3 @@
-for v in default tabw4; do echo "VARIANT $v"; if [ $v = default ]; then unset SHK_LIB_PATH; else export SHK_LIB_PATH=$PWD/tools/variants/$v.so; fi
-python tools/landscape.py --genes 1000,60000 --ot 0.0,0.5,1.0 --reps 3 2>/dev/null
-python tools/landscape.py --genes 60000 --ot 0.5 --k 31 --q 20 --reps 3 2>/dev/null
-done
+python tools/landscape.py --genes 1 --ot 0.0,0.5,1.0 --reps 4 2>/dev/null
+python tools/landscape.py --genes 1000,60000 --ot 0.5 --reps 3 2>/dev/null
+python tools/landscape.py --genes 1 --ot 0.5 --read-len 300 --pairs 5000000 --reps 3 2>/dev/null
