@@ -889,6 +889,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         s_rc = ~x & kmer_mask;
       }
       bool s_ok = s_exists && slot_valid(ss);
+      if (!__ballot(s_ok)) return false;   // (no sampled slot is a valid k-mer -- masked qualities, N: nothing to hash)
       const bool s_isrc = !(s_fwd < s_rc);
       const uint64_t s_hash = xxh64_u64(s_isrc ? s_rc : s_fwd);
       const uint64_t s_pos = POW2 ? (s_hash & P.bf_mask) : bf_pos_np(s_hash, P);

@@ -156,7 +156,7 @@ struct BatchFilePart {
   int fd = -1;
   uint64_t off0 = 0, off1 = 0;            // byte range of the batch in the file
   uint32_t fixed_width = 0;               // != 0: every record of this batch has this many bytes (record r starts at off0 + r * width)
-  std::vector<uint32_t> rec_off;          // else: start of record r relative to off0, n + 1 entries
+  std::vector<uint64_t> rec_off;          // else: start of record r relative to off0, n + 1 entries
   uint64_t start_of(size_t r) const { return fixed_width ? (uint64_t)r * fixed_width : rec_off[r]; }
 };
 
@@ -213,11 +213,11 @@ inline size_t lean_parse_range(int fd, uint64_t off0, uint64_t off1, size_t want
         if (all_hint) {
           // the first record of another shape: from here on record starts are kept explicitly
           part.rec_off.resize(r);
-          for (size_t i = 0; i < r; ++i) part.rec_off[i] = (uint32_t)(i * hw);
+          for (size_t i = 0; i < r; ++i) part.rec_off[i] = (uint64_t)i * hw;
           all_hint = false;
         }
       }
-      if (!all_hint) part.rec_off.push_back((uint32_t)(buf_file + at - off0));
+      if (!all_hint) part.rec_off.push_back(buf_file + at - off0);
       if (so + f.seq_len > seq.size()) { seq.resize((size_t)((so + f.seq_len) * 2 + 64)); if (with_qual) qual.resize(seq.size()); }
       memcpy(seq.data() + so, b + at + f.seq_off, f.seq_len);
       if (with_qual) memcpy(qual.data() + so, b + at + f.qual_off, f.seq_len);
@@ -236,7 +236,7 @@ inline size_t lean_parse_range(int fd, uint64_t off0, uint64_t off1, size_t want
   if (r == want) {
     seq.resize((size_t)so);
     if (with_qual) qual.resize((size_t)so);
-    if (all_hint) part.fixed_width = hw; else part.rec_off.push_back((uint32_t)(off1 - off0));
+    if (all_hint) part.fixed_width = hw; else part.rec_off.push_back(off1 - off0);
   }
   return r;
 }

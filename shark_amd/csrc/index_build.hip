@@ -587,66 +587,68 @@ int build_index(Ctx *ctx)
           }
         }
         table_bytes = slots * sizeof(uint64_t);
-        // the reference itself, for the anchored extension of the table kernels (SHK_NO_ANCHOR=1: not built; the tests run both)
+        // the reference itself, for the anchored extension of the table kernels (SHK_NO_ANCHOR=1: not built; the tests run both).
+        // Optional: when its memory cannot be had the index is complete without it.
         ix.ref_total = 0;
         if (!wrap && total > 0 && total < (1ull << 31) && !getenv("SHK_NO_ANCHOR")) {
           const uint64_t n_dw = (total + 15) / 16;
-          uint32_t *d_lost = nullptr;
-          BI_HIP(hipMalloc((void **)&ix.ref2, (n_dw + 4) * sizeof(uint32_t)));
-          BI_HIP(hipMemsetAsync(ix.ref2 + n_dw, 0, 4 * sizeof(uint32_t), st));
-          BI_HIP(hipMalloc((void **)&ix.refpay, (total + 1) * sizeof(uint32_t)));
-          BI_HIP(hipMalloc((void **)&ix.anchor, (slots + 2) * sizeof(uint32_t)));
-          BI_HIP(hipMemsetAsync(ix.anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
-          BI_HIP(hipMalloc((void **)&d_lost, sizeof(uint32_t)));
-          BI_HIP(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), st));
-          hipLaunchKernelGGL(ref_pack2_kernel, dim3(grid_for(n_dw, 256)), dim3(256), 0, st, d_bytes, total, ix.ref2, n_dw);
-          BI_HIP(hipGetLastError());
-          hipLaunchKernelGGL(ref_anchor_kernel, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st, d_bytes, total, d_rec_off, n_rec, k, ix.bf_bits,
-                             ix.bf_bits - 1, ix.pow2 ? 1 : 0, (const uint64_t *)ix.tab, lg, ix.refpay, ix.anchor, d_lost);
-          BI_HIP(hipGetLastError());
-          uint32_t h_lost = 0;
-          BI_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-          BI_HIP(hipStreamSynchronize(st));
+          uint32_t *d_lost = nullptr, *d_lens = nullptr;
+          uint64_t *d_stmp = nullptr;
+          ListEntry *ent_all = nullptr;
+          uint16_t *ids_all = nullptr;
+          auto drop_anchor = [&]() {
+            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.anchor);
+            ix.ref2 = ix.refpay = ix.anchor = nullptr;
+            ix.ref_total = 0;
+          };
+          bool have = hipMalloc((void **)&ix.ref2, (n_dw + 4) * sizeof(uint32_t)) == hipSuccess &&
+                      hipMalloc((void **)&ix.refpay, (total + 8) * sizeof(uint32_t)) == hipSuccess &&   // (+8: read 16 bytes at a time by tools)
+                      hipMalloc((void **)&ix.anchor, (slots + 2) * sizeof(uint32_t)) == hipSuccess &&
+                      hipMalloc((void **)&d_lost, sizeof(uint32_t)) == hipSuccess;
+          if (!have) { (void)hipGetLastError(); drop_anchor(); }
+          if (have) {
+            BI_HIP(hipMemsetAsync(ix.ref2 + n_dw, 0, 4 * sizeof(uint32_t), st));
+            BI_HIP(hipMemsetAsync(ix.refpay + total, 0xFF, 8 * sizeof(uint32_t), st));
+            BI_HIP(hipMemsetAsync(ix.anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
+            BI_HIP(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(ref_pack2_kernel, dim3(grid_for(n_dw, 256)), dim3(256), 0, st, d_bytes, total, ix.ref2, n_dw);
+            BI_HIP(hipGetLastError());
+            hipLaunchKernelGGL(ref_anchor_kernel, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st, d_bytes, total, d_rec_off, n_rec, k, ix.bf_bits,
+                               ix.bf_bits - 1, ix.pow2 ? 1 : 0, (const uint64_t *)ix.tab, lg, ix.refpay, ix.anchor, d_lost);
+            BI_HIP(hipGetLastError());
+            uint32_t h_lost = 0;
+            BI_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            BI_HIP(hipStreamSynchronize(st));
+            if (h_lost != 0) { have = false; drop_anchor(); }   // (a key the table does not hold: leave the extension out rather than trust it)
+          }
           (void)hipFree(d_lost);
           // multi-gene lists along the reference (see ref_multi_len_kernel); left out -- the lists then stay where the ranks point --
-          // when the copies would not fit the 32-bit list offsets or the 30-bit payload
-          bool ref_lists = false;
-          if (h_lost == 0 && n_set + 1 + total + 1 <= TAB_PAYLOAD) {
-            uint32_t *d_lens = nullptr;
-            uint64_t *d_stmp = nullptr;
-            BI_HIP(hipMalloc((void **)&d_lens, (total + 1) * sizeof(uint32_t)));
-            BI_HIP(hipMalloc((void **)&d_stmp, scan_temp_words(total + 1) * sizeof(uint64_t)));
+          // when the copies would not fit the 32-bit list offsets or the 30-bit payload, or their memory cannot be had
+          if (have && n_set + 1 + total + 1 <= TAB_PAYLOAD && hipMalloc((void **)&d_lens, (total + 1) * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&d_stmp, scan_temp_words(total + 1) * sizeof(uint64_t)) == hipSuccess) {
             hipLaunchKernelGGL(ref_multi_len_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, (const uint32_t *)ix.refpay, total, (const ListEntry *)ix.ent, d_lens);
             BI_HIP(hipGetLastError());
             const uint64_t *d_R = exclusive_scan_u32(d_lens, d_lens, total + 1, d_stmp, st);
             uint64_t R = 0;
             BI_HIP(hipMemcpyAsync(&R, d_R, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
             BI_HIP(hipStreamSynchronize(st));
-            if (tot_idx + R + 8 < (1ull << 32) && R <= 16 * total) {
-              ListEntry *ent_all = nullptr;
-              uint16_t *ids_all = nullptr;
-              BI_HIP(hipMalloc((void **)&ent_all, (n_set + 1 + total + 1) * sizeof(ListEntry)));
-              BI_HIP(hipMalloc((void **)&ids_all, (tot_idx + R + 8) * sizeof(uint16_t)));
+            if (tot_idx + R + 8 < (1ull << 32) && R <= 16 * total && hipMalloc((void **)&ent_all, (n_set + 1 + total + 1) * sizeof(ListEntry)) == hipSuccess &&
+                hipMalloc((void **)&ids_all, (tot_idx + R + 8) * sizeof(uint16_t)) == hipSuccess) {
               BI_HIP(hipMemcpyAsync(ent_all, ix.ent, (n_set + 1) * sizeof(ListEntry), hipMemcpyDeviceToDevice, st));
               BI_HIP(hipMemcpyAsync(ids_all, ix.ids, (tot_idx + 8) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
               BI_HIP(hipStreamSynchronize(st));
               (void)hipFree(ix.ent); (void)hipFree(ix.ids);
               ix.ent = ent_all; ix.ids = ids_all;
+              ent_all = nullptr; ids_all = nullptr;
               hipLaunchKernelGGL(ref_multi_write_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, ix.refpay, total, ix.ent, n_set, ix.ids, (uint32_t)tot_idx,
                                  (const uint32_t *)d_lens);
               BI_HIP(hipGetLastError());
               BI_HIP(hipStreamSynchronize(st));
-              ref_lists = true;
             }
-            (void)hipFree(d_lens); (void)hipFree(d_stmp);
           }
-          (void)ref_lists;
-          if (h_lost == 0) {
-            ix.ref_total = (uint32_t)total;
-          } else {   // (a key the table does not hold: leave the extension out rather than trust it)
-            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.anchor);
-            ix.ref2 = ix.refpay = ix.anchor = nullptr;
-          }
+          (void)hipGetLastError();   // (an allocation that failed above is not an error of the build)
+          (void)hipFree(ent_all); (void)hipFree(ids_all); (void)hipFree(d_lens); (void)hipFree(d_stmp);
+          if (have) ix.ref_total = (uint32_t)total;
         }
       } else {
         (void)hipFree(ix.tab);   // displacement overflow: keep the bit-vector path
