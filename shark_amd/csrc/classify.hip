@@ -901,6 +901,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   if (lx) {
     p.lsum32 = ctx->idx.ltab;
     p.lsum_shift = ctx->idx.ltab_mul;   // (no summary in this mode: the field carries the table's slot multiplier)
+    p.lx_gene = ctx->idx.ltab_gene;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));   // (= UniGeom::MIN_WAVES)

@@ -106,6 +106,10 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_ANCH_CUT
 #define SHK_ANCH_CUT 0
 #endif
+// (-DSHK_NO_SPARSE=1: a build without the sparse first round of one-gene indices, for A/B timing; at run time SHK_NO_SPARSE=1 when the index is built)
+#ifndef SHK_NO_SPARSE
+#define SHK_NO_SPARSE 0
+#endif
 // slots per mate that the anchored extension samples through the table (a power of two, at most 16)
 #ifndef SHK_ANCH_SAMPLE
 #define SHK_ANCH_SAMPLE 4
@@ -226,6 +230,27 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (ub < thr_full) { cutE = (uint32_t)CutPlan<U>::E0; cutUb = ub; }
   };
   if (UNI) plan_cut(L1, L2);
+  // ---- the sparse first round (one-gene index in LDS).  With ONE gene in the index nothing competes: a read is that
+  // gene's iff the bases covered by its k-mers that are in the filter reach c * len, and a LOWER bound on that coverage which
+  // passes settles it.  So the 128 probes in front of the cut's stop are made in another order: round A = the even slots of
+  // the prefix [0, 128 - T) (57 k-mers that tile 129 bases of mate 1, and an error costs a base or two, not k) plus T tiles --
+  // disjoint k-mers k apart, counted back from the last slot of the pair, k bases each --; round B = the rest of the prefix.
+  // A read from the gene is through behind round A (2 x 150 bp: 248 of the 180 bases needed, 97 % of the on-target pairs at
+  // 1 % errors, instead of behind three rounds and a vote); a read without any match behind B is cut as before, the prefix
+  // being what the cut needs (bases_behind(128 - T) < c * len fixes T).  Everything else -- a few per cent -- probes the T left-over
+  // slots, brings the matches into the usual order and goes on as ever.  spT = 0: not used (several genes, another geometry).
+  constexpr bool SPARSE = LX && UNI && CUT && ACCEPT && !SHK_NO_SPARSE && U >= 3 && JA_ROUNDS >= 2 && JA_ROUNDS <= 3;
+  uint32_t spT = 0, spLast = 0, spUb = 0;
+  if (SPARSE && P.lx_gene != 0xFFFFFFFFu && cutE == 2u) {
+    const uint32_t nkl = nk2 ? nk2 : nk1;
+    spLast = (nk2 ? P2 : 0u) + nkl - 1u;                       // the last slot of the pair; tile t is the slot spLast - t k
+    for (uint32_t T = 16u; T >= 1u; --T) {
+      const bool in_mate = (T - 1u) * k < nkl;                                  // the tiles stay inside the last mate,
+      const bool apart = spLast - (T - 1u) * k >= (128u - T) + k - 1u;          // do not touch what the prefix covers,
+      const uint32_t ub = bases_behind(128u - T, nk1, nk2, P2, L1, L2);         // and the prefix still carries the cut
+      if (in_mate && apart && spLast >= (T - 1u) * k && ub < thr_full) { spT = T; spUb = ub; break; }
+    }
+  }
   const uint8_t *sbase[G], *qbase[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -1015,6 +1040,85 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       if (found_cover(j_const) < thr_r - ub) return true;
       return per_gene && gene_cover(j_const) < thr_r - ub;
     };
+    // the slot ss of the read as a probe of the exact LDS table (LX): is its k-mer in the filter?  (`want` false: no probe)
+    auto lx_hit_at = [&](const uint32_t ss_in, const bool want) -> bool {
+      const uint32_t ss = want ? ss_in : 0u;
+      const uint32_t q = rcap - k - ss;
+      const uint32_t *f = fw + (ss >> 4);
+      const uint32_t *r = rv + (q >> 4);
+      const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+      const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+      const uint32_t af = (ss & 15u) << 1, ar = (q & 15u) << 1;
+      const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, af) << 32) | __builtin_amdgcn_alignbit(d1, d0, af);
+      const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, ar) << 32) | __builtin_amdgcn_alignbit(e1, e0, ar);
+      const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+      const uint64_t h = xxh64_u64(fwd < rc ? fwd : rc);
+      const uint32_t *T = lsum;
+      const char *D = reinterpret_cast<const char *>(lsum + LTAB_T_WORDS);
+      const uint32_t tagmask15 = (uint32_t)(P.bf_mask >> LTAB_SLOT_LG);
+      const uint32_t gmask2 = (tagmask15 & ((1u << LTAB_GROUP_LG) - 1u)) << 1;
+      const uint32_t dd = *reinterpret_cast<const uint16_t *>(D + (((uint32_t)h >> (LTAB_SLOT_LG - 1)) & gmask2));
+      const uint32_t tg = __builtin_amdgcn_alignbit((uint32_t)(h >> 32), (uint32_t)h, LTAB_SLOT_LG) & tagmask15;
+      const uint32_t base = (uint32_t)h + (tg >> LTAB_GROUP_LG) * P.lsum_shift;
+      const uint32_t ee = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + (((base + dd) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+      return want & ((ee >> 13) == ((tg << 1) | 1u));   // (not validated: the caller looks at the slot when something matched)
+    };
+    // the first two rounds of a one-gene index in the sparse order (see spT above).  true: the read is settled.  false: mt / slo of
+    // the rounds 0 and 1 are what probe_rounds would have left (matches validated), the read goes on behind the cut's first stop.
+    auto sparse_first = [&]() -> bool {
+      const uint32_t T = spT, nA = 64u - T, ln = (uint32_t)lane;
+      const bool tile = ln >= nA;
+      const uint32_t sA = tile ? spLast - (ln - nA) * k : 2u * ln;
+      bool hA = lx_hit_at(sA, true);
+      uint64_t HA = __ballot(hA);
+      if (HA) {
+        hA = hA && slot_valid(sA);   // (the slot has to exist and be a valid k-mer)
+        HA = __ballot(hA);
+      }
+      if (HA) {
+        // bases covered by what matched: an even slot adds min(k, distance to the next even match), a tile k
+        const uint64_t H1 = HA & ((1ull << nA) - 1ull);
+        const uint64_t nx = (H1 >> ln) >> 1;
+        const uint32_t step = nx ? 2u * ((uint32_t)__builtin_ctzll(nx) + 1u) : k;
+        const uint32_t cov = wave_sum_u32((hA && !tile) ? (step < k ? step : k) : 0u) + k * (uint32_t)__builtin_popcountll(HA >> nA);
+        if (cov >= thr_r) {
+          if (lane == 0 && !SHK_ABL(P, 64u)) {
+            const ClassifyOut *O = kernarg_params()->out;
+            O->count[read] = 1u;
+            uint2 pk;
+            pk.x = P.lx_gene & 0xFFFFu;
+            pk.y = 0u;
+            *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+          }
+          return true;
+        }
+      }
+      const uint32_t sB = ln < nA - 1u ? 2u * ln + 1u : ln + nA;
+      bool hB = lx_hit_at(sB, true);
+      uint64_t HB = __ballot(hB);
+      if (HB) {
+        hB = hB && slot_valid(sB);
+        HB = __ballot(hB);
+      }
+      if (!(HA | HB) && spUb < thr_r) return true;   // the bound cut: nothing of the prefix is in the filter
+      // (a few per cent of the reads) the T slots in front of the stop that the tiles displaced, then the usual order:
+      // slot s was probed by lane s / 2 of round A or B (even / odd s < 2 nA - 1), by lane s - nA of B, or by lane s - (128 - T) here
+      const bool hF = lx_hit_at(128u - T + ln, ln < T) && slot_valid(ln < T ? 128u - T + ln : 0u);
+      const uint32_t v = (hA ? 1u : 0u) | (hB ? 2u : 0u) | (hF ? 4u : 0u);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t sl = ln + 64u * j;
+        const bool eo = sl < 2u * nA - 1u, inB = sl < 128u - T;
+        const uint32_t src = eo ? sl >> 1 : (inB ? sl - nA : sl - (128u - T));
+        const uint32_t bit = eo ? sl & 1u : (inB ? 1u : 2u);
+        const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+        mt[j] = ((pv >> bit) & 1u) != 0u;
+        slo[j] = P.lx_gene;
+        okm[j] = mt[j] ? 0xFFFFFFFFu : 0u;
+        lane_any |= mt[j];
+      }
+      return false;
+    };
     if constexpr (JA >= U) {
       // nothing to decide early (two rounds): the cut's first stop at most
       if constexpr (E < U) {
@@ -1026,14 +1130,28 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
     } else {
       if constexpr (E < JA) {
-        probe_rounds(I0{}, IE{}, 0u);
+        bool first_done = false;
+        if constexpr (SPARSE && E == 2) {
+          if (spT) {
+            if (sparse_first()) return true;
+            first_done = true;
+          }
+        }
+        if (!first_done) probe_rounds(I0{}, IE{}, 0u);
         if (ruled_out(IE{}, cutUb, false)) return true;
         probe_rounds(std::integral_constant<int, (E < JA ? E : 0)>{}, IA{}, 0u);
         if (ruled_out(IA{}, ubJA, true)) return true;
       } else {
         // (E == JA: the cut's first stop.  E == U: no stop was planned -- c is small, or the index sits behind the L2 summary,
         //  where a stop of its own cost more than it saved -- but this one exists anyway, so the cut is tried at it)
-        probe_rounds(I0{}, IA{}, 0u);
+        bool first_done = false;
+        if constexpr (SPARSE && E == 2 && JA == 2) {
+          if (spT) {
+            if (sparse_first()) return true;
+            first_done = true;
+          }
+        }
+        if (!first_done) probe_rounds(I0{}, IA{}, 0u);
         if (ruled_out(IA{}, ubJA, true)) return true;
       }
       if (vote(IA{}, std::false_type{}, ubJA)) return true;

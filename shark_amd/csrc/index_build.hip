@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void ref_multi_write_kernel(uint32_t *__restri
 
 // LDS-resident exact table of a tiny index (lds_table.hpp): the keys are read back from the position table just built.
 // false = no displacement fits some group (the caller keeps the LDS-summary chain).
-static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, std::vector<uint32_t> &img, uint32_t *mul)
+// *one_gene: the payload all keys share (every probe that matches answers with that single-gene list), 0xFFFFFFFF when they differ
+static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, std::vector<uint32_t> &img, uint32_t *mul, uint32_t *one_gene)
 {
   std::vector<LtabKey> keys;
   const uint64_t n_buckets = 1ull << tab_lg;
@@ -348,6 +349,12 @@ static bool build_lds_table(const std::vector<uint64_t> &tab, uint32_t tab_lg, s
       const uint32_t gene = lo & TAB_PAYLOAD;
       keys.push_back(LtabKey{((uint64_t)(hi >> 8) << tab_lg) | home, ((lo >> 31) || gene >= LTAB_ESC) ? LTAB_ESC : gene});
     }
+  *one_gene = 0xFFFFFFFFu;
+  if (!keys.empty() && keys[0].payload != LTAB_ESC) {
+    *one_gene = keys[0].payload;
+    for (const LtabKey &key : keys)
+      if (key.payload != keys[0].payload) { *one_gene = 0xFFFFFFFFu; break; }
+  }
   return ltab_build(keys, img, mul);
 }
 
@@ -575,12 +582,15 @@ int build_index(Ctx *ctx)
         // tiny indices (a gene or a few): the whole table fits the LDS of a CU as a perfect hash -- uniform batches then
         // touch no memory but their own bases (classify_uni.hpp LSL = 21); the chains above stay for trimmed reads
         if (ix.ltab) { (void)hipFree(ix.ltab); ix.ltab = nullptr; }
+        ix.ltab_gene = 0xFFFFFFFFu;
         if (ix.pow2 && ix.lsum_shift && lgB >= 24 && lgB <= LTAB_MAX_POS_LG && n_set <= LTAB_MAX_KEYS && !getenv("SHK_NO_LDS_TABLE")) {
           std::vector<uint64_t> h_tab(slots);
           std::vector<uint32_t> img;
           BI_HIP(hipMemcpyAsync(h_tab.data(), ix.tab, slots * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
           BI_HIP(hipStreamSynchronize(st));
-          if (build_lds_table(h_tab, lg, img, &ix.ltab_mul)) {
+          uint32_t one_gene = 0xFFFFFFFFu;
+          if (build_lds_table(h_tab, lg, img, &ix.ltab_mul, &one_gene)) {
+            if (!getenv("SHK_NO_SPARSE")) ix.ltab_gene = one_gene;   // (SHK_NO_SPARSE=1: the usual probe order on one-gene indices too; the tests run both)
             BI_HIP(hipMalloc((void **)&ix.ltab, LTAB_BYTES));
             BI_HIP(hipMemcpyAsync(ix.ltab, img.data(), LTAB_BYTES, hipMemcpyHostToDevice, st));
             BI_HIP(hipStreamSynchronize(st));

@@ -149,6 +149,7 @@ static void fill_params(Ctx *ctx, Slot &s, const shk_batch *b)
   p.tab = ix.tab_lg ? ix.tab : nullptr; p.tab_lg = ix.tab_lg;
   p.tab_nt = ix.tab_lg && (16ull << ix.tab_lg) > (256ull << 20);   // beyond L2 + Infinity Cache
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
+  p.lx_gene = 0xFFFFFFFFu;   // (launch_classify_uni sets it when it chooses the exact LDS table)
   p.ref2 = ix.ref2; p.refpay = ix.refpay; p.anchor = ix.anchor; p.ref_total = ix.ref_total;
   p.bf_bits = ix.bf_bits;
   p.bf_mask = ix.pow2 ? ix.bf_bits - 1 : ~0ull;   // (non power-of-two: positions are reduced explicitly, the masks become no-ops)

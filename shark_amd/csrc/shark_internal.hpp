@@ -66,6 +66,7 @@ struct DeviceIndex {
   uint32_t lbig_shift = 0;    //   indices too dense for the 2^18-bit one; 0 = not built
   uint32_t *ltab = nullptr;   // LDS-resident EXACT table of a tiny index (LTAB_BYTES image: T[2^15] then D[2^13]; lds_table.hpp)
   uint32_t ltab_mul = 0;      //   the multiplier its slots were computed with
+  uint32_t ltab_gene = 0xFFFFFFFFu;   //   the ONE gene every key of that table answers with (a one-gene index), else 0xFFFFFFFF
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
   bool tab_with_summary = false;
@@ -118,6 +119,7 @@ struct ClassifyParams {
   uint64_t mod_c;
   const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
   uint32_t lsum_shift;
+  uint32_t lx_gene;          // exact table in LDS (LSL = 21): the gene of a one-gene index (DeviceIndex::ltab_gene), else 0xFFFFFFFF
   uint64_t bf_bits;
   uint64_t bf_mask;
   // options

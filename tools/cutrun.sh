@@ -1,2 +1,7 @@
-python tools/landscape.py --genes 60000 --ot 0.5 --k 31 --q 20 --reps 3 2>/dev/null
-python tools/landscape.py --genes 1000,60000 --ot 0.0,0.5 --reps 3 2>/dev/null
+#!/bin/bash
+# scratch: A/B of the sparse first round on the one-gene index
+mkdir -p gpurun_out/sparse
+for L in 150 100; do
+  timeout -k 10 300 python tools/landscape.py --genes 1 --ot 0,0.5,1 --ab --ab-var SHK_NO_SPARSE --reps 3 --read-len $L >> gpurun_out/sparse/ab.jsonl 2>> gpurun_out/sparse/ab.log || exit 1
+done
+cat gpurun_out/sparse/ab.jsonl
