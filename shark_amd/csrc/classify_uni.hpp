@@ -110,6 +110,14 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_NO_SPARSE
 #define SHK_NO_SPARSE 0
 #endif
+// (-DSHK_NO_PARTIAL=1: the round between the cut's two stops is always probed whole, for A/B timing)
+#ifndef SHK_NO_PARTIAL
+#define SHK_NO_PARTIAL 0
+#endif
+// the partial round leaves room for matches that cover SHK_PART_MARGIN_K * k + 1 bases of one gene
+#ifndef SHK_PART_MARGIN_K
+#define SHK_PART_MARGIN_K 2
+#endif
 // slots per mate that the anchored extension samples through the table (a power of two, at most 16)
 #ifndef SHK_ANCH_SAMPLE
 #define SHK_ANCH_SAMPLE 4
@@ -596,8 +604,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         // nothing of these rounds passed the summary: no matches (the hit path may still run for the other rounds)
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) {
-          if (ROUNDS) { mt[j] = false; slo[j] = 0u; }
-          else bk[j] = make_uint4(0u, 0u, 0u, 0u);   // (an empty slot's compared word is 0: matches nothing)
+          if (ROUNDS) {
+            const bool kn = ANCH && ((known >> j) & 1u) != 0u;   // (settled slots stay)
+            mt[j] = kn && mt[j];
+            slo[j] = kn ? slo[j] : 0u;
+          } else bk[j] = make_uint4(0u, 0u, 0u, 0u);   // (an empty slot's compared word is 0: matches nothing)
         }
       }
       return LX || something;
@@ -1139,7 +1150,42 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         }
         if (!first_done) probe_rounds(I0{}, IE{}, 0u);
         if (ruled_out(IE{}, cutUb, false)) return true;
-        probe_rounds(std::integral_constant<int, (E < JA ? E : 0)>{}, IA{}, 0u);
+        constexpr int EJ = E < JA ? E : 0;   // (= E: this branch)
+        using IEJ = std::integral_constant<int, EJ>;
+        bool whole = true;
+        if constexpr (TOL && ANCH && !SHK_NO_PARTIAL) {
+          // Table modes (large references): the second stop rules a read out when no gene's matches cover c * len less what is
+          // still unprobed -- and the chance matches of an off-target read are isolated k-mers of different genes, k bases each.
+          // So the round between the stops is probed only as far as that argument needs: up to the first slot X behind which
+          // the rest covers at most c * len - (SHK_PART_MARGIN_K k + 1) bases (2 x 150 bp, k = 17, c = 0.6: 11 of the round's 46
+          // slots).  Ruled out there: the other 35 memory requests are never made; else the rest of the round follows.
+          const uint32_t margin = (uint32_t)SHK_PART_MARGIN_K * k + 1u;
+          if (thr_r > margin) {
+            const uint32_t B = thr_r - margin;
+            // the smallest slot X with bases_behind(X) <= B
+            const uint32_t l1 = nk1 ? nk1 + k - 1u : 0u, l2 = nk2 ? nk2 + k - 1u : 0u;
+            uint32_t X;
+            if (l1 + l2 <= B) X = 0u;
+            else if (nk1 && l1 + l2 - B < nk1) X = l1 + l2 - B;
+            else if (l2 <= B) X = nk1;
+            else X = P2 + (l2 - B < nk2 ? l2 - B : nk2);
+            const uint32_t lo = 64u * (uint32_t)EJ, hi = 64u * (uint32_t)JA;
+            // slots of the round at or behind X that exist (the ones the partial round leaves out)
+            const uint32_t e1 = nk1 > X ? (nk1 < hi ? nk1 : hi) - (X > lo ? X : lo) : 0u;
+            const uint32_t b2 = X > P2 ? X : P2, t2 = P2 + nk2 < hi ? P2 + nk2 : hi;
+            const uint32_t left_out = (X < hi ? e1 : 0u) + ((X < hi && t2 > b2 && b2 >= lo) ? t2 - b2 : 0u);
+            if (X > lo && X < hi && left_out >= 8u) {
+              const uint32_t skip = ((uint32_t)lane + lo >= X) ? (1u << EJ) : 0u;
+              mt[EJ] = false;
+              slo[EJ] = 0u;
+              probe_rounds(IEJ{}, IA{}, skip);
+              if (ruled_out(IA{}, bases_behind(X, nk1, nk2, P2, l1, l2), true)) return true;
+              probe_rounds(IEJ{}, IA{}, skip ^ (1u << EJ));
+              whole = false;
+            }
+          }
+        }
+        if (whole) probe_rounds(IEJ{}, IA{}, 0u);
         if (ruled_out(IA{}, ubJA, true)) return true;
       } else {
         // (E == JA: the cut's first stop.  E == U: no stop was planned -- c is small, or the index sits behind the L2 summary,
