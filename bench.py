@@ -485,8 +485,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                 "frac_of_binding": valu["frac_of_issue_ceiling"] if (valu and lds_mode) else None,
                 "what_frac_is": "the contract's figure: SURVEY 8(d) algorithmic bytes (every k-mer of every read, as the reference visits them) / kernel time / 8 TB/s "
-                                "HBM peak -- a model figure, not HBM use: on this index the exact table sits in LDS and the bound cut / early decision (DESIGN.md 3) "
-                                "never make most of those probes.  `bound` names what does bind the kernel, `frac_of_binding` its use "
+                                "HBM peak -- a model figure, not HBM use, and it may exceed 1: on this index the exact table sits in LDS, and the bound cut, the early "
+                                "decision and the sparse first round (DESIGN.md 3) prove most of those probes irrelevant to the read's result and never make them "
+                                "(an off-target pair needs 128 of its 268 k-mers, a pair from the gene 64).  `bound` names what does bind the kernel, `frac_of_binding` its use "
                                 "(VALU wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time))",
                 "kernel": "classify_uni_kernel" if "table" in h.probe_mode() else "classify_fast_kernel",
                 "kernel_ms": round(kern_ms, 4), "launches": int(tm["n_launches"]),
