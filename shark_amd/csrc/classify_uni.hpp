@@ -249,6 +249,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // slots, brings the matches into the usual order and goes on as ever.  spT = 0: not used (several genes, another geometry).
   constexpr bool SPARSE = LX && UNI && CUT && ACCEPT && !SHK_NO_SPARSE && U >= 3 && JA_ROUNDS >= 2 && JA_ROUNDS <= 3;
   uint32_t spT = 0, spLast = 0, spUb = 0;
+  // (where a settled read's result goes: held across the loop.  Re-read per read like the vote does, the two dependent scalar
+  //  loads were 5 % of an on-target launch: 4.41 -> 4.21 ms per 10 M pairs at 50 % on-target.  Fetching the bases two reads ahead
+  //  instead of one was measured as well and changed nothing: 4.21 -> 4.29 ms)
+  uint32_t *sp_count = nullptr;
+  uint16_t *sp_inl = nullptr;
   if (SPARSE && P.lx_gene != 0xFFFFFFFFu && cutE == 2u) {
     const uint32_t nkl = nk2 ? nk2 : nk1;
     spLast = (nk2 ? P2 : 0u) + nkl - 1u;                       // the last slot of the pair; tile t is the slot spLast - t k
@@ -258,6 +263,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       const uint32_t ub = bases_behind(128u - T, nk1, nk2, P2, L1, L2);         // and the prefix still carries the cut
       if (in_mate && apart && spLast >= (T - 1u) * k && ub < thr_full) { spT = T; spUb = ub; break; }
     }
+    sp_count = P.out->count;
+    sp_inl = P.out->inl;
   }
   const uint8_t *sbase[G], *qbase[G];
 #pragma unroll
@@ -1094,12 +1101,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t cov = wave_sum_u32((hA && !tile) ? (step < k ? step : k) : 0u) + k * (uint32_t)__builtin_popcountll(HA >> nA);
         if (cov >= thr_r) {
           if (lane == 0 && !SHK_ABL(P, 64u)) {
-            const ClassifyOut *O = kernarg_params()->out;
-            O->count[read] = 1u;
+            sp_count[read] = 1u;
             uint2 pk;
             pk.x = P.lx_gene & 0xFFFFu;
             pk.y = 0u;
-            *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+            *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
           }
           return true;
         }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# scratch: margin of the partial round
+# scratch: early out-pointer loads in the vote
 mkdir -p gpurun_out/part
-for v in pk1 base pk3; do
+for v in base early; do
   if [ $v = base ]; then unset SHK_LIB_PATH; else export SHK_LIB_PATH=$PWD/tools/variants/$v.so; fi
   echo "== $v"
-  timeout -k 10 300 python tools/landscape.py --genes 60000 --ot 0,0.5 --reps 3 2> gpurun_out/part/land_$v.log | cut -c1-20,150-190 || exit 1
+  timeout -k 10 500 python tools/landscape.py --genes 1,10,100,1000,60000 --ot 0.5,1 --reps 3 2> gpurun_out/part/land_$v.log | python3 -c "import sys,json; [print(d[\"genes\"], d[\"on_target\"], d[\"kernel_ms\"]) for d in map(json.loads, sys.stdin)]" || exit 1
 done
