@@ -3,83 +3,129 @@
 
 namespace shk {
 
-// inclusive scan of one value per thread across a 256-thread workgroup;
-// returns the inclusive prefix, *total receives the workgroup total
-__device__ __forceinline__ uint64_t block_inclusive_scan_u64(uint64_t v, uint64_t *total, uint64_t *lds /* >= 4 */)
+static_assert(SCAN_ITEMS == 16 && SCAN_THREADS == 256, "the kernels below load four uint4 per thread and combine four waves");
+
+// the 16 items of a thread: vector accesses when the tile is whole and the pointer aligned, else item by item (0 behind n)
+template <bool VEC>
+__device__ __forceinline__ void load_items(const uint32_t *__restrict__ in, uint64_t base, uint64_t n, uint32_t (&v)[SCAN_ITEMS])
 {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (VEC && base + SCAN_ITEMS <= n) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 a = p[q];
+      v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? in[base + i] : 0u;
+  }
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// inclusive scan of one 32-bit value per lane across the wave (modulo 2^32)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t t = __shfl_up(v, o, 64);
+    const uint32_t t = __shfl_up(v, o, 64);
     if (lane >= o) v += t;
   }
-  if (lane == 63) lds[wave] = v;
+  return v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_kernel(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ tile_sums)
+{
+  __shared__ uint64_t lds[SCAN_THREADS / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  load_items<VEC>(in, base, n, v);
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+  s = wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// one workgroup of 1024 threads: exclusive scan of the tile sums in place (each thread a run of consecutive tiles); total -> *total_out
+constexpr int SCAN_OFFS_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_OFFS_THREADS) void scan_tile_offsets_kernel(uint64_t *__restrict__ tile_sums, uint64_t ntiles, uint64_t *__restrict__ total_out)
+{
+  __shared__ uint64_t lds[SCAN_OFFS_THREADS / 64];
+  const uint64_t per = (ntiles + SCAN_OFFS_THREADS - 1) / SCAN_OFFS_THREADS;
+  const uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
+  uint64_t s = 0;
+  for (uint64_t i = lo; i < hi; ++i) s += tile_sums[i];
+  // inclusive scan of the threads' sums: within the wave, then over the 16 wave totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
   __syncthreads();
   uint64_t add = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-    const uint64_t s = lds[w];
-    if (w < wave) add += s;
-    tot += s;
+  for (int w = 0; w < SCAN_OFFS_THREADS / 64; ++w) {
+    const uint64_t t = lds[w];
+    if (w < wave) add += t;
+    tot += t;
   }
-  __syncthreads();
-  *total = tot;
-  return v + add;
+  uint64_t run = add + inc - s;
+  for (uint64_t i = lo; i < hi; ++i) {
+    const uint64_t t = tile_sums[i];
+    tile_sums[i] = run;
+    run += t;
+  }
+  if (threadIdx.x == 0) *total_out = tot;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_kernel(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ tile_sums)
-{
-  __shared__ uint64_t lds[4];
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  uint64_t s = 0;
-  if (base + SCAN_ITEMS <= n) {
-    const uint4 a = *reinterpret_cast<const uint4 *>(in + base);
-    const uint4 b = *reinterpret_cast<const uint4 *>(in + base + 4);
-    s = (uint64_t)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-  } else {
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-      if (base + i < n) s += in[base + i];
-  }
-  uint64_t tot;
-  block_inclusive_scan_u64(s, &tot, lds);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-// one workgroup: exclusive scan of the tile sums in place; total -> *total_out
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_offsets_kernel(uint64_t *__restrict__ tile_sums, uint64_t ntiles, uint64_t *__restrict__ total_out)
-{
-  __shared__ uint64_t lds[4];
-  uint64_t carry = 0;
-  for (uint64_t b = 0; b < ntiles; b += SCAN_THREADS) {
-    const uint64_t i = b + threadIdx.x;
-    const uint64_t v = i < ntiles ? tile_sums[i] : 0;
-    uint64_t tot;
-    const uint64_t inc = block_inclusive_scan_u64(v, &tot, lds);
-    if (i < ntiles) tile_sums[i] = carry + inc - v;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) *total_out = carry;
-}
-
+template <bool VEC>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
                                                                  const uint64_t *__restrict__ tile_offs)
 {
-  __shared__ uint64_t lds[4];
+  __shared__ uint32_t lds[SCAN_THREADS / 64];
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
-  uint64_t s = 0;
+  load_items<VEC>(in, base, n, v);
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+  // (the outputs are 32-bit: everything below is modulo 2^32; the 64-bit total comes from the tile sums)
+  const uint32_t inc = wave_inclusive_scan_u32(s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t add = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) add += w < wave ? lds[w] : 0u;
+  uint32_t run = (uint32_t)tile_offs[blockIdx.x] + add + inc - s;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
-    v[i] = base + i < n ? in[base + i] : 0u;
-    s += v[i];
+    const uint32_t t = v[i];
+    v[i] = run;
+    run += t;
   }
-  uint64_t tot;
-  const uint64_t inc = block_inclusive_scan_u64(s, &tot, lds);
-  uint64_t run = tile_offs[blockIdx.x] + inc - s;
+  if (VEC && base + SCAN_ITEMS <= n) {
+    uint4 *p = reinterpret_cast<uint4 *>(out + base);
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i) {
-    if (base + i < n) out[base + i] = (uint32_t)run;
-    run += v[i];
+    for (int q = 0; q < 4; ++q) p[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+      if (base + i < n) out[base + i] = v[i];
   }
 }
 
@@ -92,9 +138,12 @@ const uint64_t *exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t n
     (void)hipMemsetAsync(total, 0, sizeof(uint64_t), stream);
     return total;
   }
-  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, n, temp);
-  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, temp, ntiles, total);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, out, n, temp);
+  const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+  if (vec) hipLaunchKernelGGL(scan_tile_sums_kernel<true>, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, n, temp);
+  else hipLaunchKernelGGL(scan_tile_sums_kernel<false>, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, n, temp);
+  hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_OFFS_THREADS), 0, stream, temp, ntiles, total);
+  if (vec) hipLaunchKernelGGL(scan_apply_kernel<true>, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, out, n, temp);
+  else hipLaunchKernelGGL(scan_apply_kernel<false>, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, out, n, temp);
   return total;
 }
 
