@@ -895,9 +895,10 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lsum32 = ctx->idx.lbig32;
     p.lsum_shift = ctx->idx.lbig_shift;
   }
-  // tiny indices: the exact table in LDS (uniform batches; power-of-two filters).  Trimmed reads stay on the LDS-summary chain:
-  // measured 9.8 ms per 10 M pairs with the table in LDS (4 waves per SIMD) against 9.7 ms (6 waves per SIMD)
-  const bool lx = uni && mode == PM_LDS_TAB && ctx->idx.ltab != nullptr && (u <= 5 || u == 10);
+  // tiny indices: the exact table in LDS (uniform batches; power-of-two filters).  Trimmed reads stay on the LDS-summary chain
+  // (measured 9.8 ms per 10 M pairs with the table in LDS, 4 waves per SIMD, against 9.7 ms at 6 waves per SIMD) -- unless the
+  // index has one gene: the sparse first round (classify_uni.hpp) needs the exact table
+  const bool lx = (uni || ctx->idx.ltab_gene != 0xFFFFFFFFu) && mode == PM_LDS_TAB && ctx->idx.ltab != nullptr && (u <= 5 || u == 10);
   if (lx) {
     p.lsum32 = ctx->idx.ltab;
     p.lsum_shift = ctx->idx.ltab_mul;   // (no summary in this mode: the field carries the table's slot multiplier)

@@ -247,24 +247,54 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // 1 % errors, instead of behind three rounds and a vote); a read without any match behind B is cut as before, the prefix
   // being what the cut needs (bases_behind(128 - T) < c * len fixes T).  Everything else -- a few per cent -- probes the T left-over
   // slots, brings the matches into the usual order and goes on as ever.  spT = 0: not used (several genes, another geometry).
-  constexpr bool SPARSE = LX && UNI && CUT && ACCEPT && !SHK_NO_SPARSE && U >= 3 && JA_ROUNDS >= 2 && JA_ROUNDS <= 3;
+  // (Ragged batches on a one-gene index run this kernel with the exact table too -- see launch_classify_uni -- and plan per read.)
+  constexpr bool SPARSE = LX && CUT && ACCEPT && !SHK_NO_SPARSE && U >= 3 && JA_ROUNDS >= 2 && JA_ROUNDS <= 3;
   uint32_t spT = 0, spLast = 0, spUb = 0;
   // (where a settled read's result goes: held across the loop.  Re-read per read like the vote does, the two dependent scalar
   //  loads were 5 % of an on-target launch: 4.41 -> 4.21 ms per 10 M pairs at 50 % on-target.  Fetching the bases two reads ahead
   //  instead of one was measured as well and changed nothing: 4.21 -> 4.29 ms)
   uint32_t *sp_count = nullptr;
   uint16_t *sp_inl = nullptr;
-  if (SPARSE && P.lx_gene != 0xFFFFFFFFu && cutE == 2u) {
+  const bool sp_on = SPARSE && P.lx_gene != 0xFFFFFFFFu;
+  // floor(x / k) and floor(x / (k - 1)) for x < 2048 as a multiplication (k <= 32)
+  const uint32_t sp_rk = sp_on ? (65536u + k - 1u) / k : 0u, sp_rk1 = (sp_on && k > 1u) ? (65536u + k - 2u) / (k - 1u) : 0u;
+  // the smallest slot s with bases_behind(s) <= B
+  auto slot_for_ub = [&](const uint32_t B, const uint32_t l1, const uint32_t l2) -> uint32_t {
+    const uint32_t c1 = nk1 ? l1 : 0u, c2 = nk2 ? l2 : 0u;   // (a mate shorter than k has no slot and covers nothing)
+    if (c1 + c2 <= B) return 0u;
+    if (nk1 && c1 + c2 - B < nk1) return c1 + c2 - B;
+    if (c2 <= B) return nk1;
+    return P2 + (c2 - B < nk2 ? c2 - B : nk2);
+  };
+  auto plan_sparse = [&](const uint32_t l1, const uint32_t l2) {
+    spT = 0;
+    if (!sp_on || cutE != 2u || !(nk1 | nk2) || !thr_full) return;
     const uint32_t nkl = nk2 ? nk2 : nk1;
     spLast = (nk2 ? P2 : 0u) + nkl - 1u;                       // the last slot of the pair; tile t is the slot spLast - t k
-    for (uint32_t T = 16u; T >= 1u; --T) {
-      const bool in_mate = (T - 1u) * k < nkl;                                  // the tiles stay inside the last mate,
-      const bool apart = spLast - (T - 1u) * k >= (128u - T) + k - 1u;          // do not touch what the prefix covers,
-      const uint32_t ub = bases_behind(128u - T, nk1, nk2, P2, L1, L2);         // and the prefix still carries the cut
-      if (in_mate && apart && spLast >= (T - 1u) * k && ub < thr_full) { spT = T; spUb = ub; break; }
+    // the largest T <= 16 whose tiles stay inside the last mate ((T - 1) k < nkl), do not touch what the prefix covers
+    // (spLast - (T - 1) k >= (128 - T) + k - 1, i.e. T (k - 1) <= spLast - 127), and whose prefix still carries the cut
+    // (bases_behind(128 - T) < c * len, i.e. 128 - T >= the first slot with at most c * len - 1 bases behind it)
+    uint32_t T = 16u;
+    const uint32_t t_in = (((nkl - 1u) * sp_rk) >> 16) + 1u;
+    T = T < t_in ? T : t_in;
+    if (k > 1u) {
+      if (spLast < 127u) return;
+      const uint32_t t_ap = ((spLast - 127u) * sp_rk1) >> 16;
+      T = T < t_ap ? T : t_ap;
     }
+    const uint32_t X = slot_for_ub(thr_full - 1u, l1, l2);
+    if (X > 127u) return;
+    T = T < 128u - X ? T : 128u - X;
+    if (T == 0u) return;
+    // (the conditions themselves, not their closed forms, decide)
+    const uint32_t back = (T - 1u) * k;
+    const uint32_t ub = bases_behind(128u - T, nk1, nk2, P2, l1, l2);
+    if (back < nkl && spLast >= back && spLast - back >= (128u - T) + k - 1u && ub < thr_full) { spT = T; spUb = ub; }
+  };
+  if (sp_on) {
     sp_count = P.out->count;
     sp_inl = P.out->inl;
+    if (UNI) plan_sparse(L1, L2);
   }
   const uint8_t *sbase[G], *qbase[G];
 #pragma unroll
@@ -392,7 +422,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
-    if (!UNI) plan_cut(m_cur.L1, m_cur.L2);
+    if (!UNI) { plan_cut(m_cur.L1, m_cur.L2); if (SPARSE) plan_sparse(m_cur.L1, m_cur.L2); }
     uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
     if (cutE < (uint32_t)U || JA_ROUNDS < U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
@@ -1168,13 +1198,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           const uint32_t margin = (uint32_t)SHK_PART_MARGIN_K * k + 1u;
           if (thr_r > margin) {
             const uint32_t B = thr_r - margin;
-            // the smallest slot X with bases_behind(X) <= B
             const uint32_t l1 = nk1 ? nk1 + k - 1u : 0u, l2 = nk2 ? nk2 + k - 1u : 0u;
-            uint32_t X;
-            if (l1 + l2 <= B) X = 0u;
-            else if (nk1 && l1 + l2 - B < nk1) X = l1 + l2 - B;
-            else if (l2 <= B) X = nk1;
-            else X = P2 + (l2 - B < nk2 ? l2 - B : nk2);
+            const uint32_t X = slot_for_ub(B, l1, l2);   // the smallest slot with at most B bases behind it
             const uint32_t lo = 64u * (uint32_t)EJ, hi = 64u * (uint32_t)JA;
             // slots of the round at or behind X that exist (the ones the partial round leaves out)
             const uint32_t e1 = nk1 > X ? (nk1 < hi ? nk1 : hi) - (X > lo ? X : lo) : 0u;
@@ -1240,7 +1265,7 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
 {
 #define LU4(M_, L_, HQ_, UN_) hipLaunchKernelGGL((classify_uni_kernel<U, M_, HQ_, L_, UN_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p)
 #define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
-                        else if (L_ == 18) { if (hasq) LU4(M_, 18, true, false); else LU4(M_, 18, false, false); } } while (0)
+                        else if (L_ != 20) { if (hasq) LU4(M_, L_, true, false); else LU4(M_, L_, false, false); } } while (0)
   switch (mode) {
   case PM_LDS_TAB:
     if (lx) { if constexpr (U <= 5 || U == 10) LU(PM_LDS_TAB, 21); }   // (launch_classify_uni asks for it only where it is compiled)

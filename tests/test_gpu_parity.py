@@ -1278,7 +1278,7 @@ def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
 @pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (140, 140, 17), (100, 100, 17), (125, 125, 12), (151, 101, 17), (101, 151, 17),
                                      (250, 0, 17), (300, 0, 21), (160, 160, 5)])
 def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
-    """a one-gene index held in LDS probes the first 128 slots of a uniform batch in another order (even slots + tiles, then the
+    """a one-gene index held in LDS probes the first 128 slots of a read (uniform batches and trimmed reads alike) in another order (even slots + tiles, then the
     rest) and settles a read as soon as a lower bound of its coverage passes c * len: reads from the gene with 0-12 % errors,
     chimeric reads whose coverage lands on either side of every threshold, reads with N and masked qualities, off-target reads --
     every result equals the oracle's, with the sparse order and (SHK_NO_SPARSE=1 at index build time) without it"""
@@ -1298,13 +1298,14 @@ def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
         for c, q in ((0.6, 0), (0.25, 0), (0.45, 20), (0.8, 0), (0.95, 0), (1.0, 0), (0.0, 0)):
             o, h, info = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=c, min_quality=q)
             assert h.probe_mode() == "lds-table", h.probe_mode()
-            for sub_rate in (0.0, 0.01, 0.04, 0.12):
-                batch = _sequenced_pairs(rng, genes, 500, L1, L2, False, q > 0, sub_rate, 0.002 if sub_rate else 0.0, 0.003)
+            for ragged in (False, True):       # (trimmed reads run the same kernel on a one-gene index and plan per read)
+                for sub_rate in (0.0, 0.01, 0.04, 0.12):
+                    batch = _sequenced_pairs(rng, genes, 350, L1, L2, ragged, q > 0, sub_rate, 0.002 if sub_rate else 0.0, 0.003)
+                    goff, _ = _compare_classify(o, h, batch)
+                    n_assigned += int(goff[-1])
+                batch = _chimeric_batch(rng, genes, 700, L1, L2, ragged, with_n=True, qual=q > 0, k_hint=k)
                 goff, _ = _compare_classify(o, h, batch)
                 n_assigned += int(goff[-1])
-            batch = _chimeric_batch(rng, genes, 900, L1, L2, False, with_n=True, qual=q > 0, k_hint=k)
-            goff, _ = _compare_classify(o, h, batch)
-            n_assigned += int(goff[-1])
             h.close()
     assert n_assigned > 0
 
