@@ -837,6 +837,40 @@ def test_device_api_with_a_wrong_length_bound(oracle):
         assert np.array_equal(h.gene_counts(8), np.bincount(oi, minlength=8)[:8].astype(np.uint64)), bound
 
 
+def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
+    """device-resident batches: uniform_check_kernel decides on the device whether every read has one length per mate (two offsets
+    per thread, the third from the next lane).  One read a base shorter -- first, last, odd / even index, either side of a wave and
+    of a workgroup of the check, in either mate -- makes the batch ragged; an all-equal batch with an odd read count stays uniform.
+    The associations are the oracle's every time (a wrong verdict would read every later read at the wrong place)."""
+    from shark_amd.capi import hip_memcpy_dtoh
+    rng = np.random.default_rng(977)
+    genes = synth.make_genes(rng, 1, 5000, 5000)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 30)
+    dev = torch.device("cuda:0")
+    for n in (1031, 1030):
+        base = synth.make_reads(rng, genes, n, read_len=120, paired=True, on_target=0.7)
+        m1 = [base["seq1"][int(base["off1"][i]):int(base["off1"][i + 1])] for i in range(n)]
+        m2 = [base["seq2"][int(base["off2"][i]):int(base["off2"][i + 1])] for i in range(n)]
+        for odd in (None, 0, 1, 2, 63, 64, 127, 128, 129, 511, 512, 513, n - 3, n - 2, n - 1):
+            for mate in ((1,) if odd is None else (1, 2)):
+                a, b = list(m1), list(m2)
+                if odd is not None:
+                    if mate == 1:
+                        a[odd] = a[odd][:-1]
+                    else:
+                        b[odd] = b[odd][:-1]
+                bt = synth.batch_from_lists(a, b)
+                og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"])
+                t = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for k, v in bt.items() if v is not None}
+                r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=120)
+                goff = np.empty(n + 1, np.uint32)
+                hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+                gids = np.empty(int(r.n_assoc), np.uint16)
+                hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+                assert np.array_equal(goff, og) and np.array_equal(gids, oi), (n, odd, mate)
+    h.close()
+
+
 @pytest.mark.parametrize("q", [94, 95, 100, 222, 223, 256, 300])
 def test_min_quality_wraps_like_the_reference_char(oracle, q):
     """argument_parser.hpp:144 stores -q in a `char` and FastqSplitter.hpp:70 adds 33 in a `char`: values above 94 wrap

@@ -11,7 +11,7 @@ for step in "$@"; do
     cli_tests)   timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -k "cli" -x -q > $out/$step.log 2>&1 ;;
     fuzz)        timeout -k 10 900 python -m pytest tests/test_gpu_fuzz.py -x -q -s > $out/$step.log 2>&1 ;;
     anch_tests)  timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py -k "anchored or chimeric or synthetic_parity or every_kernel or long_and_ragged" -x -q > $out/$step.log 2>&1 ;;
-    sparse_tests) timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -k "sparse_first or lds_table or example_bit or bound_cut" -x -q > $out/$step.log 2>&1 ;;
+    sparse_tests) timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -k "sparse_first or lds_table or example_bit or bound_cut or uniformity or device_api or device_resident" -x -q > $out/$step.log 2>&1 ;;
     long_tests)  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -k "long_pairs or every_kernel or long_and_ragged or packed_position or anchored" -x -q > $out/$step.log 2>&1 ;;
     land_ab)     timeout -k 10 900 python tools/landscape.py --genes 250,1000,10000,60000 --ab > $out/landscape_ab.jsonl 2> $out/$step.log ;;
     land_ot)     timeout -k 10 900 python tools/landscape.py --genes 1000,60000 --ot 0,1 --ab > $out/landscape_ot.jsonl 2> $out/$step.log ;;
