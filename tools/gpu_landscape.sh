@@ -6,6 +6,7 @@ out=${1:-gpurun_out/landscape}; mkdir -p $out
 python tools/landscape.py --genes 1,10,60,100,150,250,1000,10000,60000 --ot 0.5 > $out/sizes.jsonl 2>/dev/null
 python tools/landscape.py --genes 1,100,1000,60000 --ot 0.0,1.0 > $out/on_target.jsonl 2>/dev/null
 python tools/landscape.py --genes 250,1000,10000,60000 --ot 0.5 --ab > $out/anchor_ab.jsonl 2>/dev/null
+python tools/landscape.py --genes 1 --ot 0,0.5,1 --ab --ab-var SHK_NO_SPARSE > $out/sparse_ab.jsonl 2>/dev/null
 python tools/landscape.py --genes 1,1000,60000 --ot 0.5 --read-len 300 --pairs 5000000 > $out/len300.jsonl 2>/dev/null
 python tools/landscape.py --genes 1,1000,60000 --ot 0.5 --read-len 250 --pairs 5000000 > $out/len250.jsonl 2>/dev/null
 python tools/landscape.py --genes 1,1000,60000 --ot 0.5 --read-len 100 > $out/len100.jsonl 2>/dev/null
