@@ -889,7 +889,18 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint32_t u = fast_kernel_unroll(max_slots);
   // indices too dense for the 32 KiB LDS summary may still have the 128 KiB one (index_build.hip): uniform batches then
   // run in LDS-summary mode with it, whatever chain ragged batches use on this index
-  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10);
+  // ... unless the batch just finished says that most pairs are the panel's: behind the LDS summary every hit of such a pair is a
+  // table lookup through L2 (150 genes, per 10 M pairs at 0 / 50 / 100 % on-target: 5.6 / 16.5 / 26.2 ms), while the position-table
+  // kernel with the anchored extension reads the reference's payloads instead (7.9 / 11.0 / 14.8 ms).  Both give the same
+  // results; the denser the summary, the earlier the other kernel wins (measured crossover: 64 / 42 / 17 % of the pairs assigned
+  // at 60 / 100 / 150 genes, pass rates 0.12 / 0.20 / 0.28).  SHK_BIG_LDS_ALWAYS=1: no switching (A/B timing, tests)
+  bool many_assigned = false;
+  if (ctx->last.last_n_reads && ctx->idx.ref_total && ctx->idx.lbig_shift && !getenv("SHK_BIG_LDS_ALWAYS")) {
+    double f = 1.0 - 3.0 * ctx->idx.lbig_pass;
+    f = f < 0.1 ? 0.1 : (f > 0.9 ? 0.9 : f);
+    many_assigned = (double)ctx->last.last_n_assoc > f * (double)ctx->last.last_n_reads;
+  }
+  const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10) && !many_assigned;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
     p.lsum32 = ctx->idx.lbig32;

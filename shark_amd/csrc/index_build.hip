@@ -577,6 +577,7 @@ int build_index(Ctx *ctx)
             BI_HIP(hipGetLastError());
             BI_HIP(hipStreamSynchronize(st));
             ix.lbig_shift = sh;
+            ix.lbig_pass = pass;
           }
         }
         // tiny indices (a gene or a few): the whole table fits the LDS of a CU as a perfect hash -- uniform batches then

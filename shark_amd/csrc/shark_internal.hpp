@@ -64,6 +64,7 @@ struct DeviceIndex {
   uint32_t lsum_shift = 0;    // 0 = not used
   uint32_t *lbig32 = nullptr; // 2^20-bit summary (128 KiB of LDS, one 1024-thread workgroup per CU): classify_uni_kernel on
   uint32_t lbig_shift = 0;    //   indices too dense for the 2^18-bit one; 0 = not built
+  double lbig_pass = 0.0;     //   the share of random k-mers that pass it
   uint32_t *ltab = nullptr;   // LDS-resident EXACT table of a tiny index (LTAB_BYTES image: T[2^15] then D[2^13]; lds_table.hpp)
   uint32_t ltab_mul = 0;      //   the multiplier its slots were computed with
   uint32_t ltab_gene = 0xFFFFFFFFu;   //   the ONE gene every key of that table answers with (a one-gene index), else 0xFFFFFFFF

@@ -1031,6 +1031,28 @@ def test_panel_sized_index_uses_the_big_lds_summary(oracle, bf_bits, monkeypatch
         assert np.array_equal(g2, wg) and np.array_equal(i2, wi)
 
 
+def test_panel_sized_index_follows_the_assigned_fraction(oracle, monkeypatch):
+    """an index with the 2^20-bit LDS summary switches its uniform batches to the position-table kernel (anchored extension) while
+    the batch just finished had many pairs assigned, and back -- identical results either way, in every order of batches, and with
+    the switching turned off"""
+    rng = np.random.default_rng(2121)
+    genes = synth.make_genes(rng, 100, 2000, 3000, share_every=5)
+    on = synth.make_reads(rng, genes, 3000, read_len=150, paired=True, on_target=1.0)
+    off = synth.make_reads(rng, genes, 3000, read_len=150, paired=True, on_target=0.0)
+    mix = synth.make_reads(rng, genes, 3000, read_len=150, paired=True, on_target=0.5)
+    for always in (False, True):
+        if always:
+            monkeypatch.setenv("SHK_BIG_LDS_ALWAYS", "1")
+        o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 33)
+        assert "lds" not in h.probe_mode()
+        fr = []
+        for b in (on, on, off, off, mix, on, mix, off, on):
+            goff, _ = _compare_classify(o, h, b)
+            fr.append(int(goff[-1]) / 3000)
+        assert max(fr) > 0.9 and min(fr) < 0.05
+        h.close()
+
+
 @pytest.mark.parametrize("k,bf_bits,n_bases", [
     (17, 1 << 33, 25_600),      # lds-summary+table: walks per round; 25 584 keys in 32 768 slots
     (17, 5 << 32, 25_600),      # the same with hash % size
