@@ -582,8 +582,9 @@ def main():
         t1 = time.perf_counter() - t0
         cpu = {"value": round(2 * ns / tc, 1), "unit": "reads/s", "cores": threads, "kind": "port",
                "physical_cores": phys or None, "cpu_model": model,
-               "sample": "%d pairs of the same batch (the first %d and %d from its middle), %d threads x 50 000-read chunks (main.cpp:215), %.1f s"
-                         % (ns, n_head, n_mid, threads, tc),
+               "sample": ("%d pairs of the same batch (%s), %d threads x 50 000-read chunks (main.cpp:215), %.1f s"
+                          % (ns, ("the whole launch: head, middle and tail" if ns == n else
+                                  "the first %d and %d from its middle" % (n_head, n_mid) if n_mid else "its first %d" % n_head), threads, tc)),
                "parity_with_gpu": parity,
                "one_thread": {"value": round(2 * n1 / t1, 1), "unit": "reads/s", "sample": "first %d pairs, %.1f s" % (n1, t1)}}
         o.close()
