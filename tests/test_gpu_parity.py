@@ -1332,7 +1332,7 @@ def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
 # one-gene indices in LDS: the sparse first round (classify_uni.hpp, spT / sparse_first)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (140, 140, 17), (100, 100, 17), (125, 125, 12), (151, 101, 17), (101, 151, 17),
-                                     (250, 0, 17), (300, 0, 21), (160, 160, 5)])
+                                     (250, 0, 17), (300, 0, 21), (160, 160, 5), (150, 12, 17), (12, 150, 17)])
 def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
     """a one-gene index held in LDS probes the first 128 slots of a read (uniform batches and trimmed reads alike) in another order (even slots + tiles, then the
     rest) and settles a read as soon as a lower bound of its coverage passes c * len: reads from the gene with 0-12 % errors,
