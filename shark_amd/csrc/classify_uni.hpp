@@ -1171,13 +1171,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         HB = __ballot(hB);
       }
       if (!(HA | HB) && spUb < thr_r) return true;   // the bound cut: nothing of the prefix is in the filter
-      // (a few per cent of the reads) the T slots in front of the stop that the tiles displaced, then the usual order:
-      // slot s was probed by lane s / 2 of round A or B (even / odd s < 2 nA - 1), by lane s - nA of B, or by lane s - (128 - T) here
-      const bool hF = lx_hit_at(128u - T + ln, ln < T) && slot_valid(ln < T ? 128u - T + ln : 0u);
-      const uint32_t v = (hA ? 1u : 0u) | (hB ? 2u : 0u) | (hF ? 4u : 0u);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint32_t sl = ln + 64u * j;
+      // (a few per cent of the reads) the matches in the usual order: slot s was probed by lane s / 2 of round A or B (even / odd
+      // s < 2 nA - 1) or by lane s - nA of B; the T slots in front of the stop that the tiles displaced are not probed yet
+      auto settle_round = [&](const int j, const uint32_t v) {
+        const uint32_t sl = ln + 64u * (uint32_t)j;
         const bool eo = sl < 2u * nA - 1u, inB = sl < 128u - T;
         const uint32_t src = eo ? sl >> 1 : (inB ? sl - nA : sl - (128u - T));
         const uint32_t bit = eo ? sl & 1u : (inB ? 1u : 2u);
@@ -1185,8 +1182,30 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         mt[j] = ((pv >> bit) & 1u) != 0u;
         slo[j] = P.lx_gene;
         okm[j] = mt[j] ? 0xFFFFFFFFu : 0u;
-        lane_any |= mt[j];
+      };
+      const uint32_t vAB = (hA ? 1u : 0u) | (hB ? 2u : 0u);
+      settle_round(0, vAB);
+      settle_round(1, vAB);
+      if (HA | HB) {
+        // the whole prefix is known now: what it covers (as the vote counts it) + the tiles -- a read with more errors than the
+        // even slots forgive is settled here, behind the two rounds an off-target read costs
+        const uint64_t H0 = __ballot(mt[0]), H1 = __ballot(mt[1]);
+        const uint32_t cov = cover(H0, 0ull) + cover(H1, H0) + cover(0ull, H1) + k * (uint32_t)__builtin_popcountll(HA >> nA);
+        if (cov >= thr_r) {
+          if (lane == 0 && !SHK_ABL(P, 64u)) {
+            sp_count[read] = 1u;
+            uint2 pk;
+            pk.x = P.lx_gene & 0xFFFFu;
+            pk.y = 0u;
+            *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+          }
+          return true;
+        }
       }
+      // ... then the displaced slots, and on behind the cut's first stop as ever
+      const bool hF = lx_hit_at(128u - T + ln, ln < T) && slot_valid(ln < T ? 128u - T + ln : 0u);
+      settle_round(1, vAB | (hF ? 4u : 0u));
+      lane_any = mt[0] | mt[1];
       return false;
     };
     if constexpr (JA >= U) {

@@ -18,6 +18,7 @@ ap.add_argument("--q", type=int, default=0)
 ap.add_argument("--read-len", type=int, default=150)
 ap.add_argument("--ab", action="store_true", help="also measure without the anchored extension and compare the results")
 ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--sub-rate", type=float, default=0.01, help="substitutions per base of the on-target reads")
 ap.add_argument("--ab-var", default="SHK_NO_ANCHOR", help="the build-time switch --ab compares (SHK_NO_ANCHOR, SHK_NO_SPARSE)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -25,7 +26,7 @@ for ng in [int(x) for x in a.genes.split(",")]:
     genes = synth.make_reference(1, 20000) if ng == 1 else synth.make_gencode_like_reference(ng)
     bf_log2 = 33 if ng < 20000 else (36 if a.k <= 17 else 37)
     for ot in [float(x) for x in a.ot.split(",")]:
-        b = synth.make_pairs_device(a.pairs, genes, dev, seed=synth.SEED + 7, read_len=a.read_len, on_target=ot, with_qual=a.q > 0)
+        b = synth.make_pairs_device(a.pairs, genes, dev, seed=synth.SEED + 7, read_len=a.read_len, on_target=ot, with_qual=a.q > 0, sub_rate=a.sub_rate)
         torch.cuda.synchronize()
         ptr = {k: (v.data_ptr() if v is not None else 0) for k, v in b.items()}
         res = {}
@@ -44,7 +45,7 @@ for ng in [int(x) for x in a.genes.split(",")]:
             goff = np.empty(a.pairs + 1, np.uint32); hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
             gids = np.empty(max(int(r.n_assoc), 1), np.uint16); hip_memcpy_dtoh(gids, r.gene_ids, int(r.n_assoc) * 2)
             res[anchor] = (goff, gids[:int(r.n_assoc)])
-            print(json.dumps({"genes": ng, "bf_log2": bf_log2, "k": a.k, "q": a.q, "on_target": ot, "pairs": a.pairs, "anchored" if a.ab_var == "SHK_NO_ANCHOR" else "with": anchor, "read_len": a.read_len, "mode": h.probe_mode(),
+            print(json.dumps({"genes": ng, "bf_log2": bf_log2, "k": a.k, "q": a.q, "on_target": ot, "pairs": a.pairs, "anchored" if a.ab_var == "SHK_NO_ANCHOR" else "with": anchor, "read_len": a.read_len, "sub_rate": a.sub_rate, "mode": h.probe_mode(),
                               "n_set_bits": info["n_set_bits"], "kernel_ms": round(tm["total_ms"] / tm["n_launches"], 3), "n_assoc": int(r.n_assoc),
                               "last_n_long": tm["last_n_long"], "last_n_tie": tm["last_n_tie"]}), flush=True)
             h.close()
