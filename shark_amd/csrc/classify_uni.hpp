@@ -245,8 +245,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // disjoint k-mers k apart, counted back from the last slot of the pair, k bases each --; round B = the rest of the prefix.
   // A read from the gene is through behind round A (2 x 150 bp: 248 of the 180 bases needed, 97 % of the on-target pairs at
   // 1 % errors, instead of behind three rounds and a vote); a read without any match behind B is cut as before, the prefix
-  // being what the cut needs (bases_behind(128 - T) < c * len fixes T).  Everything else -- a few per cent -- probes the T left-over
-  // slots, brings the matches into the usual order and goes on as ever.  spT = 0: not used (several genes, another geometry).
+  // being what the cut needs (bases_behind(128 - T) < c * len fixes T).  Everything else -- a few per cent -- is brought into the
+  // usual order and tried again over the whole prefix and the tiles; what is still open probes the T left-over slots and goes on
+  // as ever.  spT = 0: not used (several genes, another geometry).
   // (Ragged batches on a one-gene index run this kernel with the exact table too -- see launch_classify_uni -- and plan per read.)
   constexpr bool SPARSE = LX && CUT && ACCEPT && !SHK_NO_SPARSE && U >= 3 && JA_ROUNDS >= 2 && JA_ROUNDS <= 3;
   uint32_t spT = 0, spLast = 0, spUb = 0;
