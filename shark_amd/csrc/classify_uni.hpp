@@ -1139,6 +1139,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // the rounds 0 and 1 are what probe_rounds would have left (matches validated), the read goes on behind the cut's first stop.
     auto sparse_first = [&]() -> bool {
       const uint32_t T = spT, nA = 64u - T, ln = (uint32_t)lane;
+      // (the read's one association: the index's gene)
+      auto write_the_gene = [&]() {
+        if (lane == 0 && !SHK_ABL(P, 64u)) {
+          sp_count[read] = 1u;
+          uint2 pk;
+          pk.x = P.lx_gene & 0xFFFFu;
+          pk.y = 0u;
+          *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+        }
+      };
       const bool tile = ln >= nA;
       const uint32_t sA = tile ? spLast - (ln - nA) * k : 2u * ln;
       bool hA = lx_hit_at(sA, true);
@@ -1154,13 +1164,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t step = nx ? 2u * ((uint32_t)__builtin_ctzll(nx) + 1u) : k;
         const uint32_t cov = wave_sum_u32((hA && !tile) ? (step < k ? step : k) : 0u) + k * (uint32_t)__builtin_popcountll(HA >> nA);
         if (cov >= thr_r) {
-          if (lane == 0 && !SHK_ABL(P, 64u)) {
-            sp_count[read] = 1u;
-            uint2 pk;
-            pk.x = P.lx_gene & 0xFFFFu;
-            pk.y = 0u;
-            *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
-          }
+          write_the_gene();
           return true;
         }
       }
@@ -1193,13 +1197,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint64_t H0 = __ballot(mt[0]), H1 = __ballot(mt[1]);
         const uint32_t cov = cover(H0, 0ull) + cover(H1, H0) + cover(0ull, H1) + k * (uint32_t)__builtin_popcountll(HA >> nA);
         if (cov >= thr_r) {
-          if (lane == 0 && !SHK_ABL(P, 64u)) {
-            sp_count[read] = 1u;
-            uint2 pk;
-            pk.x = P.lx_gene & 0xFFFFu;
-            pk.y = 0u;
-            *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
-          }
+          write_the_gene();
           return true;
         }
       }
