@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs.
-usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var"""
+usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var, GZ=1 (the sample files gzip -1 compressed: the inflate-bound path)"""
 import json, os, subprocess, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -53,22 +53,27 @@ t0 = time.time()
 write_fastq(os.path.join(td, "r1.fq"), 1)
 write_fastq(os.path.join(td, "r2.fq"), 2)
 gen_s = time.time() - t0
+SUFFIX = ""
+if os.environ.get("GZ", "0") == "1":
+    ps = [subprocess.Popen(["gzip", "-1", os.path.join(td, f)]) for f in ("r1.fq", "r2.fq")]
+    assert all(p.wait() == 0 for p in ps)
+    SUFFIX = ".gz"
 if os.environ.get('WARM', '1') == '1':      # read the files once, untimed: the first read of freshly written tmpfs pages pays for their LRU activation
     for f in ('r1.fq', 'r2.fq'):
-        subprocess.run(['cat', os.path.join(td, f)], stdout=subprocess.DEVNULL)
+        subprocess.run(['cat', os.path.join(td, f + SUFFIX)], stdout=subprocess.DEVNULL)
 # CLI_T=16,64 runs the same files once per thread count
 for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
     args = extra + (["-t", t] if t else [])
     t0 = time.time()
     with open(os.path.join(td, "out.ssv"), "wb") as so:
-        r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"),
-                            "-2", os.path.join(td, "r2.fq"), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-v"] + args,
+        r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq" + SUFFIX),
+                            "-2", os.path.join(td, "r2.fq" + SUFFIX), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-v"] + args,
                            stdout=so, stderr=subprocess.PIPE)
     t1 = time.time()
     dt = t1 - t0
     ep = [float(l.split("(epoch ")[1].rstrip(")")) for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]") and "(epoch " in l]
     gaps = {"before_main_ms": round((ep[0] - t0) * 1e3, 1), "after_last_ms": round((t1 - ep[-1]) * 1e3, 1)} if ep else {}
     print(json.dumps({"pairs": n, "gaps": gaps, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
-                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "headers": "var" if VAR else "fixed",
+                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "headers": "var" if VAR else "fixed", "gz": SUFFIX == ".gz",
                       "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:].split(" (epoch")[0] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
 subprocess.run(["rm", "-rf", td])
