@@ -98,6 +98,13 @@ int shk_index_info_get(const shk_ctx *ctx, shk_index_info *info);
  * builds it at up to 0.8 load (long probe paths), SHK_NO_LDS_TABLE=1 leaves
  * the LDS-resident table out; all three are for the tests. */
 const char *shk_probe_mode(const shk_ctx *ctx);
+/* The classify kernel instantiation the LAST batch's main launch ran, as rocprofv3 names it (e.g.
+ * "classify_uni_kernel<5, 5, false, 21, true>"; the last argument reads "device" when uniform_check_kernel decided on the
+ * device which of the two launched instantiations did the work).  On a panel-sized index the choice depends on the batch
+ * before (shk_probe_mode names the index's chains, this names what ran), so a timing or a profile can say what it measured.
+ * New: the reference has no counterpart.  The environment's test switches (SHK_FORCE_GENERIC, SHK_BIG_LDS_ALWAYS) are read
+ * once, by shk_create. */
+const char *shk_last_kernel(const shk_ctx *ctx);
 
 /* Parity introspection: copy the device-resident index to host buffers.
  * words: (bf_bits+63)/64 uint64_t in sdsl::bit_vector layout, bit i =

@@ -50,7 +50,7 @@ EXPORTS = [
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
     "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode", "shk_gene_counts_allreduce",
     "shk_classify_submit", "shk_classify_wait", "shk_dist_unique_id", "shk_dist_init", "shk_dist_gene_counts_allreduce",
-    "shk_dist_info", "shk_measure_random_lookups",
+    "shk_dist_info", "shk_measure_random_lookups", "shk_last_kernel",
 ]
 SHK_PIPE_DEPTH = 3
 SHK_DIST_ID_BYTES = 128
@@ -93,6 +93,7 @@ def load():
     L.shk_free_pinned.restype = None; L.shk_free_pinned.argtypes = [p]
     L.shk_version.restype = C.c_char_p; L.shk_version.argtypes = []
     L.shk_probe_mode.restype = C.c_char_p; L.shk_probe_mode.argtypes = [p]
+    L.shk_last_kernel.restype = C.c_char_p; L.shk_last_kernel.argtypes = [p]
     L.shk_gene_counts_allreduce.restype = C.c_int; L.shk_gene_counts_allreduce.argtypes = [C.POINTER(p), C.c_int, p, C.c_uint32]
     L.shk_classify_submit.restype = C.c_int; L.shk_classify_submit.argtypes = [p, C.POINTER(ShkBatch), C.POINTER(C.c_uint64)]
     L.shk_classify_wait.restype = C.c_int; L.shk_classify_wait.argtypes = [p, C.c_uint64, C.POINTER(ShkResult)]
@@ -167,6 +168,10 @@ class SharkHip:
 
     def probe_mode(self):
         return self.L.shk_probe_mode(self.h).decode()
+
+    def last_kernel(self):
+        """the classify kernel instantiation the last batch ran (rocprofv3's name for it)"""
+        return self.L.shk_last_kernel(self.h).decode()
 
     def copy_bf(self):
         nw = (self.bf_bits + 63) // 64

@@ -34,6 +34,8 @@
 // probes before the first wait.  `__ballot` of the pass / hit flags ends the read immediately when
 // nothing hit -- the common case for off-target reads.  DESIGN.md 3 has the full description and
 // what bounds the kernel.
+#include <cstdio>
+
 #include "classify_common.hpp"
 
 namespace shk {
@@ -859,14 +861,14 @@ int launch_classify_fast(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, 
   else if (u == 8) launch_fast_u<8>(p, mode, hasq, grid, stream);
   else launch_fast_u<10>(p, mode, hasq, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
+  snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_fast_kernel<%u, %d, %s>", u, mode, hasq ? "true" : "false");
   return SHK_OK;
 }
 
 // (SHK_FORCE_GENERIC=1: every batch through classify_fast_kernel / process_read -- the tests run both code paths)
 bool uni_kernel_available(const Ctx *ctx)
 {
-  const char *e = getenv("SHK_FORCE_GENERIC");
-  return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap && !(e && e[0] == '1');
+  return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap && !ctx->env_force_generic;
 }
 
 // classify_uni_kernel lives in classify_uni.hpp, instantiated per unroll in classify_uni_u<U>.hip
@@ -895,7 +897,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   // results; the denser the summary, the earlier the other kernel wins (measured crossover: 64 / 42 / 17 % of the pairs assigned
   // at 60 / 100 / 150 genes, pass rates 0.12 / 0.20 / 0.28).  SHK_BIG_LDS_ALWAYS=1: no switching (A/B timing, tests)
   bool many_assigned = false;
-  if (ctx->last.last_n_reads && ctx->idx.ref_total && ctx->idx.lbig_shift && !getenv("SHK_BIG_LDS_ALWAYS")) {
+  if (ctx->last.last_n_reads && ctx->idx.ref_total && ctx->idx.lbig_shift && !ctx->env_big_lds_always) {
     double f = 1.0 - 3.0 * ctx->idx.lbig_pass;
     f = f < 0.1 ? 0.1 : (f > 0.9 ? 0.9 : f);
     many_assigned = (double)ctx->last.last_n_assoc > f * (double)ctx->last.last_n_reads;
@@ -929,6 +931,11 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   else if (u == 8) launch_uni_u8(p, mode, hasq, false, false, uni, grid, stream);
   else launch_uni_u10(p, mode, hasq, big, lx, uni, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
+  // (with p.uni_flag both instantiations are launched and one returns at once: the name says UNI = "device")
+  if (uni || !p.uni_flag)
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s", u, mode, hasq ? "true" : "false",
+             (lx && (u <= 5 || u == 10)) ? 21 : ((big && (u <= 5 || u == 10)) ? 20 : 18), p.uni_flag ? "device" : (uni ? "true" : "false"),
+             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "", (lx && p.lx_gene != 0xFFFFFFFFu) ? " +sparse-first-round" : "");
   return SHK_OK;
 }
 

@@ -106,6 +106,12 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_ANCH_CUT
 #define SHK_ANCH_CUT 0
 #endif
+#if SHK_ANCH_CUT != 0 && !defined(SHK_TIMING_ONLY)
+#error "-DSHK_ANCH_CUT=n builds a library whose results are WRONG (timing-only ablation): say so with -DSHK_TIMING_ONLY as well"
+#endif
+#if defined(SHK_ABLATION) && !defined(SHK_TIMING_ONLY)
+#error "-DSHK_ABLATION builds a library that can return wrong results (SHK_ABLATE bits): say so with -DSHK_TIMING_ONLY as well"
+#endif
 // (-DSHK_NO_SPARSE=1: a build without the sparse first round of one-gene indices, for A/B timing; at run time SHK_NO_SPARSE=1 when the index is built)
 #ifndef SHK_NO_SPARSE
 #define SHK_NO_SPARSE 0

@@ -612,53 +612,63 @@ int build_index(Ctx *ctx)
             ix.ref2 = ix.refpay = ix.anchor = nullptr;
             ix.ref_total = 0;
           };
+          // Everything in here is optional, so nothing in here may fail the build: an allocation that cannot be had, a launch or a
+          // copy that fails -- the temporaries are freed, the extension is dropped, the sticky error is cleared and the index is
+          // complete without it.
+#define AX_HIP(call) do { if ((call) != hipSuccess) return false; } while (0)
           bool have = hipMalloc((void **)&ix.ref2, (n_dw + 4) * sizeof(uint32_t)) == hipSuccess &&
                       hipMalloc((void **)&ix.refpay, (total + 8) * sizeof(uint32_t)) == hipSuccess &&   // (+8: read 16 bytes at a time by tools)
                       hipMalloc((void **)&ix.anchor, (slots + 2) * sizeof(uint32_t)) == hipSuccess &&
                       hipMalloc((void **)&d_lost, sizeof(uint32_t)) == hipSuccess;
-          if (!have) { (void)hipGetLastError(); drop_anchor(); }
-          if (have) {
-            BI_HIP(hipMemsetAsync(ix.ref2 + n_dw, 0, 4 * sizeof(uint32_t), st));
-            BI_HIP(hipMemsetAsync(ix.refpay + total, 0xFF, 8 * sizeof(uint32_t), st));
-            BI_HIP(hipMemsetAsync(ix.anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
-            BI_HIP(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), st));
+          have = have && [&]() -> bool {
+            AX_HIP(hipMemsetAsync(ix.ref2 + n_dw, 0, 4 * sizeof(uint32_t), st));
+            AX_HIP(hipMemsetAsync(ix.refpay + total, 0xFF, 8 * sizeof(uint32_t), st));
+            AX_HIP(hipMemsetAsync(ix.anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
+            AX_HIP(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), st));
             hipLaunchKernelGGL(ref_pack2_kernel, dim3(grid_for(n_dw, 256)), dim3(256), 0, st, d_bytes, total, ix.ref2, n_dw);
-            BI_HIP(hipGetLastError());
+            AX_HIP(hipGetLastError());
             hipLaunchKernelGGL(ref_anchor_kernel, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st, d_bytes, total, d_rec_off, n_rec, k, ix.bf_bits,
                                ix.bf_bits - 1, ix.pow2 ? 1 : 0, (const uint64_t *)ix.tab, lg, ix.refpay, ix.anchor, d_lost);
-            BI_HIP(hipGetLastError());
+            AX_HIP(hipGetLastError());
             uint32_t h_lost = 0;
-            BI_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            BI_HIP(hipStreamSynchronize(st));
-            if (h_lost != 0) { have = false; drop_anchor(); }   // (a key the table does not hold: leave the extension out rather than trust it)
-          }
+            AX_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            AX_HIP(hipStreamSynchronize(st));
+            return h_lost == 0;   // (a key the table does not hold: leave the extension out rather than trust it)
+          }();
           (void)hipFree(d_lost);
           // multi-gene lists along the reference (see ref_multi_len_kernel); left out -- the lists then stay where the ranks point --
-          // when the copies would not fit the 32-bit list offsets or the 30-bit payload, or their memory cannot be had
-          if (have && n_set + 1 + total + 1 <= TAB_PAYLOAD && hipMalloc((void **)&d_lens, (total + 1) * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void **)&d_stmp, scan_temp_words(total + 1) * sizeof(uint64_t)) == hipSuccess) {
+          // when the copies would not fit the 32-bit list offsets or the 30-bit payload, or their memory cannot be had.  A failure
+          // behind the point where refpay has been rewritten drops the whole extension (ix.ent / ix.ids stay valid either way: their
+          // rank-ordered parts are copied before they are replaced).
+          have = have && [&]() -> bool {
+            if (!(n_set + 1 + total + 1 <= TAB_PAYLOAD && hipMalloc((void **)&d_lens, (total + 1) * sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&d_stmp, scan_temp_words(total + 1) * sizeof(uint64_t)) == hipSuccess))
+              return true;
             hipLaunchKernelGGL(ref_multi_len_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, (const uint32_t *)ix.refpay, total, (const ListEntry *)ix.ent, d_lens);
-            BI_HIP(hipGetLastError());
+            AX_HIP(hipGetLastError());
             const uint64_t *d_R = exclusive_scan_u32(d_lens, d_lens, total + 1, d_stmp, st);
             uint64_t R = 0;
-            BI_HIP(hipMemcpyAsync(&R, d_R, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-            BI_HIP(hipStreamSynchronize(st));
-            if (tot_idx + R + 8 < (1ull << 32) && R <= 16 * total && hipMalloc((void **)&ent_all, (n_set + 1 + total + 1) * sizeof(ListEntry)) == hipSuccess &&
-                hipMalloc((void **)&ids_all, (tot_idx + R + 8) * sizeof(uint16_t)) == hipSuccess) {
-              BI_HIP(hipMemcpyAsync(ent_all, ix.ent, (n_set + 1) * sizeof(ListEntry), hipMemcpyDeviceToDevice, st));
-              BI_HIP(hipMemcpyAsync(ids_all, ix.ids, (tot_idx + 8) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
-              BI_HIP(hipStreamSynchronize(st));
-              (void)hipFree(ix.ent); (void)hipFree(ix.ids);
-              ix.ent = ent_all; ix.ids = ids_all;
-              ent_all = nullptr; ids_all = nullptr;
-              hipLaunchKernelGGL(ref_multi_write_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, ix.refpay, total, ix.ent, n_set, ix.ids, (uint32_t)tot_idx,
-                                 (const uint32_t *)d_lens);
-              BI_HIP(hipGetLastError());
-              BI_HIP(hipStreamSynchronize(st));
-            }
-          }
-          (void)hipGetLastError();   // (an allocation that failed above is not an error of the build)
+            AX_HIP(hipMemcpyAsync(&R, d_R, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            AX_HIP(hipStreamSynchronize(st));
+            if (!(tot_idx + R + 8 < (1ull << 32) && R <= 16 * total && hipMalloc((void **)&ent_all, (n_set + 1 + total + 1) * sizeof(ListEntry)) == hipSuccess &&
+                  hipMalloc((void **)&ids_all, (tot_idx + R + 8) * sizeof(uint16_t)) == hipSuccess))
+              return true;
+            AX_HIP(hipMemcpyAsync(ent_all, ix.ent, (n_set + 1) * sizeof(ListEntry), hipMemcpyDeviceToDevice, st));
+            AX_HIP(hipMemcpyAsync(ids_all, ix.ids, (tot_idx + 8) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+            AX_HIP(hipStreamSynchronize(st));
+            (void)hipFree(ix.ent); (void)hipFree(ix.ids);
+            ix.ent = ent_all; ix.ids = ids_all;
+            ent_all = nullptr; ids_all = nullptr;
+            hipLaunchKernelGGL(ref_multi_write_kernel, dim3(grid_for(total + 1, 256)), dim3(256), 0, st, ix.refpay, total, ix.ent, n_set, ix.ids, (uint32_t)tot_idx,
+                               (const uint32_t *)d_lens);
+            AX_HIP(hipGetLastError());
+            AX_HIP(hipStreamSynchronize(st));
+            return true;
+          }();
+#undef AX_HIP
+          (void)hipGetLastError();   // (nothing that failed above is an error of the build)
           (void)hipFree(ent_all); (void)hipFree(ids_all); (void)hipFree(d_lens); (void)hipFree(d_stmp);
+          if (!have) drop_anchor();
           if (have) ix.ref_total = (uint32_t)total;
         }
       } else {

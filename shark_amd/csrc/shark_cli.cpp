@@ -573,6 +573,11 @@ class ReadAnalyzer {
 class OffsetWriter {
  public:
   OffsetWriter() = default;
+  // (every error return of main() that runs while a writer is in scope comes through here: the helper threads are joined, never
+  // destroyed while joinable -- that would be std::terminate instead of the exit code the caller was promised)
+  ~OffsetWriter() { (void)close(); }
+  OffsetWriter(const OffsetWriter &) = delete;
+  OffsetWriter &operator=(const OffsetWriter &) = delete;
   bool open(const std::string &path, unsigned helpers)
   {
     fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
@@ -1268,6 +1273,10 @@ int main(int argc, char *argv[])
       std::cerr << "[shark/io] threads " << io_threads << ", parallel readers " << n_readers << (fixed_width ? " fixed-width records (" : " (") << std::min<uint64_t>(irregular_at.load(), n_par_batches)
                 << " batches, " << tr << " thread-seconds), serial reader: " << (fs ? "index " + std::to_string(fs->t_index) + " s (" + fs->stage_report() + "), fill " + std::to_string(fs->t_fill) + " s, serial " + std::to_string(fs->t_serial) + " s" : std::string("not needed"))
                 << "; classify(gpu0) " << t_gpu[0] << " s, output " << t_out << " s" << std::endl;
+      // per GPU: seconds its analyzer thread spent inside shk_classify_submit / _wait (the host-fed multi-GPU leg of bench.py reads this)
+      std::cerr << "[shark/gpu-busy]";
+      for (int g = 0; g < n_gpus; ++g) std::cerr << " " << t_gpu[(size_t)g];
+      std::cerr << std::endl;
     }
     bool written = true;
     if (out1) written = w1.close() && written;

@@ -319,6 +319,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     p.n_work = n;
     p.work_count = nullptr;
     if ((rc = launch_classify_general(ctx, p, false, n_waves, st))) return rc;
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_general_kernel<wrap>");
   }
   if (!ctx->idx.wrap) {
     if (!table_kernel) {
@@ -530,6 +531,11 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   ctx->prm = *prm;
   ctx->prm.single = prm->single ? 1 : 0;
   ctx->q8 = (int8_t)(uint8_t)(prm->min_quality & 0xFF);                // static_cast<char>(mq), argument_parser.hpp:144
+  {
+    const char *e = getenv("SHK_FORCE_GENERIC");
+    ctx->env_force_generic = e && e[0] == '1';
+    ctx->env_big_lds_always = getenv("SHK_BIG_LDS_ALWAYS") != nullptr;
+  }
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };
 #define CR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP); } while (0)
   CR_HIP(hipSetDevice(prm->device));
@@ -621,6 +627,8 @@ const char *shk_probe_mode(const shk_ctx *ctx)
   if (!ctx || ctx->mode != 2) return "";
   return probe_mode_name(ctx);
 }
+
+const char *shk_last_kernel(const shk_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int shk_index_copy_bf(const shk_ctx *cctx, uint64_t *words, uint64_t n_words)
 {
@@ -868,6 +876,19 @@ int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint3
       const int init_rc = with_stdout_on_stderr([&] { return api.CommInitAll(comms.data(), n_ctx, devs.data()); });
       if (init_rc != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
       for (int i = 0; i < n_ctx; ++i) { ctxs[i]->group_comm = comms[(size_t)i]; ctxs[i]->group_devs = devs; }
+      // RCCL sets its channels up on a communicator's FIRST collective (of the order of the whole reduction of 512 KiB, or more): one
+      // throw-away all-reduce of the totals buffers, so that the reduction a caller times is a steady-state one
+      int wrc = api.GroupStart();
+      for (int i = 0; i < n_ctx && wrc == 0; ++i) {
+        (void)hipSetDevice(devs[(size_t)i]);
+        wrc = api.AllReduce(ctxs[i]->d_gene_totals, ctxs[i]->d_gene_totals, 65536, 5, 0, ctxs[i]->group_comm, ctxs[i]->stream);
+      }
+      if (wrc == 0) wrc = api.GroupEnd();
+      for (int i = 0; i < n_ctx; ++i) {
+        (void)hipSetDevice(devs[(size_t)i]);
+        (void)hipStreamSynchronize(ctxs[i]->stream);
+      }
+      if (wrc != 0) { c0->last_error = "ncclAllReduce (warm-up) failed"; return SHK_ERR_HIP; }
     }
     int rc = api.GroupStart();
     for (int i = 0; i < n_ctx && rc == 0; ++i) {
@@ -919,6 +940,13 @@ int shk_dist_init(shk_ctx *ctx, const uint8_t *id, int rank, int world)
   ctx->dist_comm = comm;
   ctx->dist_rank = rank;
   ctx->dist_world = world;
+  // the communicator's first collective sets RCCL's channels up: made here (every rank is in this call), on the totals buffer, so
+  // that shk_dist_gene_counts_allreduce is a steady-state collective from its first use on
+  if (api.AllReduce(ctx->d_gene_totals, ctx->d_gene_totals, 65536, 5, 0, comm, ctx->stream) != 0) {
+    ctx->last_error = "ncclAllReduce (warm-up) failed";
+    return SHK_ERR_HIP;
+  }
+  SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SHK_OK;
 }
 

@@ -266,6 +266,13 @@ struct Ctx {
   void *group_comm = nullptr;
   std::vector<int> group_devs;
 
+  // test / A-B switches of the environment, read ONCE when the context is created (never per launch):
+  //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
+  //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
+  bool env_force_generic = false, env_big_lds_always = false;
+  // which classify kernel the last batch's main launch was (shk_last_kernel): the choice can depend on the batch before it
+  char last_kernel[96] = "";
+
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev_start, ev_stop;

@@ -68,6 +68,18 @@ def max_over_ranks(seconds, device):
     return seconds
 
 
+def gather_rows(row, device):
+    """every rank's list of floats -> list of lists, on every rank (the job's own channel; world 1: [row])"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [list(row)]
+    t = torch.tensor(list(row), dtype=torch.float64, device=device)
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        t = t.cpu()
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu().tolist()] for o in out]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

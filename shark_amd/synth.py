@@ -99,7 +99,12 @@ def make_pairs_device(n, genes, device, seed=SEED, read_len=150, on_target=0.5, 
             for qq in (qual1, qual2):
                 qq[b0 * L:(b0 + m) * L] = _qualities(m, L, g, device, qual_model).reshape(-1)
     off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=device)
-    return {"seq1": seq1, "off1": off, "seq2": seq2, "off2": off.clone(), "qual1": qual1, "qual2": qual2}
+    out = {"seq1": seq1, "off1": off, "seq2": seq2, "off2": off.clone(), "qual1": qual1, "qual2": qual2}
+    # libsharkhip works on its own NON-BLOCKING streams: they do not wait for torch's stream, so the batch has to be complete before
+    # its pointers are handed over (a caller that classified right away read offsets that were still being written -- found as a
+    # memory fault in bench.py's CLI leg, round 4)
+    torch.cuda.synchronize(device)
+    return out
 
 
 def to_host_sample(batch, n_sample, read_len=150, first=0):

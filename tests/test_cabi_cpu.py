@@ -115,3 +115,25 @@ def test_cli_reports_a_sample_that_cannot_be_opened(built, tmp_path):
     assert r.returncode == 1 and "cannot open the sample" in r.stderr
     r = subprocess.run([CLI, "-r", str(fa), "-1", str(fq), "-2", str(tmp_path / "nonexistent.fq")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open the sample" in r.stderr
+
+
+def test_cli_error_exits_are_exit_code_1_with_the_default_outputs(built, tmp_path):
+    """every error return behind the point where the output writers exist -- with the DEFAULT -o (sharked_sample.1 is always opened,
+    argument_parser.hpp:168-173, so a writer with live helper threads is in scope) -- is exit code 1 and a message, never
+    std::terminate from a joinable thread's destructor (rc 134): a reference that cannot be opened, and, on a box without a GPU,
+    the context that cannot be created"""
+    fq = tmp_path / "a.fq"
+    fq.write_text("@r\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n")
+    r = subprocess.run([CLI, "-r", str(tmp_path / "nonexistent.fa"), "-1", str(fq), "-2", str(fq)], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    assert "cannot open" in r.stderr and "terminate called" not in r.stderr
+    import torch
+    if torch.cuda.is_available():
+        return
+    fa = tmp_path / "g.fa"
+    fa.write_text(">g\nACGTACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([CLI, "-r", str(fa), "-1", str(fq), "-2", str(fq)], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    assert "cannot create a context on GPU 0" in r.stderr and "terminate called" not in r.stderr
+    r = subprocess.run([CLI, "-r", str(fa), "-1", str(fq)], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert r.returncode == 1 and "terminate called" not in r.stderr

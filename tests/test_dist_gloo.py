@@ -83,3 +83,28 @@ def test_byte_range_partition_reproduces_the_single_process_ssv(oracle, tmp_path
         meta = json.load(open(str(out) + ".json"))
         assert meta["batches"] == (1700 + batch - 1) // batch
         assert sum(meta["counts"]) == want.read_bytes().count(b"\n")
+
+
+def test_bench_read_set_shards_are_a_partition_at_every_rank_count():
+    """bench.py's strong-scaling split (the same read set whatever N): at 1, 2, 4, 8 GPUs -- and the odd counts -- the ranks' chunk
+    lists tile the chunk ids, every rank gets equally many, and at the default sizes (80 M pairs, 10 M per launch) the chunks are
+    the SAME 8 chunks at every power of two, so gene_count_checksum cannot depend on N.  (The 8-rank run itself is the driver's: a
+    one-GPU box takes at most six processes on its card, so the GPU suite rehearses 4 ranks over gloo.)"""
+    import importlib.util
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 3, 4, 5, 6, 7, 8):
+        seen, per_pass, cp0 = [], None, None
+        for r in range(world):
+            cp, mine, allp = bench.shard_chunks("strong", 80_000_000, 10_000_000, world, r)
+            seen += mine
+            assert per_pass in (None, allp) and cp0 in (None, cp)
+            per_pass, cp0 = allp, cp
+            assert len(mine) == len(seen) // (r + 1)
+        assert sorted(seen) == list(range(len(seen))) and cp0 * len(seen) == per_pass
+        if world in (1, 2, 4, 8):
+            assert cp0 == 10_000_000 and len(seen) == 8 and per_pass == 80_000_000
+        cp, mine, allp = bench.shard_chunks("weak", 80_000_000, 10_000_000, world, world - 1)
+        assert (cp, mine, allp) == (10_000_000, [world - 1], 10_000_000 * world)

@@ -359,12 +359,15 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("launcher,scaling", [("self", "strong"), ("torchrun", "strong"), ("self", "weak")])
-def test_bench_two_ranks_dry_run(tmp_path, launcher, scaling):
-    """the N>1 code path of bench.py (rank env, shards of one read set, barrier, MAX over ranks, count all-reduce) with
-    two ranks sharing the one GPU of the test box over gloo; the real multi-GPU run uses RCCL inside the library.
-    launcher "self": exactly the driver's form, `python3 bench.py --gpus 2 ...` -- bench.py starts its two ranks itself
-    (main.cpp:219-223 starts the reference's workers from the one command line); "torchrun": the contract's launcher form."""
+@pytest.mark.parametrize("launcher,scaling,ranks", [("self", "strong", 2), ("torchrun", "strong", 2), ("self", "weak", 2), ("self", "strong", 4)])
+def test_bench_ranks_dry_run(tmp_path, launcher, scaling, ranks):
+    """the N>1 code path of bench.py (rank env, shards of one read set, passes per step, warm-up collective, barrier, MAX over
+    ranks, count all-reduce, the per-rank split gathered over the job's channel, the other ranks' wait for rank 0) with `ranks`
+    ranks sharing the one GPU of the test box over gloo; the real multi-GPU run uses RCCL inside the library.
+    launcher "self": exactly the driver's form, `python3 bench.py --gpus N ...` -- bench.py starts its ranks itself
+    (main.cpp:219-223 starts the reference's workers from the one command line); "torchrun": the contract's launcher form.
+    Four ranks is what one card takes next to this process (the box allows six processes on it); the split for 8 is checked on
+    the CPU (tests/test_dist_gloo.py)."""
     import json
     import subprocess
     import sys
@@ -372,32 +375,43 @@ def test_bench_two_ranks_dry_run(tmp_path, launcher, scaling):
     env = dict(os.environ, SHARK_DIST_BACKEND="gloo")
     for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
-    base = [os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "250000", "--total-pairs", "1000000",
-            "--scaling", scaling, "--no-configs", "--no-boundary", "--no-cpu-baseline", "--no-cli"]
+    reps = 2
+    base = [os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "250000", "--total-pairs", "1000000", "--reps-per-step", str(reps),
+            "--scaling", scaling, "--no-configs", "--no-boundary", "--no-cpu-baseline", "--no-cli", "--no-live-counters"]
     if launcher == "self":
-        cmd = ["python3"] + base + ["--gpus", "2"]
+        cmd = ["python3"] + base + ["--gpus", str(ranks)]
     else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port())] + base + ["--gpus", "2"]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + base + ["--gpus", str(ranks)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out_lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(out_lines) == 1, r.stdout[-2000:]          # ONE JSON line, rank 0's
     j = json.loads(out_lines[0])
-    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == scaling and j["cpu_baseline"] is None
+    assert j["n_gpus"] == ranks and j["ranks_seen"] == ranks and j["scaling"] == scaling and j["cpu_baseline"] is None
     assert j["config"]["gene_count_checksum"] == j["config"]["assoc_per_step"] > 0
+    # every rank's split of the timed window, gathered over the job's own channel
+    pr = j["per_rank"]
+    assert [x["rank"] for x in pr] == list(range(ranks))
+    for x in pr:
+        assert x["launches"] == 2 * j["config"]["launches_per_step_per_gpu"] and x["kernel_ms"] > 0 and x["wall_ms"] >= x["kernel_ms"] * 0.5
+        assert x["allreduce_ms"] >= 0 and x["barrier_wait_ms"] >= 0
+        assert x["wall_ms"] + x["allreduce_ms"] + x["barrier_wait_ms"] <= j["ms_per_step"] * 2 * 1.001 + 1.0   # inside the (max over ranks) window
+    # the roofline never claims more than the resource it names has (without counters: the compulsory HBM bytes)
+    assert 0 < j["roofline"]["frac"] <= 1 and j["roofline"]["bound"] in ("hbm", "valu-issue", "memory-side-request-rate")
+    assert j["roofline"]["hbm_compulsory"]["frac_of_hbm_peak"] <= 1
     if scaling == "strong":
         # the same read set on one GPU: same reads per step, same associations
         r1 = subprocess.run([sys.executable] + base + ["--gpus", "1"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
         assert r1.returncode == 0, r1.stderr[-3000:]
         j1 = json.loads([x for x in r1.stdout.splitlines() if x.startswith("{")][-1])
-        assert j1["n_gpus"] == 1 and j1["ranks_seen"] == 1
-        assert j["config"]["reads_per_step"] == j1["config"]["reads_per_step"] == 2 * 1000000
+        assert j1["n_gpus"] == 1 and j1["ranks_seen"] == 1 and len(j1["per_rank"]) == 1
+        assert j["config"]["reads_per_step"] == j1["config"]["reads_per_step"] == 2 * 1000000 * reps
         assert j["config"]["assoc_per_step"] == j1["config"]["assoc_per_step"]
         assert j["config"]["gene_count_checksum"] == j1["config"]["gene_count_checksum"]
-        assert j1["config"]["launches_per_step_per_gpu"] == 2 * j["config"]["launches_per_step_per_gpu"]
+        assert j1["config"]["launches_per_step_per_gpu"] == ranks * j["config"]["launches_per_step_per_gpu"]
     else:
-        assert j["config"]["reads_per_step"] == 2 * 2 * 250000
+        assert j["config"]["reads_per_step"] == ranks * 2 * 250000 * reps
 
 
 def test_bench_refuses_a_rank_count_that_is_not_gpus():
@@ -412,7 +426,7 @@ def test_bench_refuses_a_rank_count_that_is_not_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SHARK_DIST_BACKEND")}
     n_dev = torch.cuda.device_count()
     r = subprocess.run(["python3", os.path.join(root, "bench.py"), "--gpus", str(n_dev + 1), "--steps", "1", "--no-configs", "--no-boundary",
-                        "--no-cpu-baseline", "--no-cli"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+                        "--no-cpu-baseline", "--no-cli", "--no-live-counters"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert r.returncode != 0 and "GPU(s)" in r.stderr and not r.stdout.strip()
 
 
@@ -610,6 +624,39 @@ def test_full_size_properties_config2():
     m = 3_333_333
     g6, _ = run(b["seq1"], b["off1"], b["seq2"], b["off2"], m=m)
     assert np.array_equal(g6, goff[:m + 1])
+
+
+def test_full_size_config2_equals_the_oracle(oracle):
+    """BASELINE configs[1] at full size -- the bench's own launch: 10 M pairs 2x150 bp (50 % on-target, 1 % substitutions, 0.2 % N),
+    1 gene x 20 kb, k=17, c=0.6, 2^33-bit filter, resident in HBM -- equals the oracle on EVERY pair, offsets and gene ids (the
+    oracle on all host threads; bench.py makes the same comparison in its cpu_baseline leg).  The launch takes the exact LDS table
+    with the sparse first round, the bound cut and the early decision: each shortcut's own test uses batches of a few hundred
+    reads, this one is the 10 M-pair equality."""
+    from shark_amd import synth as dsynth
+    from shark_amd.capi import hip_memcpy_dtoh
+    n, L = 10_000_000, 150
+    dev = torch.device("cuda:0")
+    genes = dsynth.make_reference(1, 20000)
+    h = _hip(k=17, c=0.6, bf_bits=1 << 33)
+    h.build([g.tobytes() for g in genes])
+    b = dsynth.make_pairs_device(n, genes, dev, seed=dsynth.SEED + 1, read_len=L, on_target=0.5)
+    torch.cuda.synchronize()
+    r = h.classify_device(n, b["seq1"].data_ptr(), b["off1"].data_ptr(), b["seq2"].data_ptr(), b["off2"].data_ptr(), max_read_len=L)
+    assert "classify_uni_kernel<5, " in h.last_kernel() and ", 21, " in h.last_kernel() and "+sparse-first-round" in h.last_kernel(), h.last_kernel()
+    goff = np.empty(n + 1, np.uint32)
+    hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+    gids = np.empty(int(r.n_assoc), np.uint16)
+    hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+    hb = dsynth.to_host_sample(b, n, L)
+    o = oracle.Shark(k=17, c=0.6, bf_bits=1 << 33)
+    o.build([g.tobytes() for g in genes])
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    og, oi = o.classify(hb["seq1"], hb["off1"], hb["seq2"], hb["off2"], nthreads=threads)
+    o.close()
+    assert np.array_equal(og, goff), "gene_off differs at read %d" % int(np.argmax(og != goff))
+    assert np.array_equal(oi, gids)
+    assert 0.45 * n < int(goff[-1]) < 0.55 * n
+    h.close()
 
 
 def test_gene_counts_allreduce_over_rccl(oracle, tmp_path, monkeypatch):
@@ -1045,11 +1092,18 @@ def test_panel_sized_index_follows_the_assigned_fraction(oracle, monkeypatch):
             monkeypatch.setenv("SHK_BIG_LDS_ALWAYS", "1")
         o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 33)
         assert "lds" not in h.probe_mode()
-        fr = []
+        fr, kernels = [], set()
         for b in (on, on, off, off, mix, on, mix, off, on):
             goff, _ = _compare_classify(o, h, b)
             fr.append(int(goff[-1]) / 3000)
+            kernels.add(h.last_kernel())
         assert max(fr) > 0.9 and min(fr) < 0.05
+        # what ran (shk_last_kernel): with the switching on both the 128 KiB LDS summary (LSL = 20) and the position-table kernel with
+        # the anchored extension took batches; with SHK_BIG_LDS_ALWAYS=1 (read once, at shk_create) only the former
+        lds = {x for x in kernels if ", 20, " in x}
+        tab = {x for x in kernels if "+anchored-extension" in x}
+        assert lds, kernels
+        assert (not tab) if always else bool(tab), kernels
         h.close()
 
 
@@ -1323,6 +1377,9 @@ def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
                     batch = _sequenced_pairs(rng, genes, 400, L1, L2, ragged, q > 0, sub_rate, indel_rate, 0.002)
                     goff, _ = _compare_classify(o, h, batch)
                     assert goff[-1] > 0 or c > 0.6
+                    # the A side ran WITH the extension, the B side without (the switch is read when the index is built)
+                    if "classify_uni_kernel" in h.last_kernel():
+                        assert ("+anchored-extension" in h.last_kernel()) == anchor, h.last_kernel()
             if q == 0:
                 _probe_every_kmer(o, h, genes, k, stride=7)
             h.close()
@@ -1359,6 +1416,9 @@ def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
                     batch = _sequenced_pairs(rng, genes, 350, L1, L2, ragged, q > 0, sub_rate, 0.002 if sub_rate else 0.0, 0.003)
                     goff, _ = _compare_classify(o, h, batch)
                     n_assigned += int(goff[-1])
+                    # the A side ran the sparse order, the B side the usual one (the switch is read when the index is built)
+                    if ", 21, " in h.last_kernel():
+                        assert ("+sparse-first-round" in h.last_kernel()) == sparse, h.last_kernel()
                 batch = _chimeric_batch(rng, genes, 700, L1, L2, ragged, with_n=True, qual=q > 0, k_hint=k)
                 goff, _ = _compare_classify(o, h, batch)
                 n_assigned += int(goff[-1])

@@ -10,9 +10,9 @@ name; the per-GPU shard of the 8-GPU configs).  Checked per config:
   * both probe chains (position table vs filter words + rank directory) give identical results
   * a 200 000-pair sample of the batch is bit-equal to the oracle's associations
   * per-gene counters equal the histogram of the per-read results
-  * configs[2] at its full length: 100 M pairs streamed through shk_classify_submit / _wait in 4 M-pair batches (three in
-    flight), every batch equal to the resident classification of the same pairs, counters = histogram, oracle sample of
-    the last batch
+  * configs[2] AND configs[4] at their full length: 100 M pairs / 200 M pairs with qualities streamed through
+    shk_classify_submit / _wait in 4 M-pair batches (three in flight), every batch equal to the resident classification of
+    the same pairs, counters = histogram, oracle sample of the last batch
   * membership at scale: 50 M reference k-mers, each classified as a read of its own, all come back assigned (a key
     the position table had lost, or a search that ends too early, would show here and nowhere in whole-read parity),
     and both probe chains return the same associations for them
@@ -54,8 +54,9 @@ STREAM_PAIRS = 100_000_000
 STREAM_BATCH = 4_000_000
 
 
-def _stream_full_length(h, o, batch, goff, gids):
-    """BASELINE configs[2]'s full stream -- 100 M pairs -- through shk_classify_submit / _wait in batches of 4 M pairs, three in
+def _stream_full_length(h, o, batch, goff, gids, stream_pairs=STREAM_PAIRS, min_assigned=0.45):
+    """BASELINE configs[2]'s full stream -- 100 M pairs -- (configs[4]: 200 M pairs = 400 M reads, WITH their qualities: twice the
+    bytes over the link) through shk_classify_submit / _wait in batches of 4 M pairs, three in
     flight, as the reference streams a sample of any length in chunks (main.cpp:66-77, FastqSplitter.hpp:47-93).  The pool of
     10 M device-generated pairs is copied to pinned host memory once; batch i is the window of 4 M pairs that starts at a
     rolling offset, so consecutive batches differ.  Every batch's associations must equal the resident classification of the
@@ -64,8 +65,11 @@ def _stream_full_length(h, o, batch, goff, gids):
     from shark_amd.capi import SHK_PIPE_DEPTH
     pool1 = batch["seq1"].cpu().pin_memory().numpy()
     pool2 = batch["seq2"].cpu().pin_memory().numpy()
+    hasq = batch.get("qual1") is not None
+    qool1 = batch["qual1"].cpu().pin_memory().numpy() if hasq else None
+    qool2 = batch["qual2"].cpu().pin_memory().numpy() if hasq else None
     off = np.arange(0, (STREAM_BATCH + 1) * L, L, dtype=np.uint64)
-    n_batches = STREAM_PAIRS // STREAM_BATCH
+    n_batches = stream_pairs // STREAM_BATCH
     firsts = [(i * 1_000_003) % (PAIRS - STREAM_BATCH) for i in range(n_batches)]
     cnt = np.diff(goff.astype(np.int64))
     h.gene_counts_reset()
@@ -86,22 +90,25 @@ def _stream_full_length(h, o, batch, goff, gids):
     for first in firsts:
         if len(tickets) == SHK_PIPE_DEPTH:
             drain()
-        tickets.append((first, h.submit(pool1[first * L:(first + STREAM_BATCH) * L], off, pool2[first * L:(first + STREAM_BATCH) * L], off)))
+        sl = slice(first * L, (first + STREAM_BATCH) * L)
+        tickets.append((first, h.submit(pool1[sl], off, pool2[sl], off, qool1[sl] if hasq else None, qool2[sl] if hasq else None)))
     while tickets:
         drain()
-    assert total > 0.45 * STREAM_PAIRS
+    assert total > min_assigned * stream_pairs
     assert np.array_equal(h.gene_counts(65536), hist), "per-gene counters differ from the histogram of the streamed results"
     first, bo, bi = last
     lo = STREAM_BATCH - SAMPLE                                   # the tail of the last batch
     s1 = pool1[(first + lo) * L:(first + STREAM_BATCH) * L]
     s2 = pool2[(first + lo) * L:(first + STREAM_BATCH) * L]
     so = np.arange(0, (SAMPLE + 1) * L, L, dtype=np.uint64)
-    og, oi = o.classify(s1, so, s2, so, None, None, nthreads=min(os.cpu_count() or 1, 64))
+    q1 = qool1[(first + lo) * L:(first + STREAM_BATCH) * L] if hasq else None
+    q2 = qool2[(first + lo) * L:(first + STREAM_BATCH) * L] if hasq else None
+    og, oi = o.classify(s1, so, s2, so, q1, q2, nthreads=min(os.cpu_count() or 1, 64))
     assert np.array_equal(og.astype(np.int64), bo[lo:].astype(np.int64) - int(bo[lo]))
     assert np.array_equal(oi, bi[int(bo[lo]):])
 
 
-def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words, stream=False):
+def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words, stream=0, min_assigned=0.45):
     from shark_amd import SharkHip, synth
     from shark_amd.capi import hip_memcpy_dtoh
     genes = synth.make_gencode_like_reference(60000)
@@ -162,7 +169,7 @@ def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words, strea
         kres[mode] = (koffs, kids)
         del kseq, koff, kqual
         if stream and mode == "auto":
-            _stream_full_length(h, o, batch, goff, gids)
+            _stream_full_length(h, o, batch, goff, gids, stream, min_assigned)
         h.close()
     assert np.array_equal(res["auto"][0], res["bitvector"][0]) and np.array_equal(res["auto"][1], res["bitvector"][1]), \
         "the two probe chains disagree"
@@ -181,15 +188,17 @@ def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words, strea
 
 def test_config2_gencode_scale_k17_8gb(oracle, monkeypatch):
     """BASELINE configs[2] (and [3]'s per-GPU shard): 60 000 genes, k=17, c=0.6, bf = 2^36 bits."""
-    goff, gids = _scale_case(oracle, monkeypatch, k=17, bf_log2=36, q=0, single=False, compare_words=True, stream=True)
+    goff, gids = _scale_case(oracle, monkeypatch, k=17, bf_log2=36, q=0, single=False, compare_words=True, stream=STREAM_PAIRS)
     cnt = np.diff(goff.astype(np.int64))
     assert 0.45 * PAIRS < (cnt > 0).sum() < 0.60 * PAIRS     # half the pairs are drawn from genes
     assert (cnt > 1).sum() > 100_000                          # shared gene halves: genuine ties
 
 
 def test_config4_gencode_scale_k31_q20_single_16gb(oracle, monkeypatch):
-    """BASELINE configs[4]: k=31 (max k), -q 20 (quality-mask path), --single, bf = 2^37 bits."""
-    goff, gids = _scale_case(oracle, monkeypatch, k=31, bf_log2=37, q=20, single=True, compare_words=False)
+    """BASELINE configs[4]: k=31 (max k), -q 20 (quality-mask path), --single, bf = 2^37 bits -- and its full stream: 200 M pairs
+    (400 M reads) with their qualities through submit / wait, as the reference streams a sample of any length in 50 000-read
+    chunks (FastqSplitter.hpp:47-93; the qualities are consumed at :70,:84,:104-109)."""
+    goff, gids = _scale_case(oracle, monkeypatch, k=31, bf_log2=37, q=20, single=True, compare_words=False, stream=200_000_000, min_assigned=0.30)
     cnt = np.diff(goff.astype(np.int64))
     assert cnt.max() == 1                                     # --single: never more than one gene per read
     # qualities low at the read ends only (shark_amd/synth.py "ends"): most on-target pairs keep enough valid 31-mers, so the

@@ -19,7 +19,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "profiles")
 KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]    # same list as bench.py
 
@@ -52,22 +52,21 @@ commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], cap
 dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "shark_amd/csrc"], capture_output=True, text=True).stdout.strip()
 out = {
     "commit": commit + ("+dirty" if dirty else ""), "kernel_src_sha": kernel_src_sha(), "k": 17, "bf_log2": 33,
-    "how": "tools/gpu_profiles.sh: rocprofv3 --pmc <one counter set per run> --kernel-trace; per launch of the kernel that does the "
-           "work (10 M pairs 2x150 bp); FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (uncorrected)",
+    "how": "tools/gpu_profiles.sh -> bench.py --profile-passes: rocprofv3 --pmc <one counter set per child run> --kernel-trace; per launch of the kernel that "
+           "does the work (10 M pairs 2x150 bp; the last of three launches); FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (uncorrected)",
     "kernel_stats": {k: {"calls": c, "avg_ms": round(ms, 4)} for k, (c, ms) in avg_ms.items()},
     "workloads": {},
 }
-for wl, kernels in raw.items():
-    # the kernel that did the work = the one with the most VALU instructions
-    kn = max(kernels, key=lambda k: kernels[k].get("SQ_INSTS_VALU", 0))
-    c = kernels[kn]
-    name = wl if wl == "configs2" else "configs1_ot%.2f" % float(wl.split("ot")[1])
-    e = {"kernel": kn.replace("void shk::", ""), "pairs": 10_000_000}
+for name, c in raw.items():
+    # bench.py --profile-passes: {workload: {"kernel": ..., counter: value per launch, ...}}
+    if not c:
+        continue
+    e = {"kernel": c.get("kernel"), "kernel_reported_by_library": c.get("kernel_reported_by_library"), "pairs": 10_000_000, "n_assoc": c.get("n_assoc")}
     for key in ("FETCH_SIZE", "WRITE_SIZE"):
         if key in c:
             e[key + "_KB"] = c[key]
     for key in ("TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
-                "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_THREAD_CYCLES_VALU"):
+                "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_INST_CYCLES_VMEM"):
         if key in c:
             e[key] = c[key]
     if "SQ_INSTS_VALU" in e:
@@ -75,6 +74,8 @@ for wl, kernels in raw.items():
         e["salu_per_pair"] = round(e.get("SQ_INSTS_SALU", 0) / e["pairs"], 1)
         if "SQ_THREAD_CYCLES_VALU" in e:
             e["active_lanes_per_valu"] = round(e["SQ_THREAD_CYCLES_VALU"] / e["SQ_INSTS_VALU"], 1)
+    if "TCC_MISS_sum" in e:
+        e["memory_side_requests_per_pair"] = round(e["TCC_MISS_sum"] / e["pairs"], 1)
     out["workloads"][name] = e
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:2500])

@@ -1,0 +1,45 @@
+#!/bin/bash
+# GPU-box driver: tools/gpu_steps.sh <tag> <step> [<step> ...]   (through gpurun; see tools/gpu.sh)
+# Every step logs to gpurun_out/<tag>/<step>.log and the run stops at the first step that fails (no GPU step is started behind
+# one that timed out or was killed).  Steps:
+#   suite            the whole `pytest -m gpu` suite          scale      tests/test_gpu_scale.py (configs[2] / configs[4] shapes)
+#   t:<expr>         pytest tests/test_gpu_parity.py -k <expr>           fuzz       tests/test_gpu_fuzz.py
+#   bench            the default bench line (what the driver runs)       bench_quick  headline only, no side legs
+#   bench:<args>     bench.py with the given arguments (comma separated)
+#   profiles         tools/gpu_profiles.sh (kernel stats + counter passes for profiles/)
+#   land:<args>      tools/landscape.py <args> (comma separated)         ragged:<genes>  tools/ragged_rate.py (GENES=<genes>)
+#   ab:<ot>:<lib>... bench workload at on-target <ot> on library variants (base = in-tree, else tools/variants/<lib>.so), interleaved
+#   py:<script+args> python3 <script> <args> (comma separated)           mem        memory / tmpfs / cpu figures of the box
+tag=$1; shift
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+for step in "$@"; do
+  echo "== $step $(date +%T)"
+  log=$out/$(echo "$step" | tr ':/ ,' '____').log
+  case $step in
+    suite)       timeout -k 10 1150 python3 -m pytest tests -m gpu -x -q --durations=15 > $log 2>&1 ;;
+    scale)       timeout -k 10 1150 python3 -m pytest tests/test_gpu_scale.py -x -q --durations=5 > $log 2>&1 ;;
+    fuzz)        timeout -k 10 900 python3 -m pytest tests/test_gpu_fuzz.py -x -q -s > $log 2>&1 ;;
+    t:*)         timeout -k 10 1150 python3 -m pytest tests/test_gpu_parity.py -k "${step#t:}" -x -q --durations=8 > $log 2>&1 ;;
+    bench)       timeout -k 10 900 python3 bench.py > $out/bench.json 2> $log ;;
+    bench_quick) timeout -k 10 600 python3 bench.py --no-configs --no-boundary --no-cpu-baseline --no-cli --no-live-counters > $out/bench_quick.json 2> $log ;;
+    bench:*)     timeout -k 10 900 python3 bench.py $(echo "${step#bench:}" | tr ',' ' ') > $log.json 2> $log ;;
+    profiles)    bash tools/gpu_profiles.sh > $log 2>&1 ;;
+    land:*)      timeout -k 10 900 python3 tools/landscape.py $(echo "${step#land:}" | tr ',' ' ') > $log.jsonl 2> $log ;;
+    ragged:*)    GENES=${step#ragged:} timeout -k 10 600 python3 tools/ragged_rate.py > $log.jsonl 2> $log ;;
+    py:*)        timeout -k 10 900 python3 $(echo "${step#py:}" | tr ',' ' ') > $log.out 2> $log ;;
+    ab:*)        IFS=: read -r _ ot libs <<< "$step"
+                 for rep in 1 2; do for v in $(echo $libs | tr ':' ' '); do
+                   if [ $v = base ]; then unset SHK_LIB_PATH; else export SHK_LIB_PATH=$PWD/tools/variants/$v.so; fi
+                   timeout -k 10 300 python3 bench.py --no-configs --no-cpu-baseline --no-boundary --no-cli --no-live-counters --steps 2 --reps-per-step 2 --total-pairs 20000000 --on-target $ot 2>> $log \
+                     | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['config']['on_target'], d['roofline']['kernel_ms'], d['config']['assoc_per_step'], d['roofline']['kernel_reported_by_library'])" | tee -a $log.txt
+                 done; done; unset SHK_LIB_PATH ;;
+    mem)         { nproc; free -g; df -h /dev/shm /tmp; cat /sys/fs/cgroup/memory.max /sys/fs/cgroup/cpu.max 2>/dev/null; grep -c processor /proc/cpuinfo; which rocprofv3; } > $log 2>&1 ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+  rc=$?
+  echo "rc=$rc" >> $log
+  tail -4 $log
+  if [ $rc -ne 0 ]; then echo "step $step failed (rc=$rc): stopping"; exit $rc; fi
+done
