@@ -609,16 +609,35 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
   __syncthreads();
   const uint64_t n = P.n;
   const uint64_t L1 = n ? P.off1[1] - P.off1[0] : 0, L2 = (n && P.seq2) ? P.off2[1] - P.off2[0] : 0;
+  __shared__ uint32_t max_s[2];
+  if (threadIdx.x == 0) { max_s[0] = 0; max_s[1] = 0; }
+  __syncthreads();
   uint32_t bad = 0;
+  uint64_t mx1 = 0, mx2 = 0;   // the longest mates: the ragged instantiation stages the whole batch in their layout
   if (blockIdx.x == 0 && threadIdx.x == 0 && n) bad |= (P.off1[0] != 0) | (P.seq2 && P.off2[0] != 0);
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    bad |= (P.off1[i + 1] - P.off1[i]) != L1;
-    if (P.seq2) bad |= (P.off2[i + 1] - P.off2[i]) != L2;
+    const uint64_t l1 = P.off1[i + 1] - P.off1[i];
+    bad |= l1 != L1;
+    mx1 = l1 > mx1 ? l1 : mx1;
+    if (P.seq2) {
+      const uint64_t l2 = P.off2[i + 1] - P.off2[i];
+      bad |= l2 != L2;
+      mx2 = l2 > mx2 ? l2 : mx2;
+    }
   }
-  if (bad) atomicOr(&bad_s, 1u);
+  if (bad) {
+    atomicOr(&bad_s, 1u);
+    // (clipped: a mate of 2^31 bases or more fits no specialisation and the kernel clamps the layout anyway)
+    atomicMax(&max_s[0], (uint32_t)(mx1 < 0x7FFFFFFFull ? mx1 : 0x7FFFFFFFull));
+    atomicMax(&max_s[1], (uint32_t)(mx2 < 0x7FFFFFFFull ? mx2 : 0x7FFFFFFFull));
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (bad_s) atomicOr(&flag[3], 1u);
+    if (bad_s) {
+      atomicOr(&flag[3], 1u);
+      atomicMax(&flag[5], max_s[0]);
+      atomicMax(&flag[6], max_s[1]);
+    }
     __threadfence();
     const uint32_t done = atomicAdd(&flag[4], 1u) + 1u;
     if (done == gridDim.x) {
@@ -628,8 +647,12 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
       const uint64_t ns = nk2 ? ((L1 + 7) & ~7ull) + nk2 : nk1;
       const uint64_t groups = ((L1 + 7) >> 3) + ((L2 + 7) >> 3);
       const bool ok = n && !any_bad && ns <= slot_cap && groups <= (slot_cap > 512u ? 128u : 64u) && L1 < (1ull << 31) && L2 < (1ull << 31);
-      flag[1] = (uint32_t)L1;
-      flag[2] = (uint32_t)L2;
+      // uniform: the one length per mate; else the longest mates (threads that saw only reads of the first read's lengths did not
+      // report: those lengths count as well)
+      const uint32_t f1 = (uint32_t)(L1 < 0x7FFFFFFFull ? L1 : 0x7FFFFFFFull), f2 = (uint32_t)(L2 < 0x7FFFFFFFull ? L2 : 0x7FFFFFFFull);
+      const uint32_t m1 = atomicMax(&flag[5], f1), m2 = atomicMax(&flag[6], f2);
+      flag[1] = any_bad ? (m1 > f1 ? m1 : f1) : f1;
+      flag[2] = any_bad ? (m2 > f2 ? m2 : f2) : f2;
       __threadfence();
       flag[0] = ok ? 1u : 0u;
     }

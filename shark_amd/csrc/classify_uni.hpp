@@ -49,6 +49,11 @@ __device__ __forceinline__ KernargParams kernarg_params()
   return p;
 }
 
+// (the ends of the mates' buffers are read once per wave through the constant address space: scalar loads.  A read's offsets are
+// NOT: scalar loads are counted by lgkmcnt like LDS accesses and return out of order, so every wait for LDS data would also wait for
+// the offsets of the read after next on their way from memory -- measured on the exact-table kernel: 7.4 -> 8.7 ms per 10 M trimmed pairs)
+typedef const uint64_t __attribute__((address_space(4))) *ConstU64;
+
 // ---- the bound cut -----------------------------------------------------------------------------------------------
 // ReadAnalyzer.hpp:104 keeps a read iff max >= c*len, where max is the largest per-gene coverage: the size of the union of
 // the intervals [p, p+k) of that gene's hits (header comment).  A gene's coverage is therefore at most the number of
@@ -172,7 +177,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
   constexpr uint32_t S = 64 * U;
-  constexpr uint32_t WORDS = stage_words_for(S);
+  // per wave: fw + rv + validity, and -- table modes, for the anchored extension -- one more bit stream: base-by-base agreement with the reference
+  constexpr uint32_t WORDS = stage_words_for(S) + (ANCH ? vbit_words_for(S) : 0u);
   __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,6 +191,33 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   }
   L1 = __builtin_amdgcn_readfirstlane(L1);
   L2 = __builtin_amdgcn_readfirstlane(L2);
+  // G: staging groups (8 bases) per lane -- one up to 512 bases per pair, two beyond (U = 10: 2 x 300 bp)
+  constexpr int G = U > 8 ? 2 : 1;
+  // FIXLAY: the ragged instantiation that keeps the exact table in LDS (one-gene indices: instruction-bound, 128 VGPRs to its name).
+  // The others keep the per-read layout: the table modes wait on memory, not on instructions, and holding a lane's layout constants
+  // next to a read's offsets, lengths and plan across the loop took them from 80 to 106-119 VGPRs -- spilled, or at four waves per
+  // SIMD, trimmed reads ran a quarter slower on them (100 / 1 000 / 60 000 genes: 12.9 / 13.9 / 21.1 -> 16.7 / 18.2 / 25.3 ms);
+  // the LDS-summary instantiations (80 VGPRs, three workgroups per CU) spilled as well
+  constexpr bool FIXLAY = !UNI && UG::LX;
+  if (FIXLAY) {
+    // Trimmed reads: (L1, L2) are the LONGEST mates of the batch, and the whole batch is staged in THEIR packed layout -- mate 2 of
+    // every pair at P2 = L1 rounded up to 8, whatever the pair's own mate 1 --, so which bases a lane stages, their LDS addresses and
+    // the mate a slot belongs to are computed once per wave, as for uniform batches; a read brings only its two lengths (the number
+    // of slots per mate, the tail masks of its last groups) and its plan (below).  Results do not depend on where mate 2 is packed:
+    // an interval [p, p + k) never reaches the other mate for any P2 >= the pair's mate 1.  Should the longest pair not fit this
+    // specialisation, the layout is that of the longest mates that do; longer reads go to the general kernel's queue, as ever.
+    const uint32_t k0 = P.k;
+    const uint32_t nkA = L1 >= k0 ? L1 - k0 + 1u : 0u, nkB = L2 >= k0 ? L2 - k0 + 1u : 0u;
+    const uint32_t ns_max = nkB ? ((L1 + 7u) & ~7u) + nkB : nkA;
+    const uint32_t gr_max = ((L1 + 7u) >> 3) + ((L2 + 7u) >> 3);
+    if (ns_max > 64u * U || gr_max > 64u * G) {
+      uint32_t cap = P.seq2 ? (64u * U + k0 - 8u) / 2u : 64u * U + k0 - 1u;
+      const uint32_t capg = P.seq2 ? 256u * G : 512u * G;
+      cap = cap < capg ? cap : capg;
+      L1 = L1 < cap ? L1 : cap;
+      L2 = L2 < cap ? L2 : cap;
+    }
+  }
   if (LSUM) {
     // stage the summary: 16 bytes per thread per pass, once per (persistent) workgroup
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
@@ -197,12 +230,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
   uint32_t *const rv = fw + code_dwords_for(S);
   uint64_t *const vbits = wbase + code_dwords_for(S);
+  uint64_t *const mbits = vbits + vbit_words_for(S);   // (ANCH only) bit p: the read's base at packed position p equals the reference's under the mate's anchor
   constexpr uint32_t rcap = stage_cap_bases(S);
 
   // ---- geometry: of every read of the batch (UNI) or of the current read ----------
   const uint32_t k = P.k;
-  // G: staging groups (8 bases) per lane -- one up to 512 bases per pair, two beyond (U = 10: 2 x 300 bp)
-  constexpr int G = U > 8 ? 2 : 1;
   uint32_t nk1, nk2, P2, g2, n_groups;
   uint32_t tail_inv[G], Lm[G], bofs[G];
   bool act[G], m2[G];
@@ -225,6 +257,17 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
   };
   set_geometry(L1, L2);
+  // (ragged batches) what a read of the batch brings of its own: slots per mate, and which of a lane's bases lie behind its mate's end
+  auto set_read = [&](const uint32_t l1, const uint32_t l2) {
+    nk1 = l1 >= k ? l1 - k + 1 : 0;
+    nk2 = l2 >= k ? l2 - k + 1 : 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      Lm[g] = m2[g] ? l2 : l1;
+      const uint32_t rem = Lm[g] > bofs[g] ? Lm[g] - bofs[g] : 0u;
+      tail_inv[g] = rem < 8u ? (0xFFu << rem) & 0xFFu : 0u;
+    }
+  };
   // the bound cut (above): rounds [0, cutE) are probed first; cutUb = bases the slots of the other rounds cover.  cutE = U: no cut
   // ubJA = the same for the stop of the early decision (JA_ROUNDS rounds; vote<J> below)
   constexpr int JA_ROUNDS = (ACCEPT && CutPlan<U>::E0 + 1 < U) ? CutPlan<U>::E0 + 1 : U;
@@ -303,6 +346,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     sp_inl = P.out->inl;
     if (UNI) plan_sparse(L1, L2);
   }
+  // (ragged, fixed layout) where the mates' buffers end: off[n]
+  uint64_t end1 = 0, end2 = 0;
+  if (FIXLAY) {
+    end1 = ((ConstU64)(uintptr_t)P.off1)[P.n];
+    end2 = P.seq2 ? ((ConstU64)(uintptr_t)P.off2)[P.n] : ~0ull;
+  }
   const uint8_t *sbase[G], *qbase[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -356,9 +405,32 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
     }
   };
+  // (ragged batches) the 8 bases a lane stages of the read at offsets m.o1 / m.o2, by the batch's layout; guarded: only dwords that
+  // hold bytes of the mate are touched
   auto fetch_groups = [&](const ReadMeta &m, Raw8 (&w)[G], Raw8 (&q)[G]) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) fetch_group<HASQ>(P, m, (uint32_t)lane + 64u * g, w[g], q[g]);
+    for (int g = 0; g < G; ++g) {
+      if (!FIXLAY) {   // the read's own layout (table modes)
+        fetch_group<HASQ>(P, m, (uint32_t)lane + 64u * g, w[g], q[g]);
+        continue;
+      }
+      w[g] = Raw8{0u, 0u, 0u, 0u};
+      q[g] = Raw8{0u, 0u, 0u, 0u};
+      const uint32_t Lr = m2[g] ? m.L2 : m.L1;
+      const uint64_t o = m2[g] ? m.o2 : m.o1;
+      // (wave-uniform) every group of the layout, and the 11 bytes behind its first, lie inside the mates' buffers: three unconditional
+      // aligned dwords per group, as for uniform batches (bytes behind the read's own end are its neighbour's, masked by tail_inv);
+      // only the last reads of the batch take the guarded loads
+      if (m.o1 + L1 + 16u <= end1 && m.o2 + L2 + 16u <= end2) {
+        if (act[g]) {
+          w[g] = load8_issue_all(sbase[g] + o, 8u);
+          if (HASQ) q[g] = load8_issue_all(qbase[g] + o, 8u);
+        }
+      } else if (act[g] && bofs[g] < Lr) {
+        w[g] = load8_issue(sbase[g] + o, Lr - bofs[g]);
+        if (HASQ) q[g] = load8_issue(qbase[g] + o, Lr - bofs[g]);
+      }
+    }
   };
   auto retire = [&](Raw8 (&w)[G], Raw8 (&q)[G]) {
 #pragma unroll
@@ -376,11 +448,23 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   if (read >= n32) return;
   Raw8 w_cur[G], q_cur[G];
   ReadMeta m_cur{}, m_nxt{};
+  // (ragged batches) a read's plan -- which rounds first, the bounds behind them, the sparse order -- depends on its two lengths alone.
+  // Computing it per read is about 150 scalar instructions, and the CU's one scalar unit serves all its waves (measured: 7.9 ms per
+  // 10 M trimmed pairs against 4.2 ms untrimmed, nearly all of it scalar); so the launch carries a table indexed by (l1, l2), cleared
+  // by the host: the first wave to meet a pair of lengths computes the plan and leaves it there, everybody else loads 16 bytes --
+  // one read ahead, with the bases.  A stale or missing entry only means computing the (same) plan again.
+  constexpr uint32_t PLAN_VALID = 0x504C414Eu;
+  // (with the fixed layout only: elsewhere the eight registers of two plans in flight made the quality-mask instantiations spill)
+  const bool has_plans = FIXLAY && P.plan_tab != nullptr && (uint64_t)(L1 + 1u) * (L2 + 1u) <= (uint64_t)P.plan_cap;
+  auto plan_index = [&](const ReadMeta &m) -> uint32_t { return (m.L1 <= L1 && m.L2 <= L2) ? m.L1 * (L2 + 1u) + m.L2 : 0u; };
+  auto plan_issue = [&](const ReadMeta &m) -> uint4 { return has_plans ? P.plan_tab[plan_index(m)] : make_uint4(0u, 0u, 0u, 0u); };
+  uint4 pl_cur = make_uint4(0u, 0u, 0u, 0u);
   if (UNI) {
     issue(read, w_cur, q_cur);
   } else {
     m_cur = fetch_meta(P, read);
     fetch_groups(m_cur, w_cur, q_cur);
+    pl_cur = plan_issue(m_cur);
     const uint32_t n1 = n32 - read > stride ? read + stride : n32;
     m_nxt = fetch_meta(P, n1 < n32 ? n1 : read);
   }
@@ -394,18 +478,20 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     for (int g = 0; g < G; ++g) { w_nxt[g] = Raw8{0u, 0u, 0u, 0u}; q_nxt[g] = Raw8{0u, 0u, 0u, 0u}; }
     ReadMetaRaw r_nn{};
     uint32_t nn = n32;
+    uint4 pl_nxt = make_uint4(0u, 0u, 0u, 0u);
     if (UNI) {
       if (have_nxt) issue(nxt, w_nxt, q_nxt);
     } else {
-      if (have_nxt) fetch_groups(m_nxt, w_nxt, q_nxt);
+      if (have_nxt) { fetch_groups(m_nxt, w_nxt, q_nxt); pl_nxt = plan_issue(m_nxt); }
       nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
       r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
-      set_geometry(m_cur.L1, m_cur.L2);
+      if (FIXLAY) set_read(m_cur.L1, m_cur.L2); else set_geometry(m_cur.L1, m_cur.L2);
     }
     bool skip = false;
     if (!UNI) {
-      const uint32_t ns = nk2 ? P2 + nk2 : nk1;
-      if (ns > S || n_groups > 64u * G) {   // does not fit this specialisation: the general kernel's queue (as process_read does)
+      const uint32_t ns = nk2 ? ((m_cur.L1 + 7u) & ~7u) + nk2 : nk1;
+      // longer than the batch's layout (FIXLAY) / this specialisation holds: the general kernel's queue (as process_read does)
+      if (FIXLAY ? (m_cur.L1 > L1 || m_cur.L2 > L2) : (ns > S || n_groups > 64u * G)) {
         if (lane == 0) {
           const ClassifyOut *O = out_ptrs(P);
           const uint32_t qi = atomicAdd(&O->counters[CTR_LONG], 1u);
@@ -452,11 +538,29 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
-    if (!UNI) { plan_cut(m_cur.L1, m_cur.L2); if (SPARSE) plan_sparse(m_cur.L1, m_cur.L2); }
+    if (!UNI) {
+      const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.w);
+      if (pw == PLAN_VALID) {
+        const uint32_t px = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.x), py = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.y),
+                       pz = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.z);
+        cutE = px & 0xFFu; spT = (px >> 8) & 0xFFu; cutUb = px >> 16;
+        ubJA = py & 0xFFFFu; thr_full = py >> 16;
+        spLast = pz & 0xFFFFu; spUb = pz >> 16;
+      } else {
+        plan_cut(m_cur.L1, m_cur.L2);
+        if (SPARSE) plan_sparse(m_cur.L1, m_cur.L2);
+        // (every field fits: lengths below 2^15 are all the table is offered, see the host side)
+        if (has_plans && lane == 0)
+          P.plan_tab[plan_index(m_cur)] = make_uint4(cutE | (spT << 8) | (cutUb << 16), ubJA | (thr_full << 16), spLast | (spUb << 16), PLAN_VALID);
+      }
+    }
     uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
+    // a read without any invalid character (N, masked quality) -- most reads -- needs no validity window per slot: every existing
+    // slot is a valid k-mer (table modes test validity before a probe; uniform branch around eight instructions per slot and round)
+    const bool any_inv = __ballot(inv_real != 0u) != 0ull;
     if (cutE < (uint32_t)U || JA_ROUNDS < U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
-      if (__ballot(inv_real != 0u)) {
+      if (any_inv) {
         const uint32_t len = wave_sum_u32(lane_valid_bases());
         thr_r = cov_threshold(P.c, len);
       }
@@ -510,6 +614,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     const uint64_t kmask0 = (1ull << k) - 1ull;
     auto slot_valid = [&](const uint32_t pp) -> bool {
       const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+      if (!any_inv) return exists;
       const uint32_t V = pp >> 6, vs = pp & 63u;
       const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
       const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
@@ -537,12 +642,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         bool ok[U];
 #pragma unroll
         for (int j = JLO; j < JHI; ++j) {
-          const uint32_t pp = (uint32_t)lane + 64u * j;
-          const bool exists = (pp < nk1) | ((pp - P2) < nk2);
-          const uint32_t V = pp >> 6, vs = pp & 63u;
-          const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
-          const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
-          ok[j] = exists & ((win & kmask0) == kmask0);
+          ok[j] = slot_valid((uint32_t)lane + 64u * j);
           if (ANCH) ok[j] = ok[j] & (((known >> j) & 1u) == 0u);
         }
         if (SUM) {
@@ -1037,11 +1137,21 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #if SHK_ANCH_CUT == 2
       return ax[0] + ax[1] != 12345u;
 #endif
-      // (3)
-      uint32_t known = 0u, n_match = 0u, ub = 0u;
-      uint64_t Uprev = 0ull;
+      // (3) base by base.  An anchor maps a mate onto the reference linearly: the base at packed position b stands against
+      // reference base x0 - s0 + b (same strand), or against the complement of reference base x0 + s0 + k - 1 - b (other strand).
+      // Lane (m, c) = (lane >> 5, lane & 31) compares the 16 bases of chunk c of mate m in ONE xor of two dwords -- the read's
+      // 2-bit codes (fw stream) against the reference's (ref2, same layout; reversed and complemented for the other strand) -- and
+      // leaves one bit per base in `mbits`.  A slot's k-mer equals the reference k-mer at its implied position iff its k bits are
+      // all set: the same window test the validity stream gets (round 3 compared two 2k-bit windows per slot and round: six LDS
+      // reads, three reference dwords and four funnel shifts per slot instead of one 64-bit window).  Equal k-mers have equal filter
+      // positions, hence equal table slots: such a slot is settled with EXACTLY what a probe would have returned (refpay).
+      // (32 lanes per mate, 16 bases each: mates of more than 512 bases take the usual path)
+      if (nk1 + k > 513u || nk2 + k > 513u) return false;
       const uint32_t *refpay = H->refpay;
-      const uint32_t *ref2 = H->ref2;
+      // what a probe of the reference k-mer at each slot's implied position returns: requested FIRST, for every slot whose position
+      // lies in the reference (64 slots of a round read 256 contiguous bytes), so that these loads and the reference bases below
+      // are one memory round trip, not two
+      uint32_t inb_mask = 0u, okv_mask = 0u;
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const uint32_t pp = (uint32_t)lane + 64u * j;
@@ -1051,28 +1161,71 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const bool opp = in2 ? aopp[1] : aopp[0];
         const uint32_t x0 = in2 ? ax[1] : ax[0];
         const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
-        const uint32_t xr = opp ? x0 - dd : x0 + dd;
+        const uint32_t xr = opp ? x0 - dd : x0 + dd;               // where the slot's k-mer starts in the reference
         const bool inb = okv & have & (xr < ref_total);
-        const uint32_t xs = inb ? xr : 0u;
-        const uint32_t rp = refpay[xs];
-        const uint32_t *rw = ref2 + (xs >> 4);
-        const uint32_t g0 = rw[0], g1 = rw[1], g2 = rw[2];
-        uint64_t x, y;
-        windows(j, x, y);
-        const uint32_t sg = (xs & 15u) << 1;
-        const uint64_t W = ((uint64_t)__builtin_amdgcn_alignbit(g2, g1, sg) << 32) | __builtin_amdgcn_alignbit(g1, g0, sg);
-        const bool eq = opp ? ((y & kmer_mask) == (~W & kmer_mask)) : ((x & kmer_mask) == (W & kmer_mask));
-        const bool mm = inb & (rp != REFPAY_NONE) & eq;
+        slo[j] = refpay[inb ? xr : 0u];
+        inb_mask |= inb ? (1u << j) : 0u;
+        okv_mask |= okv ? (1u << j) : 0u;
+      }
+      {
+        const uint32_t *ref2 = H->ref2;
+        const uint32_t m = (uint32_t)lane >> 5, c16 = ((uint32_t)lane & 31u) << 4;
+        const uint32_t len_m = m ? (nk2 ? nk2 + k - 1u : 0u) : (nk1 ? nk1 + k - 1u : 0u);
+        const uint32_t b0 = (m ? P2 : 0u) + c16;                       // packed position of the chunk's first base
+        const uint32_t n_in = c16 < len_m ? (len_m - c16 < 16u ? len_m - c16 : 16u) : 0u;
+        const bool hv = m ? ahave[1] : ahave[0], op = m ? aopp[1] : aopp[0];
+        const uint32_t x0 = m ? ax[1] : ax[0], s0 = m ? as0[1] : as0[0];
+        // the 16 reference bases the chunk stands against, first one at `lo` (mod 2^32: a chunk that would leave the reference
+        // fails the bound and matches nothing -- its slots stay open)
+        const uint32_t lo = op ? x0 + s0 + k - 16u - b0 : x0 + b0 - s0;
+        const bool inr = hv & (n_in != 0u) & (lo < ref_total);
+        const uint32_t ls = inr ? lo : 0u, bs = n_in ? b0 : 0u;
+        const uint32_t g0 = ref2[ls >> 4], g1 = ref2[(ls >> 4) + 1u];
+        const uint32_t r0 = fw[bs >> 4], r1 = fw[(bs >> 4) + 1u];
+        uint32_t G = __builtin_amdgcn_alignbit(g1, g0, (ls & 15u) << 1);
+        if (op) {   // the other strand: base order reversed (2-bit groups), complemented
+          G = __builtin_bitreverse32(G);
+          G = ~(((G >> 1) & 0x55555555u) | ((G & 0x55555555u) << 1));
+        }
+        const uint32_t R = __builtin_amdgcn_alignbit(r1, r0, (bs & 15u) << 1);
+        const uint32_t df = R ^ G;
+        uint32_t e = ~(df | (df >> 1)) & 0x55555555u;                 // bit 2 i: base i agrees
+        e = (e | (e >> 1)) & 0x33333333u;
+        e = (e | (e >> 2)) & 0x0F0F0F0Fu;
+        e = (e | (e >> 4)) & 0x00FF00FFu;
+        e = (e | (e >> 8)) & 0xFFFFu;
+        const uint32_t M16 = inr ? (e & ((1u << n_in) - 1u)) : 0u;
+        // bytes 2 c and 2 c + 1 of the mate's part of the stream (mate 2 starts at byte P2 / 8; mate 1's last chunk may reach past it:
+        // those bytes are mate 2's).  Bytes behind the mate are cleared as far as the stream goes: no stale bit of an earlier read
+        constexpr uint32_t MBYTES = vbit_words_for(S) * 8u;
+        uint8_t *mb = reinterpret_cast<uint8_t *>(mbits);
+        const uint32_t by = b0 >> 3, end = m ? MBYTES : (P2 >> 3);
+        if (by < end) mb[by] = (uint8_t)M16;
+        if (by + 1u < end) mb[by + 1u] = (uint8_t)(M16 >> 8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint32_t known = 0u, n_match = 0u, n_open = 0u, n_runs = 0u;
+      uint64_t carry = 0ull;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const bool okv = ((okv_mask >> j) & 1u) != 0u;
+        const uint64_t m0 = mbits[j], m1 = mbits[j + 1];           // (slot pp = lane + 64 j: word j, bit `lane`)
+        const uint64_t mwin = (m0 >> (uint32_t)lane) | ((m1 << 1) << (63u - (uint32_t)lane));
+        const bool mm = (((inb_mask >> j) & 1u) != 0u) & ((mwin & kmask0) == kmask0) & (slo[j] != REFPAY_NONE);
         mt[j] = mm;
-        slo[j] = rp;
         known |= (mm | !okv) ? (1u << j) : 0u;                      // (a slot that does not exist or is no valid k-mer needs no probe either)
         lane_any |= mm;
         n_match += (uint32_t)__builtin_popcountll(__ballot(mm));
-        const uint64_t Uc = __ballot(okv & !mm);                    // open slots
-        ub += cover(Uc, Uprev);
-        Uprev = Uc;
+        // what the open slots can still cover, as an upper bound from their runs (scalar): r consecutive slots cover r + k - 1
+        // bases; runs less than k - 1 slots apart overlap, which the bound ignores (it is exact for the usual read: a run per error)
+        const uint64_t Uc = __ballot(okv & !mm);
+        n_open += (uint32_t)__builtin_popcountll(Uc);
+        n_runs += (uint32_t)__builtin_popcountll(Uc & ~((Uc << 1) | carry));
+        carry = Uc >> 63;
       }
-      ub += cover(0ull, Uprev);
+      const uint32_t ub = n_open + (k - 1u) * n_runs;
       if (n_match < 4u) { lane_any = false; return false; }
 #if SHK_ANCH_CUT == 3
       return n_match != 12345u;
@@ -1300,6 +1453,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       retire_meta(r_nn);
       m_cur = m_nxt;
       m_nxt = meta_finish(r_nn);
+      pl_cur = pl_nxt;
     }
     read = nxt;
 #pragma unroll

@@ -108,7 +108,7 @@ static void slot_free(Slot &s)
 {
   hipFree(s.d_seq1); hipFree(s.d_seq2); hipFree(s.d_qual1); hipFree(s.d_qual2); hipFree(s.d_off1); hipFree(s.d_off2);
   hipFree(s.d_count); hipFree(s.d_inl); hipFree(s.d_gene_off); hipFree(s.d_gene_ids);
-  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_uni_flag);
+  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_uni_flag); hipFree(s.d_plan);
   if (s.h_counters) (void)hipHostFree(s.h_counters);
   if (s.h_gene_off) (void)hipHostFree(s.h_gene_off);
   if (s.h_gene_ids) (void)hipHostFree(s.h_gene_ids);
@@ -287,9 +287,21 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     if (uni_mode == UNI_ASK_DEVICE) {
       if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
       s.p.uni_flag = s.d_uni_flag;
-    } else if (uni_mode == UNI_YES) {
+    } else {
+      // the one length per mate (UNI_YES), or the longest mates: the ragged instantiation stages the batch in their layout
       s.p.uni_L1 = uni_L1;
       s.p.uni_L2 = uni_L2;
+    }
+    if (uni_mode != UNI_YES) {
+      // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
+      // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
+      const uint64_t entries = uni_L1 ? ((uint64_t)uni_L1 + 1) * ((uint64_t)(b->seq2 ? uni_L2 : 0) + 1) : 0;
+      if (entries && entries <= (1ull << 20)) {
+        if ((rc = ensure_capacity(ctx, &s.d_plan, &s.cap_plan, (size_t)entries))) return rc;
+        SHK_HIP(ctx, hipMemsetAsync(s.d_plan, 0, entries * sizeof(uint4), st));
+        s.p.plan_tab = s.d_plan;
+        s.p.plan_cap = (uint32_t)entries;
+      }
     }
   }
 
@@ -386,7 +398,10 @@ static int classify_resident(Ctx *ctx, const shk_batch *b, uint32_t max_read_len
   const int long_mode = (max_read_len && max_slots <= fast_kernel_max_slots()) ? LONG_NONE_EXPECTED : LONG_UNKNOWN;
   int rc;
   const uint64_t hint_groups = (((uint64_t)max_read_len + 7) >> 3) * (paired ? 2 : 1);   // (no bound given: the table kernel queues what it cannot stage)
-  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr, UNI_ASK_DEVICE, 0, 0, hint_groups <= uni_kernel_max_groups(max_slots)))) return rc;
+  // (UNI_ASK_DEVICE: the lengths passed here only size the plan table of a batch that turns out ragged: the caller's bound per mate)
+  if ((rc = enqueue_classify(ctx, s, b, max_slots, long_mode, 0, 0, wc == nullptr, UNI_ASK_DEVICE, max_read_len, paired ? max_read_len : 0,
+                             hint_groups <= uni_kernel_max_groups(max_slots))))
+    return rc;
   SHK_HIP(ctx, hipStreamSynchronize(st));
   bool redone = false;
   if ((rc = finish_classify(ctx, s, long_mode == LONG_NONE_EXPECTED, wc == nullptr, &redone))) return rc;

@@ -142,10 +142,16 @@ struct ClassifyParams {
   const uint32_t *refpay;
   const uint32_t *anchor;
   uint32_t ref_total;
-  // batches whose reads all have one length per mate (the usual sequencer output) take classify_uni_kernel:
-  // uni_flag == nullptr: the host knows (uni_L1, uni_L2); else {1 = uniform and fits, L1, L2} written by uniform_check_kernel
+  // batches whose reads all have one length per mate (the usual sequencer output) take classify_uni_kernel's UNI instantiation,
+  // the others its ragged one, which stages every read in the layout of the batch's LONGEST mates:
+  // uni_flag == nullptr: the host knows (uni_L1, uni_L2) = the one length per mate, or the longest; else {1 = uniform and fits,
+  // L1, L2 (the same)} written by uniform_check_kernel
   uint32_t uni_L1, uni_L2;
   const uint32_t *uni_flag;
+  // ragged batches (the lengths above are then the LONGEST mates): per-launch table of read plans indexed by (l1, l2), 16 bytes each,
+  // cleared by the host and filled by the kernel itself (classify_uni.hpp); nullptr / 0 = every read computes its plan
+  uint4 *plan_tab;
+  uint32_t plan_cap;               // entries
   // per-read results and queues (device copy of ClassifyOut)
   const ClassifyOut *out;
   unsigned long long *gene_counts;  // 65536 (general kernel, EMIT mode)
@@ -197,6 +203,7 @@ struct Slot {
   uint32_t *d_tie_queue = nullptr;  size_t cap_tie_queue = 0;
   uint32_t *d_counters = nullptr;
   uint32_t *d_uni_flag = nullptr;  // 8 words: verdict of uniform_check_kernel
+  uint4 *d_plan = nullptr; size_t cap_plan = 0;   // read plans of a ragged batch (ClassifyParams::plan_tab)
   uint64_t *d_scan_temp = nullptr; size_t cap_scan_temp = 0;
   ClassifyOut *d_out = nullptr;
   ClassifyOut out_shadow{};        // what *d_out holds (rewritten only when a buffer moved)
