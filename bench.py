@@ -486,6 +486,10 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
         for ot in ([0.02] if n_gpus > 1 else [0.02, 0.50]):
             t0 = time.time()
             n_big = sizes[-1]
+            # the compressed leg (ordinary gzip -1 files, one member each: inflated in parallel in two passes, gzip_parallel.hpp) on the
+            # first gz_n pairs of the 0.02 sample
+            gz_n = min(args.cli_gz_pairs, small) if (ot == 0.02 and n_gpus == 1 and shutil.which("gzip")) else 0
+            gz_md5, gz_lines, gz_assoc_reads = None, 0, 0
             log("  cli: generating %d pairs at on-target %.2f" % (n_big, ot))
             md5 = hashlib.md5()
             md5_at, lines_at, assoc_reads_at = {}, {}, {}
@@ -505,6 +509,9 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                 cnt = np.diff(goff.astype(np.int64))
                 lines += int(r.n_assoc)
                 assoc_reads += int((cnt > 0).sum())
+                if c0 == 0 and gz_n:    # (the compressed leg classifies the first gz_n pairs of this sample)
+                    gz_lines = int(goff[gz_n])
+                    gz_assoc_reads = int((cnt[:gz_n] > 0).sum())
                 if same_len_names:      # "r<9 digits>/1 gene<d>\n" per association, reads in input order, genes ascending (ReadOutput.hpp:43)
                     ridx = np.repeat(np.arange(c0, c0 + m_all, dtype=np.int64), cnt)
                     txt = np.empty((len(ridx), 1 + nd + 2 + 1 + 4 + 1 + 1), np.uint8)
@@ -516,6 +523,8 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                     txt[:, 8 + nd] = ord("0") + gids
                     txt[:, 9 + nd] = 10
                     md5.update(txt.tobytes())
+                    if c0 == 0 and gz_n:
+                        gz_md5 = hashlib.md5(txt[:int(goff[gz_n])].tobytes()).hexdigest()
                 idx = torch.arange(c0, c0 + m_all, device=dev, dtype=torch.int64)
                 for mate, key, fh in ((1, "seq1", f1), (2, "seq2", f2)):
                     for s0 in range(0, m_all, 2_000_000):            # "@r<9 digits>/<mate>\n" + bases + "\n+\n" + qualities + "\n", 2 M records at a time
@@ -593,12 +602,52 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                     if busy is not None:
                         run["gpu_busy_s"] = busy          # per GPU: seconds its analyzer thread spent in shk_classify_submit / _wait
                     out["runs"].append(run)
+            if gz_n:
+                log("  cli: gzip -1 of the first %d pairs" % gz_n)
+                t0 = time.time()
+                ps = []
+                for mate in (1, 2):
+                    with open(os.path.join(td, "r%d.fq" % mate), "rb") as fi, open(os.path.join(td, "g%d.fq.gz" % mate), "wb") as fo:
+                        hd = subprocess.Popen(["head", "-c", str(gz_n * W)], stdin=fi, stdout=subprocess.PIPE)
+                        ps.append((hd, subprocess.Popen(["gzip", "-1"], stdin=hd.stdout, stdout=fo)))
+                        hd.stdout.close()
+                ok_gz = all(g.wait() == 0 for _, g in ps)
+                gz_s = time.time() - t0
+                gz_bytes = sum(os.path.getsize(os.path.join(td, "g%d.fq.gz" % mate)) for mate in (1, 2))
+                for mate in (1, 2):
+                    subprocess.run(["cat", os.path.join(td, "g%d.fq.gz" % mate)], stdout=subprocess.DEVNULL)
+                threads = 16
+                for fn in ("o1.fq", "o2.fq", "out.ssv"):
+                    try:
+                        os.unlink(os.path.join(td, fn))
+                    except OSError:
+                        pass
+                cmd = [exe, "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "g1.fq.gz"), "-2", os.path.join(td, "g2.fq.gz"),
+                       "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-k", str(args.k), "-v", "-t", str(threads)]
+                log("  cli: running on the compressed files")
+                t0 = time.time()
+                with open(os.path.join(td, "out.ssv"), "wb") as so:
+                    pr = subprocess.run(cmd, stdout=so, stderr=subprocess.PIPE)
+                dt = time.time() - t0
+                got = open(os.path.join(td, "out.ssv"), "rb").read()
+                fq_bytes = sum(os.path.getsize(os.path.join(td, fn)) if os.path.exists(os.path.join(td, fn)) else 0 for fn in ("o1.fq", "o2.fq"))
+                ok_md5 = (hashlib.md5(got).hexdigest() == gz_md5) if same_len_names else None
+                out["gzip_input"] = {"what": "the same command on `gzip -1` files (one gzip member per file) of the first %d pairs of the 0.02 sample, -t %d" % (gz_n, threads),
+                                     "pairs": gz_n, "threads": threads, "compressed_bytes": gz_bytes, "text_bytes": 2 * gz_n * W, "gzip_s": round(gz_s, 1),
+                                     "wall_s": round(dt, 3), "value": round(2 * gz_n / dt, 1), "unit": "reads/s", "rc": pr.returncode,
+                                     "ssv_lines": got.count(b"\n"), "expected_ssv_lines": gz_lines, "ssv_md5_equals_device_result": ok_md5,
+                                     "valid": bool(ok_gz and pr.returncode == 0 and got.count(b"\n") == gz_lines and ok_md5 is not False
+                                                   and fq_bytes == 2 * gz_assoc_reads * W)}
+                for fn in ("g1.fq.gz", "g2.fq.gz"):
+                    os.unlink(os.path.join(td, fn))
             for fn in ("r1.fq", "r2.fq", "o1.fq", "o2.fq", "out.ssv"):
                 try:
                     os.unlink(os.path.join(td, fn))
                 except OSError:
                     pass
         valid = [x for x in out["runs"] if x["valid"]]
+        if "gzip_input" in out and not out["gzip_input"]["valid"]:
+            valid = []          # (an invalid compressed run invalidates the leg like any other)
         out["all_runs_valid"] = len(valid) == len(out["runs"]) and bool(valid)
         # two sample sizes: the slope is the steady state, the intercept the fixed cost
         by = {}
@@ -649,6 +698,7 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the shark command line")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (committed counters are used when they match)")
     ap.add_argument("--cli-pairs", type=int, default=16_000_000)
+    ap.add_argument("--cli-gz-pairs", type=int, default=8_000_000, help="pairs of the CLI leg's run on gzip-compressed files (0 = none)")
     ap.add_argument("--cli-big-pairs", type=int, default=64_000_000, help="the larger of the CLI leg's two samples (cut to what /dev/shm may hold)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = threads x 50 000 (one reference chunk per thread)")
     ap.add_argument("--counter-child", default="", help=argparse.SUPPRESS)

@@ -154,7 +154,8 @@ inline int parse_record(const char *p, size_t avail, RecordFields &f)
 // One mate file's share of a batch, as the output stage needs it to fetch a record again
 struct BatchFilePart {
   int fd = -1;
-  uint64_t off0 = 0, off1 = 0;            // byte range of the batch in the file
+  const char *mem = nullptr;              // != nullptr: the batch's text is in memory (compressed samples: inflated text), not in a file
+  uint64_t off0 = 0, off1 = 0;            // byte range of the batch in the file (in memory: [0, length))
   uint32_t fixed_width = 0;               // != 0: every record of this batch has this many bytes (record r starts at off0 + r * width)
   std::vector<uint64_t> rec_off;          // else: start of record r relative to off0, n + 1 entries
   uint64_t start_of(size_t r) const { return fixed_width ? (uint64_t)r * fixed_width : rec_off[r]; }
@@ -241,6 +242,53 @@ inline size_t lean_parse_range(int fd, uint64_t off0, uint64_t off1, size_t want
   return r;
 }
 
+// The same over text that is already in memory (a compressed sample's inflated text, cut at record boundaries by the caller):
+// [text, text + len) must hold exactly `want` strict records.  The text has to stay alive while the batch is in flight: the
+// output stage reads names and qualities from it (part.mem).
+template <typename Bytes, typename Offs>
+inline size_t lean_parse_mem(const char *text, size_t len, size_t want, const RecordLayout &hint, bool with_qual, Bytes &seq, Offs &seq_off, Bytes &qual,
+                             BatchFilePart &part)
+{
+  part.fd = -1; part.mem = text; part.off0 = 0; part.off1 = len; part.fixed_width = 0; part.rec_off.clear();
+  seq_off.resize(want + 1);
+  seq.resize(len / 2 + 64);
+  if (with_qual) qual.resize(seq.size());
+  const uint32_t hw = hint.usable() ? hint.width() : 0;
+  bool all_hint = hw != 0;
+  size_t at = 0, r = 0;
+  uint64_t so = 0;
+  while (r < want) {
+    const size_t avail = len - at;
+    RecordFields f;
+    if (hw && avail >= hw && record_has_layout(text + at, hint)) {
+      f.seq_off = hint.l0; f.seq_len = hint.l1 - 1; f.qual_off = hint.l0 + hint.l1 + hint.l2; f.rec_len = hw;
+    } else {
+      if (parse_record(text + at, avail, f) != 1) break;     // irregular, or the text ends inside the record
+      if (all_hint) {
+        part.rec_off.resize(r);
+        for (size_t i = 0; i < r; ++i) part.rec_off[i] = (uint64_t)i * hw;
+        all_hint = false;
+      }
+    }
+    if (!all_hint) part.rec_off.push_back(at);
+    if (so + f.seq_len > seq.size()) { seq.resize((size_t)((so + f.seq_len) * 2 + 64)); if (with_qual) qual.resize(seq.size()); }
+    memcpy(seq.data() + so, text + at + f.seq_off, f.seq_len);
+    if (with_qual) memcpy(qual.data() + so, text + at + f.qual_off, f.seq_len);
+    seq_off[r] = so;
+    so += f.seq_len;
+    at += f.rec_len;
+    ++r;
+  }
+  seq_off[r] = so;
+  if (r == want && at != len) r = 0;          // surplus bytes behind the last record: not this batch's text
+  if (r == want) {
+    seq.resize((size_t)so);
+    if (with_qual) qual.resize((size_t)so);
+    if (all_hint) part.fixed_width = hw; else part.rec_off.push_back(len);
+  }
+  return r;
+}
+
 // The output stage's way back to a record's name, sequence and quality (ReadOutput.hpp:43-47 prints them for associated reads).
 // sparse(): one pread per record; dense(): the whole range of a run of records at once (chosen by the caller when many of them
 // are needed).  Pointers stay valid until the next call.
@@ -250,6 +298,7 @@ class RecordFetcher {
   // records [r0, r1) of `part` in one read
   bool load_dense(const BatchFilePart &part, size_t r0, size_t r1)
   {
+    if (part.mem) { dense_ = false; return true; }      // (text in memory: every record is there already)
     base_ = part.start_of(r0);
     const uint64_t end = part.start_of(r1);
     buf_.resize((size_t)(end - base_));
@@ -261,7 +310,9 @@ class RecordFetcher {
   {
     const uint64_t a = part.start_of(r), e = part.start_of(r + 1);
     const char *p;
-    if (dense_) {
+    if (part.mem) {
+      p = part.mem + a;
+    } else if (dense_) {
       p = buf_.data() + (a - base_);
     } else {
       one_.resize((size_t)(e - a));

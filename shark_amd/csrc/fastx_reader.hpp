@@ -20,10 +20,13 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "gzip_parallel.hpp"
 
 namespace shk {
 
@@ -32,8 +35,10 @@ namespace shk {
 // (main.cpp:88,:129,:202); here decompression runs AHEAD of the parser on its own thread(s):
 //   * BGZF (bgzip's blocked gzip, the usual form of compressed FASTQ): every block is an independent deflate stream
 //     of known compressed size (BSIZE in the 'BC' extra field), so the blocks of a chunk are inflated in parallel;
-//   * any other gzip stream, or a plain file: gzread on a read-ahead thread, double buffered, so that inflating
-//     overlaps parsing.
+//   * an ordinary gzip file of text (one member or many, any writer): cut into chunks that are inflated in parallel, two passes
+//     (gzip_parallel.hpp); SHARK_GZ_SERIAL=1 in the environment turns that off;
+//   * anything else (small files, a plain file, gzip of something that is not text): gzread on a read-ahead thread, double
+//     buffered, so that inflating overlaps parsing.
 // seek() (uncompressed offsets; used when the block reader hands a plain file over) restarts the read-ahead.
 // ---------------------------------------------------------------------------
 class InflateAhead {
@@ -65,6 +70,7 @@ class InflateAhead {
   // the next chunk of uncompressed bytes (valid until the next call); false at the end of the stream
   bool next(const char *&data, size_t &len)
   {
+    if (pg_) return pg_->next(data, len);
     std::unique_lock<std::mutex> l(m_);
     if (have_) {   // give the chunk handed out last time back to the producer
       have_ = false;
@@ -88,6 +94,13 @@ class InflateAhead {
     done_ = false; quit_ = false; have_ = false; cons_ = 0;
     fallback_gz_ = false;   // (a restart reads the file from `off` again: whatever made the last pass fall back is met again)
     full_[0] = full_[1] = false;
+    pg_.reset();
+    if (!bgzf_ && off == 0 && !getenv("SHARK_GZ_SERIAL")) {
+      // ordinary gzip: the parallel two-pass inflate when the file qualifies (a gzip member of text, more than a few chunks)
+      pg_.reset(new ParallelGunzip(path_, bgzf_threads_));
+      if (pg_->usable()) return true;
+      pg_.reset();
+    }
     if (bgzf_ && off == 0) {
       raw_ = fopen(path_.c_str(), "rb");
       if (!raw_) return false;
@@ -117,6 +130,7 @@ class InflateAhead {
       cv_.notify_all();
     }
     if (th_.joinable()) th_.join();
+    pg_.reset();
     if (gz_) { gzclose(gz_); gz_ = nullptr; }
     if (raw_) { fclose(raw_); raw_ = nullptr; }
   }
@@ -232,6 +246,7 @@ class InflateAhead {
 
   std::string path_;
   unsigned bgzf_threads_;
+  std::unique_ptr<ParallelGunzip> pg_;   // ordinary gzip, inflated in parallel (then none of the members below is in use)
   bool bgzf_ = false, ok_ = false, fallback_gz_ = false;
   gzFile gz_ = nullptr;
   FILE *raw_ = nullptr;

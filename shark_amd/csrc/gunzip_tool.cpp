@@ -1,0 +1,29 @@
+// gunzip_tool.cpp -- shark-gunzip: the CLI's parallel gzip reader on its own (tests, timing).
+//   shark-gunzip FILE.gz [threads]   -> the uncompressed bytes on stdout ("-n": only count them)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+
+#include "gzip_parallel.hpp"
+
+int main(int argc, char **argv)
+{
+  bool count_only = false;
+  int a = 1;
+  if (a < argc && !strcmp(argv[a], "-n")) { count_only = true; ++a; }
+  if (a >= argc) { fprintf(stderr, "usage: shark-gunzip [-n] FILE.gz [threads]\n"); return 2; }
+  const unsigned threads = a + 1 < argc ? (unsigned)atoi(argv[a + 1]) : 8u;
+  const auto t0 = std::chrono::steady_clock::now();
+  shk::ParallelGunzip z(argv[a], threads);
+  if (!z.usable()) { fprintf(stderr, "shark-gunzip: not usable on this file (too small, not gzip, or not text): the CLI falls back to gzread\n"); return 3; }
+  const char *d;
+  size_t n, total = 0;
+  while (z.next(d, n)) {
+    total += n;
+    if (!count_only && fwrite(d, 1, n, stdout) != n) return 1;
+  }
+  const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "shark-gunzip: %zu bytes in %.3f s (%.1f MB/s), %u threads\n", total, s, total / s / 1e6, threads);
+  return 0;
+}

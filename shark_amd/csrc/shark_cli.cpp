@@ -278,6 +278,9 @@ struct ReadBatch {
   // associated reads are fetched from the files again by the output stage
   bool lean = false;
   shk::BatchFilePart part1, part2;
+  // compressed samples: the inflated text of this batch's records, per mate (part1.mem / part2.mem point into them); the buffers are
+  // handed round between the cutters and the batches, never freed
+  std::vector<char, default_init_allocator<char>> text1, text2;
   std::shared_ptr<const struct FormattedBatch> text;   // what the output stage will write for this batch (filled by a formatter thread)
   // result
   std::vector<uint32_t> gene_off;
@@ -367,9 +370,11 @@ class BatchPool {
 // (gzip, multi-line records, CR/LF, ...) through the serial kseq-rule reader.
 class BatchSplitter {
  public:
-  BatchSplitter(const Options &o, unsigned threads, BatchPool &pool) : r1_(o.sample1_path), pool_(pool), paired_(o.paired_flag), maxnum_(o.batch), threads_(threads)
+  // (compressed samples: the host threads are shared between the mate files' inflaters)
+  BatchSplitter(const Options &o, unsigned threads, BatchPool &pool)
+      : r1_(o.sample1_path, std::max(2u, threads / (o.paired_flag ? 2u : 1u))), pool_(pool), paired_(o.paired_flag), maxnum_(o.batch), threads_(threads)
   {
-    if (paired_) r2_.reset(new shk::FastxReader(o.sample2_path));
+    if (paired_) r2_.reset(new shk::FastxReader(o.sample2_path, std::max(2u, threads / 2u)));
     m1_.reset(new shk::FastqMmap(o.sample1_path, threads));
     if (paired_) m2_.reset(new shk::FastqMmap(o.sample2_path, threads));
     fast_ = m1_->usable() && (!paired_ || m2_->usable()) && !getenv("SHARK_SERIAL_READER");
@@ -384,6 +389,26 @@ class BatchSplitter {
     if (paired_) r2_->seek(off2);
     next_index_ = next_index;
     n_reads_ = n_reads;
+  }
+  // continue with the serial kseq-rule reader behind the first `n` records of each mate file (compressed samples whose parallel
+  // parse met an irregular record: strict records are the kseq reader's records, so the first n are simply read over)
+  void skip_records(uint64_t n, uint64_t next_index)
+  {
+    fast_ = false;
+    auto skip = [n](shk::FastxReader &r) {
+      shk::FastxRecord a;
+      for (uint64_t i = 0; i < n; ++i)
+        if (r.read(a) < 0) break;
+    };
+    if (paired_) {
+      std::thread t2([&] { skip(*r2_); });
+      skip(r1_);
+      t2.join();
+    } else {
+      skip(r1_);
+    }
+    next_index_ = next_index;
+    n_reads_ = n;
   }
   std::string stage_report() const
   {
@@ -510,6 +535,203 @@ class BatchSplitter {
   uint64_t maxnum_;
   unsigned threads_;
   uint64_t next_index_ = 0, n_reads_ = 0;
+};
+
+template <typename T>
+class BoundedQueue {
+ public:
+  explicit BoundedQueue(size_t cap) : cap_(cap) {}
+  void push(T v)
+  {
+    std::unique_lock<std::mutex> l(m_);
+    cv_space_.wait(l, [&] { return q_.size() < cap_; });
+    q_.push_back(std::move(v));
+    cv_item_.notify_one();
+  }
+  bool pop(T &v)
+  {
+    std::unique_lock<std::mutex> l(m_);
+    cv_item_.wait(l, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) return false;
+    v = std::move(q_.front());
+    q_.pop_front();
+    cv_space_.notify_one();
+    return true;
+  }
+  // 1 = got an item, 0 = nothing there right now, -1 = closed and drained
+  int try_pop(T &v)
+  {
+    std::lock_guard<std::mutex> l(m_);
+    if (q_.empty()) return closed_ ? -1 : 0;
+    v = std::move(q_.front());
+    q_.pop_front();
+    cv_space_.notify_one();
+    return 1;
+  }
+  void close()
+  {
+    std::lock_guard<std::mutex> l(m_);
+    closed_ = true;
+    cv_item_.notify_all();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_item_, cv_space_;
+  std::deque<T> q_;
+  size_t cap_;
+  bool closed_ = false;
+};
+
+
+// ---- compressed samples ------------------------------------------------------------------------------------------------------
+// The reference reads a .gz sample through gzread on the parsing thread.  Here the text comes out of the parallel inflaters
+// (fastx_reader.hpp: BGZF blocks, or ordinary gzip in two passes, gzip_parallel.hpp) faster than one kseq-rule parser takes it
+// (0.7 GB/s per file), so it is parsed like a plain file -- by several threads, sequences only, names and qualities read back
+// for the associated reads --, from memory instead of from the file: one CUTTER per mate file takes the inflated text in order,
+// counts newlines (32 bytes at a time) and cuts it into pieces of exactly --batch records (four lines each); the pieces of the two
+// mates are joined by index and parsed by the parser threads (lean_parse_mem), which is also where a record that is not strict
+// four-line FASTQ is noticed: that batch and everything behind it is then read by the serial reader, as for plain files.
+struct GzPiece {
+  std::vector<char, default_init_allocator<char>> text;
+  size_t records = 0;      // whole groups of four lines in `text`
+  bool last = false;       // the stream ended behind this piece
+};
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline size_t newlines_until_avx2(const char *p, size_t n, uint64_t need, uint64_t &found)
+{
+  // scans [p, p + n) until `need` newlines have been seen; returns the number of bytes scanned (ends right behind the need-th
+  // newline when it is reached), found = newlines in the scanned part
+  const __m256i nl = _mm256_set1_epi8('\n');
+  size_t i = 0;
+  uint64_t c = 0;
+  for (; i + 32 <= n; i += 32) {
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i)), nl));
+    const unsigned k = (unsigned)__builtin_popcount(m);
+    if (c + k >= need) {
+      uint32_t mm = m;
+      for (uint64_t skip = need - c - 1; skip; --skip) mm &= mm - 1;      // drop the newlines in front of the wanted one
+      found = need;
+      return i + (size_t)__builtin_ctz(mm) + 1;
+    }
+    c += k;
+  }
+  for (; i < n; ++i)
+    if (p[i] == '\n' && ++c == need) { found = c; return i + 1; }
+  found = c;
+  return n;
+}
+#endif
+inline size_t newlines_until(const char *p, size_t n, uint64_t need, uint64_t &found)
+{
+#if defined(__x86_64__)
+  if (shk::cpu_has_avx2()) return newlines_until_avx2(p, n, need, found);
+#endif
+  uint64_t c = 0;
+  const char *q = p, *e = p + n;
+  while (q < e) {
+    const char *x = (const char *)memchr(q, '\n', (size_t)(e - q));
+    if (!x) break;
+    q = x + 1;
+    if (++c == need) { found = c; return (size_t)(q - p); }
+  }
+  found = c;
+  return n;
+}
+
+class GzCutter {
+ public:
+  GzCutter(const std::string &path, unsigned inflate_threads, uint64_t batch) : src_(path, inflate_threads), batch_(batch), q_(3) {}
+  ~GzCutter() { stop(); }
+  bool ok() const { return src_.ok(); }
+  void start() { th_ = std::thread([this] { run(); }); }
+  // the next piece in stream order; nullptr behind the last one
+  std::unique_ptr<GzPiece> next()
+  {
+    std::unique_ptr<GzPiece> p;
+    if (!q_.pop(p)) return nullptr;
+    return p;
+  }
+  void recycle(std::unique_ptr<GzPiece> p)
+  {
+    std::lock_guard<std::mutex> l(m_);
+    if (free_.size() < 8) free_.push_back(std::move(p));
+  }
+  // ends the cutter early (a failure elsewhere): whatever it still wants to hand over is dropped
+  void stop()
+  {
+    quit_ = true;
+    std::thread drain([this] { std::unique_ptr<GzPiece> p; while (q_.pop(p)) {} });
+    if (th_.joinable()) th_.join();
+    q_.close();
+    drain.join();
+  }
+  double seconds = 0;   // spent scanning and copying (verbose report)
+
+ private:
+  std::unique_ptr<GzPiece> fresh()
+  {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      if (!free_.empty()) {
+        std::unique_ptr<GzPiece> p = std::move(free_.back());
+        free_.pop_back();
+        p->text.clear();
+        p->records = 0;
+        p->last = false;
+        return p;
+      }
+    }
+    return std::unique_ptr<GzPiece>(new GzPiece());
+  }
+  void run()
+  {
+    std::unique_ptr<GzPiece> cur = fresh();
+    uint64_t lines = 0;                 // newlines in cur
+    const uint64_t per = 4 * batch_;
+    const char *d;
+    size_t n;
+    char last_byte = '\n';
+    while (!quit_ && src_.next(d, n)) {
+      auto t0 = std::chrono::steady_clock::now();
+      size_t at = 0;
+      while (at < n && !quit_) {
+        uint64_t found = 0;
+        const size_t used = newlines_until(d + at, n - at, per - lines, found);
+        const size_t o = cur->text.size();
+        cur->text.resize(o + used);
+        memcpy(cur->text.data() + o, d + at, used);
+        at += used;
+        lines += found;
+        if (lines == per) {
+          cur->records = batch_;
+          seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          q_.push(std::move(cur));
+          t0 = std::chrono::steady_clock::now();
+          cur = fresh();
+          lines = 0;
+        }
+      }
+      if (n) last_byte = d[n - 1];
+      seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!quit_) {
+      // a last record without its newline is a record all the same (kseq.h reads the quality up to the end of the file)
+      if (!cur->text.empty() && last_byte != '\n') { cur->text.push_back('\n'); ++lines; }
+      cur->records = (size_t)(lines / 4);
+      cur->last = true;
+      q_.push(std::move(cur));
+    }
+    q_.close();
+  }
+  shk::InflateAhead src_;
+  uint64_t batch_;
+  BoundedQueue<std::unique_ptr<GzPiece>> q_;
+  std::mutex m_;
+  std::vector<std::unique_ptr<GzPiece>> free_;
+  std::atomic<bool> quit_{false};
+  std::thread th_;
 };
 
 // ReadAnalyzer role (ReadAnalyzer.hpp:39-110): reads -> associations, on one GPU.  Up to SHK_PIPE_DEPTH batches are in
@@ -784,52 +1006,6 @@ class ReadOutput {
   std::string carry_;   // previd at the end of the previous batch (only used when a batch starts mid-chunk)
 };
 
-template <typename T>
-class BoundedQueue {
- public:
-  explicit BoundedQueue(size_t cap) : cap_(cap) {}
-  void push(T v)
-  {
-    std::unique_lock<std::mutex> l(m_);
-    cv_space_.wait(l, [&] { return q_.size() < cap_; });
-    q_.push_back(std::move(v));
-    cv_item_.notify_one();
-  }
-  bool pop(T &v)
-  {
-    std::unique_lock<std::mutex> l(m_);
-    cv_item_.wait(l, [&] { return !q_.empty() || closed_; });
-    if (q_.empty()) return false;
-    v = std::move(q_.front());
-    q_.pop_front();
-    cv_space_.notify_one();
-    return true;
-  }
-  // 1 = got an item, 0 = nothing there right now, -1 = closed and drained
-  int try_pop(T &v)
-  {
-    std::lock_guard<std::mutex> l(m_);
-    if (q_.empty()) return closed_ ? -1 : 0;
-    v = std::move(q_.front());
-    q_.pop_front();
-    cv_space_.notify_one();
-    return 1;
-  }
-  void close()
-  {
-    std::lock_guard<std::mutex> l(m_);
-    closed_ = true;
-    cv_item_.notify_all();
-  }
-
- private:
-  std::mutex m_;
-  std::condition_variable cv_item_, cv_space_;
-  std::deque<T> q_;
-  size_t cap_;
-  bool closed_ = false;
-};
-
 }  // namespace
 
 int main(int argc, char *argv[])
@@ -943,6 +1119,26 @@ int main(int argc, char *argv[])
     // ---- the parallel feed -------------------------------------------------------
     shk::BatchTable tab1, tab2;
     bool parallel_feed = !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");
+    // compressed samples (gzip magic in both mate files): inflated in parallel, cut and parsed from memory (GzCutter above);
+    // SHARK_GZ_SERIAL_PARSE=1: the serial kseq-rule reader behind the inflaters, as in round 3 (the tests run both)
+    auto is_gzip = [](const std::string &path) {
+      unsigned char h[2] = {0, 0};
+      FILE *f = fopen(path.c_str(), "rb");
+      const bool gz = f && fread(h, 1, 2, f) == 2 && h[0] == 0x1f && h[1] == 0x8b;
+      if (f) fclose(f);
+      return gz;
+    };
+    const bool gz_feed = parallel_feed && !getenv("SHARK_GZ_SERIAL_PARSE") && is_gzip(opt.sample1_path) && (!opt.paired_flag || is_gzip(opt.sample2_path));
+    if (gz_feed) parallel_feed = false;
+    const unsigned gz_inflaters = std::max(2u, io_threads / (opt.paired_flag ? 2u : 1u));
+    const unsigned n_gz_parsers = gz_feed ? std::max(2u, io_threads / 3u) : 0u;
+    std::unique_ptr<GzCutter> cut1, cut2;
+    if (gz_feed) {
+      cut1.reset(new GzCutter(opt.sample1_path, gz_inflaters, opt.batch));
+      if (opt.paired_flag) cut2.reset(new GzCutter(opt.sample2_path, gz_inflaters, opt.batch));
+      cut1->start();
+      if (cut2) cut2->start();
+    }
     uint64_t n_par_records = 0;       // records both mate files certainly have: the pair stream of the strict part
     bool fixed_width = false;
     if (parallel_feed) {
@@ -981,8 +1177,9 @@ int main(int argc, char *argv[])
     // a reader must not run ahead of the drain without bound: at most `window` batches beyond the one being written
     // the ring: a batch per reader, what the GPUs hold in flight, and a few being turned into text or waiting for their turn to be written
     // (never more batches than the sample has, plus what the serial reader and the GPU pipelines need: --batch may be large)
-    const uint64_t window = std::min<uint64_t>((uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 6,
-                                               n_par_batches + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 2);
+    const uint64_t window = gz_feed ? (uint64_t)n_gz_parsers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 6
+                                    : std::min<uint64_t>((uint64_t)n_readers + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 6,
+                                                         n_par_batches + (uint64_t)n_gpus * (SHK_PIPE_DEPTH + 2) + 2);
     {
       uint64_t widest = 0;
       for (uint64_t i = 0; i < n_par_batches; ++i) {
@@ -992,8 +1189,8 @@ int main(int argc, char *argv[])
       std::lock_guard<std::mutex> l(ctx_m);
       ring_plan.known = true;
       ring_plan.limit = (size_t)window;
-      ring_plan.bytes = n_par_batches ? (size_t)(widest / 2 + 64) : 0;
-      ring_plan.reads = n_par_batches ? (size_t)opt.batch : 0;
+      ring_plan.bytes = n_par_batches ? (size_t)(widest / 2 + 64) : (gz_feed ? (size_t)opt.batch * 160 : 0);
+      ring_plan.reads = (n_par_batches || gz_feed) ? (size_t)opt.batch : 0;
       ring_plan.paired = opt.paired_flag;
       ring_plan.with_qual = static_cast<char>(opt.min_quality) != 0;
       ctx_cv.notify_all();
@@ -1070,6 +1267,95 @@ int main(int argc, char *argv[])
       });
     }
 
+    // ---- compressed samples: pieces of the two mates joined by index, parsed from memory by n_gz_parsers threads ----
+    struct GzJob { uint64_t index; std::unique_ptr<GzPiece> p1, p2; size_t want; };
+    BoundedQueue<std::unique_ptr<GzJob>> gz_jobs(2);
+    std::atomic<uint64_t> gz_batches{0};          // batches the joiner handed out
+    std::thread gz_joiner;
+    if (gz_feed) {
+      gz_joiner = std::thread([&] {
+        for (uint64_t i = 0;; ++i) {
+          std::unique_ptr<GzPiece> a = cut1->next(), b2;
+          if (cut2) b2 = cut2->next();
+          if (!a || (cut2 && !b2)) break;
+          // the pair stream ends with the shorter mate file (FastqSplitter.hpp:60)
+          const size_t want = cut2 ? std::min(a->records, b2->records) : a->records;
+          const bool ends = a->last || (b2 && b2->last) || want < opt.batch;
+          if (want) {
+            std::unique_ptr<GzJob> j(new GzJob{i, std::move(a), std::move(b2), want});
+            gz_batches = i + 1;
+            gz_jobs.push(std::move(j));
+          }
+          if (ends || i >= irregular_at.load()) break;
+        }
+        gz_jobs.close();
+        // (whatever the cutters still hold is not part of the pair stream -- or belongs to the serial reader)
+        cut1->stop();
+        if (cut2) cut2->stop();
+      });
+      for (unsigned r = 0; r < n_gz_parsers; ++r) {
+        readers.emplace_back([&] {
+          {
+            std::unique_lock<std::mutex> l(ctx_m);
+            ctx_cv.wait(l, [&] { return ctx_done; });
+          }
+          shk::RecordLayout gl1, gl2;
+          std::unique_ptr<GzJob> j;
+          while (gz_jobs.pop(j)) {
+            const uint64_t i = j->index;
+            if (i >= irregular_at.load()) continue;
+            {
+              std::unique_lock<std::mutex> l(done_m);
+              done_cv.wait(l, [&] { return i < drained + window || i >= irregular_at.load(); });
+            }
+            if (i >= irregular_at.load()) continue;
+            std::unique_ptr<ReadBatch> b = pool.acquire();
+            if (!b) break;
+            b->index = i;
+            b->first_read = i * opt.batch;
+            b->lean = true;
+            // the text moves into the batch (its old buffer goes back to the cutter); a piece with more records than the pair
+            // stream takes is cut behind the want-th record
+            auto take = [&](GzPiece &p, std::vector<char, default_init_allocator<char>> &text, shk::RecordLayout &lay) -> size_t {
+              text.swap(p.text);
+              size_t len = text.size();
+              if (p.records > j->want) {
+                uint64_t found = 0;
+                len = newlines_until(text.data(), text.size(), 4 * (uint64_t)j->want, found);
+              }
+              if (!lay.usable()) shk::layout_of(text.data(), len, lay);
+              return len;
+            };
+            const size_t len1 = take(*j->p1, b->text1, gl1);
+            size_t ok1 = shk::lean_parse_mem(b->text1.data(), len1, j->want, gl1, need_qual, b->seq1.bytes, b->seq1.off, b->qual1.bytes, b->part1);
+            size_t ok2 = j->want;
+            if (j->p2 && ok1 == j->want) {
+              const size_t len2 = take(*j->p2, b->text2, gl2);
+              ok2 = shk::lean_parse_mem(b->text2.data(), len2, j->want, gl2, need_qual, b->seq2.bytes, b->seq2.off, b->qual2.bytes, b->part2);
+            }
+            cut1->recycle(std::move(j->p1));
+            if (j->p2) cut2->recycle(std::move(j->p2));
+            if (ok1 < j->want || ok2 < j->want) {
+              // not strict four-line FASTQ here: this batch and everything behind it belongs to the serial reader
+              pool.release(std::move(b));
+              uint64_t cur = irregular_at.load();
+              while (i < cur && !irregular_at.compare_exchange_weak(cur, i)) {}
+              done_cv.notify_all();
+              continue;
+            }
+            {
+              std::unique_lock<std::mutex> l(done_m);
+              done_cv.wait(l, [&] { return validated == i || i >= irregular_at.load(); });
+              if (i >= irregular_at.load()) { l.unlock(); pool.release(std::move(b)); continue; }
+              validated = i + 1;
+            }
+            done_cv.notify_all();
+            dispatch(std::move(b));
+          }
+        });
+      }
+    }
+
     // ---- 1+2. reference: legend in file order (FastaSplitter.hpp:48) + index -- while the readers above already parse the sample ----
     auto stop_feed = [&] {
       // a failure before the analyzers exist: end the readers (they stop at an irregular batch 0) and take their batches back
@@ -1084,6 +1370,12 @@ int main(int argc, char *argv[])
           while (q->pop(b)) {}
         }
       });
+      if (gz_feed) {
+        // (the parsers drop every job once batch 0 counts as irregular; the joiner notices the same and stops the cutters)
+        std::thread drop_jobs([&] { std::unique_ptr<GzJob> j; while (gz_jobs.pop(j)) {} });
+        if (gz_joiner.joinable()) gz_joiner.join();
+        drop_jobs.join();
+      }
       for (auto &t : readers) t.join();
       drain_q.join();
     };
@@ -1144,8 +1436,35 @@ int main(int argc, char *argv[])
     std::unique_ptr<BatchSplitter> fs;
     bool serial_needed = false, serial_failed = false;
     std::thread splitter([&] {
+      if (gz_feed && gz_joiner.joinable()) gz_joiner.join();
       for (auto &t : readers) t.join();
       timeline("parallel readers done");
+      if (gz_feed) {
+        // compressed sample: the parsers delivered batches [0, stop); an irregular record sends the rest through the serial reader,
+        // which reads over the records already delivered (they are strict: the kseq reader's records are the same)
+        const uint64_t stop = std::min<uint64_t>(irregular_at.load(), gz_batches.load());
+        serial_needed = irregular_at.load() != UINT64_MAX;
+        bool serial_ok = true;
+        if (serial_needed) {
+          fs.reset(new BatchSplitter(opt, io_threads, pool));
+          serial_ok = fs->ok();
+          if (serial_ok) {
+            fs->skip_records(stop * opt.batch, stop);
+            for (;;) {
+              auto b = (*fs)();
+              if (!b) break;
+              dispatch(std::move(b));
+            }
+          }
+        }
+        serial_failed = !serial_ok;
+        for (auto &q : todo) q->close();
+        timeline("serial reader done");
+        std::lock_guard<std::mutex> l(done_m);
+        split_finished = true;
+        done_cv.notify_all();
+        return;
+      }
       const uint64_t stop = std::min<uint64_t>(irregular_at.load(), n_par_batches);   // batches [0, stop) came from the readers
       // nothing left when the readers delivered every batch and a mate file ends exactly there (the pair stream ends with the
       // shorter file, FastqSplitter.hpp:60)

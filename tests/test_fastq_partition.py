@@ -241,3 +241,122 @@ def test_lean_reader_stops_at_the_first_irregular_batch(tool, tmp_path, damage):
             continue
         assert got["ok"] and got["first_irregular_batch"] == bad // batch, (damage, batch, got)
         assert got["records"] == (bad // batch) * batch
+
+
+# ---------------------------------------------------------------------------
+# ordinary gzip, inflated in parallel (gzip_parallel.hpp, through the host-only tool shark_amd/bin/shark-gunzip)
+# ---------------------------------------------------------------------------
+GUNZIP = os.path.join(ROOT, "shark_amd", "bin", "shark-gunzip")
+
+
+@pytest.fixture(scope="module")
+def gunzip_tool():
+    if not os.path.exists(GUNZIP):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "shark_amd", "csrc"), "../bin/shark-gunzip"], check=True, stdout=subprocess.DEVNULL)
+    return GUNZIP
+
+
+def _gunzip(tool_path, path, threads, chunk):
+    env = dict(os.environ, SHARK_GZ_CHUNK=str(chunk))
+    r = subprocess.run([tool_path, str(path), str(threads)], capture_output=True, env=env, timeout=300)
+    return r.returncode, r.stdout
+
+
+def _fastq_text(rng, n, L=150, real_names=True):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    bases = acgt[rng.integers(0, 4, size=(n, L))]
+    quals = (rng.integers(2, 42, size=(n, L)) + 33).astype(np.uint8)
+    out = []
+    for i in range(n):
+        name = b"@A00123:45:HXXXXXXXX:1:%d:%d:%d 1:N:0:ACGT" % (1101 + i // 5000, int(rng.integers(1000, 30000)), int(rng.integers(1000, 30000))) if real_names else b"@r%09d/1" % i
+        out.append(name + b"\n" + bases[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("shape", ["gzip_-1", "gzip_-6", "gzip_-9", "gzip_multi_member", "stored_member_in_the_middle", "synthetic_names_constant_quality"])
+def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
+    """every chunking (chunks of 64 KiB ... 1 MiB of compressed bytes: hundreds of block searches, windows handed from chunk to
+    chunk) and every thread count gives exactly the bytes zlib gives: the levels gzip writes, several members in one file (a new
+    member has nothing in front of it), a member of stored blocks (its chunks find no block to start from and are inflated by the
+    chunk in front of them), and text whose back-references never stop pointing into the unseen window (constant name prefix and
+    quality line: the symbols stay markers to the end of every chunk)"""
+    import zlib
+    rng = np.random.default_rng(abs(hash(shape)) % 1000)
+    text = _fastq_text(rng, 24000, real_names=shape != "synthetic_names_constant_quality")
+    if shape == "synthetic_names_constant_quality":
+        lines = text.split(b"\n")[:-1]
+        text = b"\n".join(l if i % 4 != 3 else b"I" * len(l) for i, l in enumerate(lines)) + b"\n"
+    path = tmp_path / "t.gz"
+    if shape.startswith("gzip_-"):
+        open(path, "wb").write(gzip.compress(text, compresslevel=int(shape[-1])))
+    elif shape == "gzip_multi_member":
+        cut = [0, len(text) // 5, len(text) // 5 + 1, len(text) // 2, len(text)]
+        open(path, "wb").write(b"".join(gzip.compress(text[a:b], compresslevel=lv) for a, b, lv in zip(cut, cut[1:], (6, 1, 9, 4))))
+    elif shape == "stored_member_in_the_middle":
+        a, b = len(text) // 3, len(text) // 3 + 600_000
+        open(path, "wb").write(gzip.compress(text[:a], 6) + gzip.compress(text[a:b], 0) + gzip.compress(text[b:], 6))
+    else:
+        open(path, "wb").write(gzip.compress(text, compresslevel=6))
+    assert gzip.decompress(open(path, "rb").read()) == text
+    for chunk, threads in ((65536, 8), (200_000, 3), (1 << 20, 2)):
+        rc, out = _gunzip(gunzip_tool, path, threads, chunk)
+        if os.path.getsize(path) < 3 * chunk:      # fewer than three chunks: not worth it, left to gzread
+            assert rc == 3 and out == b"", (shape, chunk)
+            continue
+        assert rc == 0 and out == text, (shape, chunk, threads, len(out), len(text))
+
+
+def test_parallel_gunzip_declines_what_it_cannot_do_and_stops_where_the_stream_breaks(gunzip_tool, tmp_path):
+    """small files, files that are not gzip and gzip of something that is not text are left to gzread (exit code 3 of the tool =
+    usable() false); a truncated file and a file with a damaged byte deliver a PREFIX of the text and end -- nothing behind the damage,
+    although the chunks behind it had found their block starts"""
+    import zlib
+    rng = np.random.default_rng(5)
+    text = _fastq_text(rng, 12000)
+    gz = gzip.compress(text, 6)
+    open(tmp_path / "small.gz", "wb").write(gzip.compress(text[:3000], 6))
+    open(tmp_path / "plain.fq", "wb").write(text)
+    open(tmp_path / "binary.gz", "wb").write(gzip.compress(rng.integers(0, 256, size=2_000_000, dtype=np.uint8).tobytes(), 6))
+    for name in ("small.gz", "plain.fq", "binary.gz"):
+        rc, out = _gunzip(gunzip_tool, tmp_path / name, 4, 65536)
+        assert rc == 3 and out == b"", name
+    open(tmp_path / "trunc.gz", "wb").write(gz[:len(gz) * 2 // 3])
+    rc, out = _gunzip(gunzip_tool, tmp_path / "trunc.gz", 4, 65536)
+    want = zlib.decompressobj(31).decompress(gz[:len(gz) * 2 // 3])
+    assert rc == 0 and text.startswith(out) and len(want) - 70000 <= len(out) <= len(want), (len(out), len(want))
+    # a damaged byte inside a Huffman block: the codes resynchronise, zlib delivers a few wrong bytes and notices at the trailer's
+    # CRC-32 -- behind everything it delivered, and the reference's reader ignores that error (kseq.h: a negative gzread is end of
+    # file).  The parallel inflate gives exactly what raw inflate of the damaged stream gives; when that is invalid, a prefix.
+    n_checked = 0
+    for at in (len(gz) // 2, len(gz) // 3 + 17, len(gz) * 3 // 4 + 5):
+        bad = bytearray(gz)
+        bad[at] ^= 0x5A
+        open(tmp_path / "bad.gz", "wb").write(bytes(bad))
+        rc, out = _gunzip(gunzip_tool, tmp_path / "bad.gz", 4, 65536)
+        assert rc == 0
+        d = zlib.decompressobj(-15)
+        try:
+            want = d.decompress(bytes(bad[10:]))       # (the header is ten bytes: no name, no extra field)
+            assert out == want, (at, len(out), len(want))
+            n_checked += 1
+        except zlib.error:
+            good = len(os.path.commonprefix([out, text]))
+            assert good > 0 and len(out) - good < 400_000, (at, good, len(out))
+    assert n_checked >= 1
+
+
+def test_reader_over_parallel_gunzip_delivers_the_serial_readers_records(tool, tmp_path):
+    """the kseq-rule reader on top of the parallel inflate (what `shark` does with a .fq.gz sample) delivers the records it delivers
+    with SHARK_GZ_SERIAL=1 (zlib's gzread on a read-ahead thread) and from the plain file"""
+    rng = np.random.default_rng(8)
+    text = _fastq_text(rng, 30000)
+    open(tmp_path / "t.fq", "wb").write(text)
+    open(tmp_path / "t.fq.gz", "wb").write(gzip.compress(text[:len(text) // 2], 1) + gzip.compress(text[len(text) // 2:], 9))
+
+    def rec(path, **env):
+        return json.loads(subprocess.run([tool, "--records", str(path)], capture_output=True, text=True, check=True, env=dict(os.environ, **env)).stdout)
+    want = rec(tmp_path / "t.fq")
+    par = rec(tmp_path / "t.fq.gz", SHARK_GZ_CHUNK="100000")
+    ser = rec(tmp_path / "t.fq.gz", SHARK_GZ_SERIAL="1")
+    assert want["records"] == 30000
+    assert (par["records"], par["bases"], par["fnv"]) == (ser["records"], ser["bases"], ser["fnv"]) == (want["records"], want["bases"], want["fnv"])

@@ -1140,7 +1140,8 @@ def test_dense_table_long_probe_paths(oracle, k, bf_bits, n_bases, monkeypatch):
     assert int(og[-1]) >= n
 
 
-@pytest.mark.parametrize("shape", ["fixed_width", "ragged", "second_file_shorter", "first_file_shorter_no_final_newline", "bgzf", "single_end_gz"])
+@pytest.mark.parametrize("shape", ["fixed_width", "ragged", "second_file_shorter", "first_file_shorter_no_final_newline", "bgzf", "single_end_gz",
+                                   "gzip_multi_member", "gzip_-9"])
 def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
     """every way the CLI gets its reads -- arithmetic offsets of fixed-width records, the parallel newline count, the pair
     stream ending with the shorter mate file, a last record without newline (serial reader takes over), BGZF blocks inflated
@@ -1191,6 +1192,19 @@ def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
         with gzip.open(str(f1) + ".gz", "wb") as fh:
             fh.write(t1)
         f1 = tmp_path / "a_1.fq.gz"
+    env = dict(os.environ)
+    if shape in ("gzip_multi_member", "gzip_-9"):
+        # ordinary gzip, inflated in parallel in two passes (gzip_parallel.hpp); chunks of 16 KiB so that files of this size are cut
+        # into a dozen of them (the default, 4 MiB, leaves files under 12 MiB to gzread)
+        env["SHARK_GZ_CHUNK"] = "16384"
+        for f, data in ((f1, t1), (f2, t2)):
+            if shape == "gzip_-9":
+                blob = gzip.compress(data, compresslevel=9)
+            else:
+                cuts = [0, len(data) // 7, len(data) // 2, len(data) // 2 + 1, len(data)]
+                blob = b"".join(gzip.compress(data[a:b], compresslevel=lv) for a, b, lv in zip(cuts, cuts[1:], (1, 6, 9, 3)))
+            open(str(f) + ".gz", "wb").write(blob)
+        f1, f2 = tmp_path / "a_1.fq.gz", tmp_path / "a_2.fq.gz"
     args = ["-r", str(fa), "-1", str(f1), "-k", "15", "-q", "4", "-c", "0.3"] + (["-2", str(f2)] if paired else [])   # (-q 4 masks ~5 % of the bases)
     ossv = tmp_path / "o.ssv"
     oracle.run_cli(args + ["-o", str(tmp_path / "o1.fq")] + (["-p", str(tmp_path / "o2.fq")] if paired else []), str(ossv))
@@ -1198,7 +1212,7 @@ def test_cli_feeds_agree_with_the_oracle_cli(oracle, tmp_path, shape):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
     for extra in (["--batch", "97", "-t", "5"], ["--batch", "1000", "-t", "3"], []):
         r = subprocess.run([exe] + args + ["-o", str(tmp_path / "h1.fq")] + (["-p", str(tmp_path / "h2.fq")] if paired else []) + extra,
-                           capture_output=True, cwd=str(tmp_path))
+                           capture_output=True, cwd=str(tmp_path), env=env)
         assert r.returncode == 0, r.stderr.decode()[-1500:]
         assert r.stdout == ossv.read_bytes(), (shape, extra)
         assert (tmp_path / "h1.fq").read_bytes() == (tmp_path / "o1.fq").read_bytes()
