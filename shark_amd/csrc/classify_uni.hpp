@@ -111,6 +111,15 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #ifndef SHK_ANCH_CUT
 #define SHK_ANCH_CUT 0
 #endif
+// how the anchored extension compares a mate with the reference: 1 = base by base (one xor per 16 bases into a bit stream, then the
+// validity window test per slot), 0 = k-mer by k-mer (round 3: two 2k-bit windows per slot and round).  Same results; measured on one
+// box per 10 M pairs at 50 / 100 % on-target (profiles/README.md, round 4): configs[2] index 20.4 / 17.8 ms against 21.8 / 18.2;
+// 1 000 genes 11.25 / 14.15 against 11.5 / 14.2.  (The form alone changed little -- its first version, whose refpay loads waited for
+// the match bits, was 9 % SLOWER: a second dependent memory round trip; what brought both forms under round 3's 21.7 / 18.9 ms are
+// the sampled bucket carrying its reference position itself (atab) and the vote's scalar bounds.)
+#ifndef SHK_ANCH_BASEWISE
+#define SHK_ANCH_BASEWISE 1
+#endif
 #if SHK_ANCH_CUT != 0 && !defined(SHK_TIMING_ONLY)
 #error "-DSHK_ANCH_CUT=n builds a library whose results are WRONG (timing-only ablation): say so with -DSHK_TIMING_ONLY as well"
 #endif
@@ -177,8 +186,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool LX = UG::LX;
   constexpr int WAVES = UG::WAVES;
   constexpr uint32_t S = 64 * U;
-  // per wave: fw + rv + validity, and -- table modes, for the anchored extension -- one more bit stream: base-by-base agreement with the reference
-  constexpr uint32_t WORDS = stage_words_for(S) + (ANCH ? vbit_words_for(S) : 0u);
+  // per wave: fw + rv + validity, and -- table modes, for the base-by-base form of the anchored extension -- one more bit stream: agreement with the reference
+  constexpr uint32_t WORDS = stage_words_for(S) + ((ANCH && SHK_ANCH_BASEWISE) ? vbit_words_for(S) : 0u);
   __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -230,7 +239,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
   uint32_t *const rv = fw + code_dwords_for(S);
   uint64_t *const vbits = wbase + code_dwords_for(S);
-  uint64_t *const mbits = vbits + vbit_words_for(S);   // (ANCH only) bit p: the read's base at packed position p equals the reference's under the mate's anchor
+  [[maybe_unused]] uint64_t *const mbits = vbits + vbit_words_for(S);   // (base-by-base form of the anchored extension only) bit p: the read's base at packed position p equals the reference's under the mate's anchor
   constexpr uint32_t rcap = stage_cap_bases(S);
 
   // ---- geometry: of every read of the batch (UNI) or of the current read ----------
@@ -926,25 +935,49 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           const bool alone = __ballot(lane_other) == 0ull;   // (then Sg[] are g's hits already)
           if (have0 && (alone || !FINAL)) {
             uint32_t cov = 0, oth = 0;
-            if (!alone) {
-              uint64_t Op = 0ull;
+            // Bounds on the scalar unit first -- they settle the usual read from a gene, whose coverage passes with room to spare:
+            // g's hits cover AT LEAST one base each and k - 1 more behind the last (the union of [p, p + k) contains every p);
+            // the other hits cover AT MOST their number + (k - 1) per run of neighbouring slots.  thr_r is the smallest coverage that
+            // passes c * len (or more, where it was planned for a read without invalid characters: still a sufficient test).
+            bool out1 = false, settled_by_bounds = false;
+            {
+              uint32_t n_mine = 0, n_oth = 0, runs_oth = 0;
+              uint64_t carry = 0ull;
 #pragma unroll
               for (int j = 0; j < J; ++j) {
-                const bool mine = hit[j] & !multi[j] & (payload[j] == p0);
-                Sg[j] = __ballot(mine);
-                const uint64_t Oc = __ballot(hit[j] & !mine);
-                oth += cover(Oc, Op);
-                Op = Oc;
+                if (!alone) {
+                  const bool mine = hit[j] & !multi[j] & (payload[j] == p0);
+                  Sg[j] = __ballot(mine);
+                  const uint64_t Oc = __ballot(hit[j] & !mine);
+                  n_oth += (uint32_t)__builtin_popcountll(Oc);
+                  runs_oth += (uint32_t)__builtin_popcountll(Oc & ~((Oc << 1) | carry));
+                  carry = Oc >> 63;
+                }
+                n_mine += (uint32_t)__builtin_popcountll(Sg[j]);
               }
-              oth += cover(0ull, Op);
+              const uint32_t cov_lb = n_mine + hk - 1u, oth_ub = n_oth + (hk - 1u) * runs_oth;
+              if (thr_r != 0u && cov_lb >= thr_r && (FINAL || cov_lb > oth_ub + ub_rest)) { out1 = true; settled_by_bounds = true; }
             }
+            if (!settled_by_bounds) {
+              // (rare: a read near the threshold, or with many k-mers of other genes) the exact counts
+              if (!alone) {
+                uint64_t Op = 0ull;
 #pragma unroll
-            for (int j = 0; j < J; ++j) cov += cover(Sg[j], j ? Sg[j - 1] : 0ull);
-            cov += cover(0ull, Sg[J - 1]);
-            const uint32_t len = wave_sum_u32(lane_valid_bases());
-            const bool pass = (double)cov >= H->c * (double)len;
-            // FINAL (alone): the threshold decides (one gene: --single changes nothing).  Else: g has to lead by more than ub_rest
-            const bool out1 = pass && (FINAL || cov > oth + ub_rest);
+                for (int j = 0; j < J; ++j) {
+                  const uint64_t Oc = __ballot(hit[j] & !(!multi[j] & (payload[j] == p0)));
+                  oth += cover(Oc, Op);
+                  Op = Oc;
+                }
+                oth += cover(0ull, Op);
+              }
+#pragma unroll
+              for (int j = 0; j < J; ++j) cov += cover(Sg[j], j ? Sg[j - 1] : 0ull);
+              cov += cover(0ull, Sg[J - 1]);
+              const uint32_t len = wave_sum_u32(lane_valid_bases());
+              const bool pass = (double)cov >= H->c * (double)len;
+              // FINAL (alone): the threshold decides (one gene: --single changes nothing).  Else: g has to lead by more than ub_rest
+              out1 = pass && (FINAL || cov > oth + ub_rest);
+            }
             if (out1 && lane == 0 && !SHK_ABL(P, 64u)) {
               const ClassifyOut *O = H->out;
               O->count[read] = 1u;
@@ -1058,7 +1091,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // 64 slots of a round read 256 bytes of it and 24 bytes of the packed reference instead of 64 buckets at 64 hashed addresses.
     //  (1) sample: SHK_ANCH_SAMPLE (four) slots spread over each mate, one per lane, probed through the table as ever (one hash per lane;
     //      measured on the configs[2] index per 10 M pairs at 0 / 50 / 100 % on-target: 8 slots 36.4 / 28.7 / 27.9 ms, 4: 34.5 / 27.5 / 27.8, 2: 33.5 / 26.5 / 28.5);
-    //  (2) the first match of each mate gives that mate's anchor: reference position + relative orientation;
+    //  (2) the first match of each mate gives that mate's anchor -- reference position + relative orientation --, which the sampled
+    //      bucket carries itself (atab);
     //  (3) every slot of an anchored mate is compared with the reference k-mer at its implied position, as a 2k-bit compare of the
     //      read's window with the reference's.  Equal k-mers have equal filter positions, hence equal table slots: the slot is
     //      settled with EXACTLY what a probe would have returned.  Unequal: the slot stays open -- nothing is assumed;
@@ -1101,13 +1135,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         s_ok = (sw >> ((uint32_t)(s_pos >> P.sum_shift) & 31u)) & 1u;
       }
       if (!__ballot(s_ok)) return false;
+      // (the sample probes `atab`: the position table's buckets with a slot's occurrence in the reference in place of its list --
+      //  "is this k-mer in the index" and "where in the reference" in one memory round trip instead of two dependent ones)
       const uint32_t sb = s_ok ? ((uint32_t)s_pos & bmask) : spare;
+      const uint4 *atab16 = reinterpret_cast<const uint4 *>(H->atab);
       uint4 sbk;
       if (P.tab_nt) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + sb);
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(atab16) + sb);
         sbk = make_uint4(v.x, v.y, v.z, v.w);
       } else {
-        sbk = tab16[sb];
+        sbk = atab16[sb];
       }
       const uint32_t s_want = want_for(s_pos);
       const bool sm0 = sbk.y == s_want, sm1 = sbk.w == s_want;       // (home bucket only: a displaced key gives no anchor)
@@ -1117,7 +1154,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       return true;
 #endif
       // (2)
-      const uint32_t s_slot = 2u * sb + (sm0 ? 0u : 1u);
+      const uint32_t s_anc = sm0 ? sbk.x : sbk.z;
       uint32_t ax[2] = {0u, 0u}, as0[2] = {0u, 0u};
       bool aopp[2] = {false, false}, ahave[2] = {false, false};
 #pragma unroll
@@ -1125,8 +1162,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(SH >> (NS * m)) & ((1u << NS) - 1u));
         if (mask) {
           const int ln = __builtin_amdgcn_readfirstlane(__builtin_ctz(mask) + (int)NS * m);
-          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)s_slot, ln);
-          const uint32_t a = H->anchor[slot];
+          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)s_anc, ln);
           ahave[m] = a != 0xFFFFFFFFu;
           ax[m] = a & 0x7FFFFFFFu;
           aopp[m] = ((a >> 31) != 0u) != (__builtin_amdgcn_readlane((int)(s_isrc ? 1u : 0u), ln) != 0);
@@ -1137,6 +1173,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #if SHK_ANCH_CUT == 2
       return ax[0] + ax[1] != 12345u;
 #endif
+#if SHK_ANCH_BASEWISE
       // (3) base by base.  An anchor maps a mate onto the reference linearly: the base at packed position b stands against
       // reference base x0 - s0 + b (same strand), or against the complement of reference base x0 + s0 + k - 1 - b (other strand).
       // Lane (m, c) = (lane >> 5, lane & 31) compares the 16 bases of chunk c of mate m in ONE xor of two dwords -- the read's
@@ -1226,6 +1263,44 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         carry = Uc >> 63;
       }
       const uint32_t ub = n_open + (k - 1u) * n_runs;
+#else
+      // (3)
+      uint32_t known = 0u, n_match = 0u, ub = 0u;
+      uint64_t Uprev = 0ull;
+      const uint32_t *refpay = H->refpay;
+      const uint32_t *ref2 = H->ref2;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t pp = (uint32_t)lane + 64u * j;
+        const bool in2 = (pp - P2) < nk2;
+        const bool okv = slot_valid(pp);
+        const bool have = in2 ? ahave[1] : ahave[0];
+        const bool opp = in2 ? aopp[1] : aopp[0];
+        const uint32_t x0 = in2 ? ax[1] : ax[0];
+        const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
+        const uint32_t xr = opp ? x0 - dd : x0 + dd;
+        const bool inb = okv & have & (xr < ref_total);
+        const uint32_t xs = inb ? xr : 0u;
+        const uint32_t rp = refpay[xs];
+        const uint32_t *rw = ref2 + (xs >> 4);
+        const uint32_t g0 = rw[0], g1 = rw[1], g2 = rw[2];
+        uint64_t x, y;
+        windows(j, x, y);
+        const uint32_t sg = (xs & 15u) << 1;
+        const uint64_t W = ((uint64_t)__builtin_amdgcn_alignbit(g2, g1, sg) << 32) | __builtin_amdgcn_alignbit(g1, g0, sg);
+        const bool eq = opp ? ((y & kmer_mask) == (~W & kmer_mask)) : ((x & kmer_mask) == (W & kmer_mask));
+        const bool mm = inb & (rp != REFPAY_NONE) & eq;
+        mt[j] = mm;
+        slo[j] = rp;
+        known |= (mm | !okv) ? (1u << j) : 0u;                      // (a slot that does not exist or is no valid k-mer needs no probe either)
+        lane_any |= mm;
+        n_match += (uint32_t)__builtin_popcountll(__ballot(mm));
+        const uint64_t Uc = __ballot(okv & !mm);                    // open slots
+        ub += cover(Uc, Uprev);
+        Uprev = Uc;
+      }
+      ub += cover(0ull, Uprev);
+#endif
       if (n_match < 4u) { lane_any = false; return false; }
 #if SHK_ANCH_CUT == 3
       return n_match != 12345u;

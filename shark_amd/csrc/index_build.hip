@@ -285,6 +285,13 @@ __global__ __launch_bounds__(RK_THREADS) void ref_anchor_kernel(const uint8_t *_
   atomicAdd(lost, 1u);
 }
 
+// the position table with a slot's occurrence in the reference in place of its list (DeviceIndex::atab)
+__global__ void atab_fill_kernel(const uint64_t *__restrict__ tab, const uint32_t *__restrict__ anchor, uint64_t *__restrict__ atab, uint64_t n_slots)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x)
+    atab[i] = (tab[i] & 0xFFFFFFFF00000000ull) | anchor[i];
+}
+
 // Multi-gene lists in REFERENCE order.  A probe that matches a multi-gene list gets its rank r and then reads ent[r] and ids[...] at
 // addresses that have nothing to do with each other from one k-mer of a read to the next.  For the slots the anchored extension
 // settles, the same lists are kept a second time, laid out along the reference: entry n_set + 1 + x of `ent` belongs to the k-mer at
@@ -603,13 +610,14 @@ int build_index(Ctx *ctx)
         ix.ref_total = 0;
         if (!wrap && total > 0 && total < (1ull << 31) && !getenv("SHK_NO_ANCHOR")) {
           const uint64_t n_dw = (total + 15) / 16;
-          uint32_t *d_lost = nullptr, *d_lens = nullptr;
+          uint32_t *d_lost = nullptr, *d_lens = nullptr, *d_anchor = nullptr;
           uint64_t *d_stmp = nullptr;
           ListEntry *ent_all = nullptr;
           uint16_t *ids_all = nullptr;
           auto drop_anchor = [&]() {
-            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.anchor);
-            ix.ref2 = ix.refpay = ix.anchor = nullptr;
+            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.atab);
+            ix.ref2 = ix.refpay = nullptr;
+            ix.atab = nullptr;
             ix.ref_total = 0;
           };
           // Everything in here is optional, so nothing in here may fail the build: an allocation that cannot be had, a launch or a
@@ -618,17 +626,21 @@ int build_index(Ctx *ctx)
 #define AX_HIP(call) do { if ((call) != hipSuccess) return false; } while (0)
           bool have = hipMalloc((void **)&ix.ref2, (n_dw + 4) * sizeof(uint32_t)) == hipSuccess &&
                       hipMalloc((void **)&ix.refpay, (total + 8) * sizeof(uint32_t)) == hipSuccess &&   // (+8: read 16 bytes at a time by tools)
-                      hipMalloc((void **)&ix.anchor, (slots + 2) * sizeof(uint32_t)) == hipSuccess &&
+                      hipMalloc((void **)&d_anchor, (slots + 2) * sizeof(uint32_t)) == hipSuccess &&
+                      hipMalloc((void **)&ix.atab, (slots + 2) * sizeof(uint64_t)) == hipSuccess &&
                       hipMalloc((void **)&d_lost, sizeof(uint32_t)) == hipSuccess;
           have = have && [&]() -> bool {
             AX_HIP(hipMemsetAsync(ix.ref2 + n_dw, 0, 4 * sizeof(uint32_t), st));
             AX_HIP(hipMemsetAsync(ix.refpay + total, 0xFF, 8 * sizeof(uint32_t), st));
-            AX_HIP(hipMemsetAsync(ix.anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
+            AX_HIP(hipMemsetAsync(d_anchor, 0xFF, (slots + 2) * sizeof(uint32_t), st));
             AX_HIP(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), st));
             hipLaunchKernelGGL(ref_pack2_kernel, dim3(grid_for(n_dw, 256)), dim3(256), 0, st, d_bytes, total, ix.ref2, n_dw);
             AX_HIP(hipGetLastError());
             hipLaunchKernelGGL(ref_anchor_kernel, dim3(grid_for(total, RK_THREADS)), dim3(RK_THREADS), 0, st, d_bytes, total, d_rec_off, n_rec, k, ix.bf_bits,
-                               ix.bf_bits - 1, ix.pow2 ? 1 : 0, (const uint64_t *)ix.tab, lg, ix.refpay, ix.anchor, d_lost);
+                               ix.bf_bits - 1, ix.pow2 ? 1 : 0, (const uint64_t *)ix.tab, lg, ix.refpay, d_anchor, d_lost);
+            AX_HIP(hipGetLastError());
+            hipLaunchKernelGGL(atab_fill_kernel, dim3(grid_for(slots + 2, 256)), dim3(256), 0, st, (const uint64_t *)ix.tab, (const uint32_t *)d_anchor, ix.atab,
+                               (uint64_t)(slots + 2));
             AX_HIP(hipGetLastError());
             uint32_t h_lost = 0;
             AX_HIP(hipMemcpyAsync(&h_lost, d_lost, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -636,6 +648,7 @@ int build_index(Ctx *ctx)
             return h_lost == 0;   // (a key the table does not hold: leave the extension out rather than trust it)
           }();
           (void)hipFree(d_lost);
+          (void)hipFree(d_anchor);
           // multi-gene lists along the reference (see ref_multi_len_kernel); left out -- the lists then stay where the ranks point --
           // when the copies would not fit the 32-bit list offsets or the 30-bit payload, or their memory cannot be had.  A failure
           // behind the point where refpay has been rewritten drops the whole extension (ix.ent / ix.ids stay valid either way: their

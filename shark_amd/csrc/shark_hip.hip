@@ -27,7 +27,7 @@ int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
 
 static void free_index(DeviceIndex &ix)
 {
-  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.anchor);
+  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.atab);
   ix = DeviceIndex{};
 }
 
@@ -150,7 +150,7 @@ static void fill_params(Ctx *ctx, Slot &s, const shk_batch *b)
   p.tab_nt = ix.tab_lg && (16ull << ix.tab_lg) > (256ull << 20);   // beyond L2 + Infinity Cache
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
   p.lx_gene = 0xFFFFFFFFu;   // (launch_classify_uni sets it when it chooses the exact LDS table)
-  p.ref2 = ix.ref2; p.refpay = ix.refpay; p.anchor = ix.anchor; p.ref_total = ix.ref_total;
+  p.ref2 = ix.ref2; p.refpay = ix.refpay; p.atab = ix.atab; p.ref_total = ix.ref_total;
   p.bf_bits = ix.bf_bits;
   p.bf_mask = ix.pow2 ? ix.bf_bits - 1 : ~0ull;   // (non power-of-two: positions are reduced explicitly, the masks become no-ops)
   if (!ix.pow2) {

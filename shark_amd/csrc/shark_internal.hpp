@@ -79,9 +79,13 @@ struct DeviceIndex {
   //            characters as 0), padded by four dwords
   //   refpay : per base position x the low word of the position-table slot of the k-mer STARTING at x (multi | payload; what a
   //            probe of that k-mer returns), REFPAY_NONE where no valid k-mer starts (record end, invalid character)
-  //   anchor : per table slot (2 per bucket) one occurrence of its key in the reference: x | strand << 31, strand = 1 when the
-  //            k-mer at x is stored reverse-complemented (its canonical form is the reverse complement); 0xFFFFFFFF = unset
-  uint32_t *ref2 = nullptr, *refpay = nullptr, *anchor = nullptr;
+  //   atab   : the position table a second time with, in place of a slot's low word (its list), one occurrence of its key in the
+  //            reference: x | strand << 31, strand = 1 when the k-mer at x is stored reverse-complemented (its canonical form is the
+  //            reverse complement); 0xFFFFFFFF = unset.  Same buckets, same high words: the anchored extension's sample probes THIS
+  //            table, and the bucket that says "the k-mer is in the index" says where in the reference in the same memory round trip
+  //            (round 3 kept the occurrences in an array of their own, indexed by the slot that had matched: a dependent load)
+  uint32_t *ref2 = nullptr, *refpay = nullptr;
+  uint64_t *atab = nullptr;
   uint32_t ref_total = 0;    // bases in ref2 / entries in refpay; 0 = not built
 };
 constexpr uint32_t REFPAY_NONE = 0xFFFFFFFFu;   // (multi with payload 2^30-1: not a rank, n_set <= 2^30-1 entries have ranks below that)
@@ -137,10 +141,10 @@ struct ClassifyParams {
   const uint64_t *off2;
   const uint8_t *qual1;
   const uint8_t *qual2;
-  // anchored extension (table modes): DeviceIndex::ref2 / refpay / anchor; ref_total = 0: not available
+  // anchored extension (table modes): DeviceIndex::ref2 / refpay / atab; ref_total = 0: not available
   const uint32_t *ref2;
   const uint32_t *refpay;
-  const uint32_t *anchor;
+  const uint64_t *atab;
   uint32_t ref_total;
   // batches whose reads all have one length per mate (the usual sequencer output) take classify_uni_kernel's UNI instantiation,
   // the others its ragged one, which stages every read in the layout of the batch's LONGEST mates:
