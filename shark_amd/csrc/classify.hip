@@ -615,21 +615,40 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
   uint32_t bad = 0;
   uint64_t mx1 = 0, mx2 = 0;   // the longest mates: the ragged instantiation stages the whole batch in their layout
   if (blockIdx.x == 0 && threadIdx.x == 0 && n) bad |= (P.off1[0] != 0) | (P.seq2 && P.off2[0] != 0);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t l1 = P.off1[i + 1] - P.off1[i];
+  // (a read's end is the next one's start: one coalesced load per read and mate, the neighbour's by shuffle, lane 63's from memory)
+  const int lane_u = threadIdx.x & 63;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = i0 + threadIdx.x;
+    const bool valid = i < n;
+    const uint64_t a1 = P.off1[valid ? i : n];
+    uint64_t b1 = __shfl_down(a1, 1);
+    if (lane_u == 63) b1 = P.off1[valid ? i + 1 : n];
+    const uint64_t l1 = valid ? b1 - a1 : L1;
     bad |= l1 != L1;
     mx1 = l1 > mx1 ? l1 : mx1;
     if (P.seq2) {
-      const uint64_t l2 = P.off2[i + 1] - P.off2[i];
+      const uint64_t a2 = P.off2[valid ? i : n];
+      uint64_t b2 = __shfl_down(a2, 1);
+      if (lane_u == 63) b2 = P.off2[valid ? i + 1 : n];
+      const uint64_t l2 = valid ? b2 - a2 : L2;
       bad |= l2 != L2;
       mx2 = l2 > mx2 ? l2 : mx2;
     }
   }
-  if (bad) {
-    atomicOr(&bad_s, 1u);
-    // (clipped: a mate of 2^31 bases or more fits no specialisation and the kernel clamps the layout anyway)
-    atomicMax(&max_s[0], (uint32_t)(mx1 < 0x7FFFFFFFull ? mx1 : 0x7FFFFFFFull));
-    atomicMax(&max_s[1], (uint32_t)(mx2 < 0x7FFFFFFFull ? mx2 : 0x7FFFFFFFull));
+  // (per wave, then per workgroup)
+  const bool wave_bad = __ballot(bad != 0u) != 0ull;
+  if (wave_bad) {
+    for (int d = 32; d; d >>= 1) {
+      const uint64_t o1 = __shfl_xor(mx1, d), o2 = __shfl_xor(mx2, d);
+      mx1 = o1 > mx1 ? o1 : mx1;
+      mx2 = o2 > mx2 ? o2 : mx2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicOr(&bad_s, 1u);
+      // (clipped: a mate of 2^31 bases or more fits no specialisation and the kernel clamps the layout anyway)
+      atomicMax(&max_s[0], (uint32_t)(mx1 < 0x7FFFFFFFull ? mx1 : 0x7FFFFFFFull));
+      atomicMax(&max_s[1], (uint32_t)(mx2 < 0x7FFFFFFFull ? mx2 : 0x7FFFFFFFull));
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -656,6 +675,196 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
       __threadfence();
       flag[0] = ok ? 1u : 0u;
     }
+  }
+}
+
+// ---- a batch of mixed lengths, class by class (classify_uni_kernel's CLS instantiation) ---------------------------------------
+// Three passes over the offsets (16 B per pair each) behind uniform_check_kernel, all of which return at once unless the batch is
+// ragged, its longest pair fits the specialisation and (L1 + 1) (L2 + 1) classes fit the histogram:
+//   class_hist_kernel     pairs per class c = l1 (L2 + 1) + l2
+//   class_plan_kernel     one workgroup: the classes' first entries (the scatter's cursors), the list of non-empty classes {l1, l2,
+//                         first entry, entries}, the class each of the CLS_SHARES shares of the entries starts in; the verdict --
+//                         flag[0] = 2 -- only if a non-empty class holds cls_min_fill pairs on average (a batch of a million
+//                         classes stays ragged)
+//   class_scatter_kernel  a pair's entry {o1, o2 | read, safe} goes to its class's next place
+// Counting is done in LDS: a workgroup takes a contiguous stretch of the batch and keeps the counters of a WINDOW of classes -- the
+// CLS_WIN classes nearest the longest mates' lengths, 151 x 151 of them for 2 x 150 bp, all there are -- and touches a class's
+// global counter once (one atomic per pair, or per wave and class, took 3-4 ms per pass for 10 M pairs: a trimmed sample has one
+// class with most of its pairs, and same-address atomics queue up).  The scatter reserves a workgroup's places per class the same
+// way -- count in LDS, one atomic per class for the range, then places handed out in LDS.  A pair outside the window (reads far
+// shorter than the longest: rare) goes to its global counter directly.
+constexpr uint32_t CLS_WIN = 36864;        // counters a workgroup keeps: 144 KiB
+constexpr uint32_t CLS_WIN_L2 = 192;       // mate-2 lengths of the window (paired batches)
+
+__device__ __forceinline__ bool class_path_ok(const ClassifyParams &P, const uint32_t slot_cap, const uint32_t *flag, uint32_t &L1, uint32_t &L2)
+{
+  if (flag[0] != 0u) return false;
+  L1 = flag[1];
+  L2 = P.seq2 ? flag[2] : 0u;
+  const uint32_t k = P.k;
+  const uint64_t nk1 = L1 >= k ? L1 - k + 1 : 0, nk2 = L2 >= k ? L2 - k + 1 : 0;
+  const uint64_t ns = nk2 ? (((uint64_t)L1 + 7) & ~7ull) + nk2 : nk1;
+  const uint64_t groups = (((uint64_t)L1 + 7) >> 3) + (((uint64_t)L2 + 7) >> 3);
+  const bool fits = ns <= slot_cap && groups <= (slot_cap > 512u ? 128u : 64u);
+  return fits && ((uint64_t)L1 + 1) * ((uint64_t)L2 + 1) <= (uint64_t)P.cls_cap;
+}
+
+// the pair's two lengths (and offsets)
+__device__ __forceinline__ void pair_lengths(const ClassifyParams &P, const uint64_t i, uint64_t &o1, uint64_t &o2, uint32_t &l1, uint32_t &l2)
+{
+  o1 = P.off1[i];
+  l1 = (uint32_t)(P.off1[i + 1] - o1);
+  o2 = 0;
+  l2 = 0;
+  if (P.seq2) { o2 = P.off2[i]; l2 = (uint32_t)(P.off2[i + 1] - o2); }
+}
+
+// the window of classes a workgroup counts in LDS: lengths (b1 .. L1) x (b2 .. L2)
+struct ClassWindow {
+  uint32_t W, w1, w2, b1, b2;
+  __device__ ClassWindow(const uint32_t L1, const uint32_t L2)
+  {
+    W = L2 + 1u;
+    w2 = W < CLS_WIN_L2 ? W : CLS_WIN_L2;
+    const uint32_t room = CLS_WIN / w2;
+    w1 = L1 + 1u < room ? L1 + 1u : room;
+    b1 = L1 + 1u - w1;
+    b2 = L2 + 1u - w2;
+  }
+  __device__ uint32_t size() const { return w1 * w2; }
+  __device__ bool holds(const uint32_t l1, const uint32_t l2) const { return l1 >= b1 && l2 >= b2; }
+  __device__ uint32_t local(const uint32_t l1, const uint32_t l2) const { return (l1 - b1) * w2 + (l2 - b2); }
+  __device__ uint32_t global_of(const uint32_t j) const { const uint32_t r = j / w2; return (r + b1) * W + (j - r * w2 + b2); }
+};
+
+__global__ __launch_bounds__(1024) void class_hist_kernel(const ClassifyParams P, uint32_t slot_cap, const uint32_t *__restrict__ flag, uint32_t *__restrict__ hist)
+{
+  uint32_t L1, L2;
+  if (!class_path_ok(P, slot_cap, flag, L1, L2)) return;
+  __shared__ uint32_t lh[CLS_WIN];
+  const ClassWindow win(L1, L2);
+  const uint32_t nw = win.size();
+  for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) lh[j] = 0u;
+  __syncthreads();
+  const uint64_t n = P.n, per = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    uint64_t o1, o2;
+    uint32_t l1, l2;
+    pair_lengths(P, i, o1, o2, l1, l2);
+    if (win.holds(l1, l2)) atomicAdd(&lh[win.local(l1, l2)], 1u);
+    else atomicAdd(&hist[l1 * win.W + l2], 1u);
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) {
+    const uint32_t v = lh[j];
+    if (v) atomicAdd(&hist[win.global_of(j)], v);
+  }
+}
+
+__global__ __launch_bounds__(1024) void class_plan_kernel(const ClassifyParams P, uint32_t slot_cap, uint32_t *__restrict__ flag, const uint32_t *__restrict__ hist,
+                                                          uint32_t *__restrict__ cursor, uint4 *__restrict__ list, uint32_t *__restrict__ share_first)
+{
+  uint32_t L1, L2;
+  if (!class_path_ok(P, slot_cap, flag, L1, L2)) return;
+  const uint32_t classes = (L1 + 1u) * (L2 + 1u), W = L2 + 1u;
+  // (the counts are walked twice by single threads: from LDS when they fit)
+  __shared__ uint32_t lh[CLS_WIN];
+  const bool staged = classes <= CLS_WIN;
+  if (staged) {
+    for (uint32_t c = threadIdx.x; c < classes; c += blockDim.x) lh[c] = hist[c];
+    __syncthreads();
+  }
+  auto pairs_of = [&](const uint32_t c) -> uint32_t { return staged ? lh[c] : hist[c]; };
+  const uint32_t per = (classes + blockDim.x - 1u) / blockDim.x;
+  const uint32_t c_lo = threadIdx.x * per < classes ? threadIdx.x * per : classes, c_hi = c_lo + per < classes ? c_lo + per : classes;
+  uint32_t sum_n = 0, sum_c = 0;
+  for (uint32_t c = c_lo; c < c_hi; ++c) {
+    const uint32_t h = pairs_of(c);
+    sum_n += h;
+    sum_c += h ? 1u : 0u;
+  }
+  // exclusive scan of (sum_n, sum_c) over the workgroup: within the wave by shuffles, the 16 wave totals by every thread
+  __shared__ uint32_t wave_n[16], wave_c[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc_n = sum_n, inc_c = sum_c;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t a = (uint32_t)__shfl_up((int)inc_n, d), b = (uint32_t)__shfl_up((int)inc_c, d);
+    if (lane >= d) { inc_n += a; inc_c += b; }
+  }
+  if (lane == 63) { wave_n[wave] = inc_n; wave_c[wave] = inc_c; }
+  __syncthreads();
+  uint32_t run_n = inc_n - sum_n, run_c = inc_c - sum_c, tot_n = 0, tot_c = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) { run_n += wave_n[w]; run_c += wave_c[w]; }
+    tot_n += wave_n[w];
+    tot_c += wave_c[w];
+  }
+  // (tot_n == n: every pair of a batch whose longest pair fits has a class)
+  if ((uint64_t)tot_n != P.n || (uint64_t)tot_c * P.cls_min_fill > P.n) return;
+  // the cursors, the list of non-empty classes, and the class every share of the list of entries starts in
+  const uint32_t share_len = (uint32_t)((P.n + CLS_SHARES - 1u) / CLS_SHARES);
+  for (uint32_t c = c_lo; c < c_hi; ++c) {
+    const uint32_t h = pairs_of(c);
+    cursor[c] = run_n;
+    if (h) {
+      const uint32_t l1 = c / W;
+      list[run_c++] = make_uint4(l1, c - l1 * W, run_n, h);
+    }
+    run_n += h;
+  }
+  __threadfence();
+  __syncthreads();
+  // (by search, every thread a few shares: a trimmed sample's untouched pairs are one class that two thirds of the shares start in)
+  for (uint32_t sh = threadIdx.x; sh < CLS_SHARES && (uint64_t)sh * share_len < P.n; sh += blockDim.x) {
+    const uint32_t e = sh * share_len;
+    uint32_t lo = 0, hi = tot_c;                    // the last class that starts at or before entry e
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (list[mid].z <= e) lo = mid; else hi = mid;
+    }
+    share_first[sh] = lo;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) flag[0] = 2u;
+}
+
+__global__ __launch_bounds__(1024) void class_scatter_kernel(const ClassifyParams P, const uint32_t *__restrict__ flag, uint32_t *__restrict__ cursor,
+                                                             uint4 *__restrict__ entries)
+{
+  if (flag[0] != 2u) return;
+  __shared__ uint32_t lh[CLS_WIN];
+  const ClassWindow win(flag[1], P.seq2 ? flag[2] : 0u);
+  const uint32_t nw = win.size();
+  for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) lh[j] = 0u;
+  __syncthreads();
+  const uint64_t n = P.n, per = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  const uint64_t end1 = P.off1[n], end2 = P.seq2 ? P.off2[n] : ~0ull;
+  // the stretch's pairs per class; its places per class, reserved with one atomic each; the places handed out
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    uint64_t o1, o2;
+    uint32_t l1, l2;
+    pair_lengths(P, i, o1, o2, l1, l2);
+    if (win.holds(l1, l2)) atomicAdd(&lh[win.local(l1, l2)], 1u);
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) {
+    const uint32_t v = lh[j];
+    if (v) lh[j] = atomicAdd(&cursor[win.global_of(j)], v);
+  }
+  __syncthreads();
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    uint64_t o1, o2;
+    uint32_t l1, l2;
+    pair_lengths(P, i, o1, o2, l1, l2);
+    const uint32_t e = win.holds(l1, l2) ? atomicAdd(&lh[win.local(l1, l2)], 1u) : atomicAdd(&cursor[l1 * win.W + l2], 1u);
+    // (.y of the second half: every 8-base group of the class's layout, and the 11 bytes behind its first, lie inside the buffers --
+    //  three unconditional aligned dwords per group then, see classify_uni_kernel's fetch_groups)
+    entries[2ull * e] = make_uint4((uint32_t)o1, (uint32_t)(o1 >> 32), (uint32_t)o2, (uint32_t)(o2 >> 32));
+    entries[2ull * e + 1ull] = make_uint4((uint32_t)i, (o1 + l1 + 16u <= end1 && o2 + l2 + 16u <= end2) ? 1u : 0u, 0u, 0u);
   }
 }
 
@@ -895,19 +1104,22 @@ bool uni_kernel_available(const Ctx *ctx)
 }
 
 // classify_uni_kernel lives in classify_uni.hpp, instantiated per unroll in classify_uni_u<U>.hip
-void launch_uni_u2(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
-void launch_uni_u3(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
-void launch_uni_u4(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
-void launch_uni_u5(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
-void launch_uni_u6(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
-void launch_uni_u8(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
-void launch_uni_u10(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s);
+void launch_uni_u2(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
+void launch_uni_u3(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
+void launch_uni_u4(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
+void launch_uni_u5(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
+void launch_uni_u6(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
+void launch_uni_u8(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
+void launch_uni_u10(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
 
 // the table kernel (every index with a position table), for uniform batches (`uni`) or ragged ones; with p.uni_flag set each
 // of the two launches decides on the device whether it is the one that runs
-int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots, bool uni, hipStream_t stream)
+// rmode: 0 = the ragged instantiation, 1 = the uniform one, 2 = class by class (a batch of mixed lengths sorted by them; exists where the
+// exact table is held in LDS: class_kernel_available)
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots, int rmode, hipStream_t stream)
 {
   if (p_in.n == 0) return SHK_OK;
+  const bool uni = rmode != 0;
   ClassifyParams p = p_in;
   const bool hasq = p.hasq != 0;
   int mode = probe_mode(ctx->idx);
@@ -946,14 +1158,16 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint64_t cap = wg16 ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  if (u == 2) launch_uni_u2(p, mode, hasq, big, lx, uni, grid, stream);
-  else if (u == 3) launch_uni_u3(p, mode, hasq, big, lx, uni, grid, stream);
-  else if (u == 4) launch_uni_u4(p, mode, hasq, big, lx, uni, grid, stream);
-  else if (u == 5) launch_uni_u5(p, mode, hasq, big, lx, uni, grid, stream);
-  else if (u == 6) launch_uni_u6(p, mode, hasq, false, false, uni, grid, stream);
-  else if (u == 8) launch_uni_u8(p, mode, hasq, false, false, uni, grid, stream);
-  else launch_uni_u10(p, mode, hasq, big, lx, uni, grid, stream);
+  if (rmode == 2 && !lx) return SHK_OK;      // (no such instantiation on this index: the verdict is never "by classes" there)
+  if (u == 2) launch_uni_u2(p, mode, hasq, big, lx, rmode, grid, stream);
+  else if (u == 3) launch_uni_u3(p, mode, hasq, big, lx, rmode, grid, stream);
+  else if (u == 4) launch_uni_u4(p, mode, hasq, big, lx, rmode, grid, stream);
+  else if (u == 5) launch_uni_u5(p, mode, hasq, big, lx, rmode, grid, stream);
+  else if (u == 6) launch_uni_u6(p, mode, hasq, false, false, rmode, grid, stream);
+  else if (u == 8) launch_uni_u8(p, mode, hasq, false, false, rmode, grid, stream);
+  else launch_uni_u10(p, mode, hasq, big, lx, rmode, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
+  if (rmode == 2) return SHK_OK;             // (shk_last_kernel names the uniform / ragged launch)
   // (with p.uni_flag both instantiations are launched and one returns at once: the name says UNI = "device")
   if (uni || !p.uni_flag)
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s", u, mode, hasq ? "true" : "false",
@@ -962,11 +1176,31 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   return SHK_OK;
 }
 
+// the CLS instantiation exists where uniform batches take the exact table in LDS
+bool class_kernel_available(const Ctx *ctx, uint32_t max_slots)
+{
+  const uint32_t u = fast_kernel_unroll(max_slots);
+  return uni_kernel_available(ctx) && probe_mode(ctx->idx) == PM_LDS_TAB && ctx->idx.ltab != nullptr && (u <= 5 || u == 10);
+}
+
+int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream)
+{
+  // one workgroup per CU at most (144 KiB of LDS each), 4 096 pairs or more per workgroup
+  const uint64_t want = (p.n + 4095) / 4096;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 256 ? want : 256));
+  hipLaunchKernelGGL(class_hist_kernel, dim3(grid), dim3(1024), 0, stream, p, slot_cap, flag, p.cls_hist);
+  if (hipGetLastError() != hipSuccess) return SHK_ERR_HIP;
+  hipLaunchKernelGGL(class_plan_kernel, dim3(1), dim3(1024), 0, stream, p, slot_cap, flag, p.cls_hist, p.cls_hist + p.cls_cap, p.cls_list, p.cls_share_first);
+  if (hipGetLastError() != hipSuccess) return SHK_ERR_HIP;
+  hipLaunchKernelGGL(class_scatter_kernel, dim3(grid), dim3(1024), 0, stream, p, flag, p.cls_hist + p.cls_cap, p.cls_entries);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream)
 {
-  if (hipMemsetAsync(flag, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return SHK_ERR_HIP;
+  if (hipMemsetAsync(flag, 0, UNI_FLAG_WORDS * sizeof(uint32_t), stream) != hipSuccess) return SHK_ERR_HIP;
   const uint64_t want = (p.n + 255) / 256;
-  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 2048 ? want : 2048))), dim3(256), 0, stream, p, slot_cap, flag);
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024))), dim3(256), 0, stream, p, slot_cap, flag);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

@@ -168,9 +168,17 @@ struct UniGeom {
 // offsets prefetched two reads ahead, bases one read ahead, as classify_fast_kernel does it -- but the structure is this
 // kernel's: straight-line miss path, the hit path behind one branch with its own parameter loads, count[] pre-zeroed.  A
 // read with more than 64 U slots or more than 64 staging groups goes to the general kernel's queue.
-template <int U, int MODE, bool HASQ, int LSL, bool UNI>
+// CLS (with UNI; exact-table instantiations): a batch of mixed lengths taken CLASS BY CLASS.  The pre-pass (class_hist_kernel /
+// class_plan_kernel / class_scatter_kernel, classify.hip) has sorted the batch's pairs by their two lengths into one list of entries
+// {o1, o2 | read, "unguarded loads are safe"}; the list is cut into CLS_SHARES equal shares, a wave takes shares, and walks the
+// classes its share runs through.  Within a class everything that depends on the lengths -- slots per mate, tail masks, the cut's
+// and the sparse round's plan, and whatever the compiler derives from them -- is a wave constant exactly as for a uniform batch;
+// a pair brings its two offsets.  (The ragged instantiation re-derives all that per read: 317 VALU + 168 scalar instructions per
+// trimmed pair against 199 + 78; 10 M pairs trimmed to 100-150 bases: 7.1 -> 4.6 ms.)
+template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false>
 __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
+  static_assert(!CLS || UNI, "CLS is a form of the uniform instantiation");
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
@@ -193,10 +201,14 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
   if (P.uni_flag) {
-    // both launches are made when only the device knows whether the batch is uniform: exactly one of them works
-    if ((P.uni_flag[0] == 1u) != UNI) return;
+    // every launch is made when only the device knows what the batch is like -- 0: ragged, 1: uniform, 2: by classes -- and exactly
+    // one of them works
+    const uint32_t verdict = P.uni_flag[0];
+    if (verdict != (CLS ? 2u : (UNI ? 1u : 0u))) return;
     L1 = P.uni_flag[1];
     L2 = P.uni_flag[2];
+  } else if (CLS) {
+    return;
   }
   L1 = __builtin_amdgcn_readfirstlane(L1);
   L2 = __builtin_amdgcn_readfirstlane(L2);
@@ -242,7 +254,28 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   [[maybe_unused]] uint64_t *const mbits = vbits + vbit_words_for(S);   // (base-by-base form of the anchored extension only) bit p: the read's base at packed position p equals the reference's under the mate's anchor
   constexpr uint32_t rcap = stage_cap_bases(S);
 
-  // ---- geometry: of every read of the batch (UNI) or of the current read ----------
+  // CLS: the wave's shares of the list of entries, and within a share the classes it runs through -- one "segment" (entries
+  // [ent_first, ent_end) of class cls_j) per pass of this loop; else one pass over the batch
+  const uint32_t n_waves = gridDim.x * WAVES;
+  const uint32_t share_len = CLS ? (uint32_t)((P.n + CLS_SHARES - 1u) / CLS_SHARES) : 0u;
+  uint32_t share = blockIdx.x * WAVES + wave, share_end = 0, cls_j = 0, ent_first = 0, ent_end = 0;
+  if (CLS) {
+    if (share >= CLS_SHARES || (uint64_t)share * share_len >= P.n) return;
+    ent_end = share * share_len;        // (where the first segment starts)
+    share_end = (uint64_t)ent_end + share_len < P.n ? ent_end + share_len : (uint32_t)P.n;
+    cls_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.cls_share_first[share]);
+  }
+  for (;;) {
+  if (CLS) {
+    const uint4 cd = P.cls_list[cls_j];       // {l1, l2, first entry, entries}
+    L1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.x);
+    L2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cd.y);
+    const uint32_t cls_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cd.z + cd.w));
+    ent_first = ent_end;
+    ent_end = cls_end < share_end ? cls_end : share_end;
+  }
+
+  // ---- geometry: of every read of the batch (UNI), of the unit's class (CLS) or of the current read ----------
   const uint32_t k = P.k;
   uint32_t nk1, nk2, P2, g2, n_groups;
   uint32_t tail_inv[G], Lm[G], bofs[G];
@@ -368,7 +401,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     qbase[g] = HASQ ? (m2[g] ? P.qual2 : P.qual1) + bofs[g] : nullptr;
   }
   // the unguarded loads read up to 11 bytes behind a group's first byte: fine while that stays inside the mate's buffer
-  const uint32_t n32 = (uint32_t)P.n, stride = gridDim.x * WAVES;
+  const uint32_t n32 = CLS ? ent_end : (uint32_t)P.n, stride = CLS ? 1u : gridDim.x * WAVES;
   const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
   const uint32_t guard_reads = Lmin >= 12u ? 1u : (Lmin ? (12u + Lmin - 1u) / Lmin : n32);   // trailing reads with guarded loads
 
@@ -416,10 +449,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   };
   // (ragged batches) the 8 bases a lane stages of the read at offsets m.o1 / m.o2, by the batch's layout; guarded: only dwords that
   // hold bytes of the mate are touched
-  auto fetch_groups = [&](const ReadMeta &m, Raw8 (&w)[G], Raw8 (&q)[G]) {
+  auto fetch_groups = [&](const ReadMeta &m, Raw8 (&w)[G], Raw8 (&q)[G], const bool entry_safe = false) {
+    const bool safe = CLS ? entry_safe : (m.o1 + L1 + 16u <= end1 && m.o2 + L2 + 16u <= end2);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (!FIXLAY) {   // the read's own layout (table modes)
+      if (!FIXLAY && !CLS) {   // the read's own layout (table modes)
         fetch_group<HASQ>(P, m, (uint32_t)lane + 64u * g, w[g], q[g]);
         continue;
       }
@@ -430,7 +464,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       // (wave-uniform) every group of the layout, and the 11 bytes behind its first, lie inside the mates' buffers: three unconditional
       // aligned dwords per group, as for uniform batches (bytes behind the read's own end are its neighbour's, masked by tail_inv);
       // only the last reads of the batch take the guarded loads
-      if (m.o1 + L1 + 16u <= end1 && m.o2 + L2 + 16u <= end2) {
+      if (safe) {
         if (act[g]) {
           w[g] = load8_issue_all(sbase[g] + o, 8u);
           if (HASQ) q[g] = load8_issue_all(qbase[g] + o, 8u);
@@ -453,10 +487,34 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     return c;
   };
 
-  uint32_t read = blockIdx.x * WAVES + wave;
-  if (read >= n32) return;
+  uint32_t it = CLS ? ent_first : blockIdx.x * WAVES + wave;   // position in the batch (CLS: in the list of entries)
+  if (!CLS && it >= n32) return;
+  uint32_t read = it;                                          // the read's index in the batch: where its result goes
   Raw8 w_cur[G], q_cur[G];
   ReadMeta m_cur{}, m_nxt{};
+  // CLS: 64 entries of the segment at a time, one per lane in six registers; a read's own offsets by v_readlane where its bases are
+  // fetched -- one load per 64 reads, and no scalars of two reads held across the loop body
+  uint4 ent_a = make_uint4(0u, 0u, 0u, 0u);
+  uint2 ent_b = make_uint2(0u, 0u);
+  uint32_t read_nxt = 0;
+  // (fetches the bases of entry e, leaves its read's index in read_nxt)
+  auto entry_fetch = [&](const uint32_t e, Raw8 (&w)[G], Raw8 (&q)[G]) {
+    const int l = (int)((e - ent_first) & 63u);
+    if (l == 0) {
+      const uint32_t mine = e + (uint32_t)lane;
+      if (mine < ent_end) {
+        ent_a = P.cls_entries[2ull * mine];
+        ent_b = *reinterpret_cast<const uint2 *>(P.cls_entries + 2ull * mine + 1ull);
+      }
+    }
+    ReadMeta m;
+    m.o1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ent_a.y, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ent_a.x, l);
+    m.o2 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ent_a.w, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ent_a.z, l);
+    m.L1 = L1;
+    m.L2 = L2;
+    read_nxt = (uint32_t)__builtin_amdgcn_readlane((int)ent_b.x, l);
+    fetch_groups(m, w, q, __builtin_amdgcn_readlane((int)ent_b.y, l) != 0);
+  };
   // (ragged batches) a read's plan -- which rounds first, the bounds behind them, the sparse order -- depends on its two lengths alone.
   // Computing it per read is about 150 scalar instructions, and the CU's one scalar unit serves all its waves (measured: 7.9 ms per
   // 10 M trimmed pairs against 4.2 ms untrimmed, nearly all of it scalar); so the launch carries a table indexed by (l1, l2), cleared
@@ -468,7 +526,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   auto plan_index = [&](const ReadMeta &m) -> uint32_t { return (m.L1 <= L1 && m.L2 <= L2) ? m.L1 * (L2 + 1u) + m.L2 : 0u; };
   auto plan_issue = [&](const ReadMeta &m) -> uint4 { return has_plans ? P.plan_tab[plan_index(m)] : make_uint4(0u, 0u, 0u, 0u); };
   uint4 pl_cur = make_uint4(0u, 0u, 0u, 0u);
-  if (UNI) {
+  if (CLS) {
+    entry_fetch(it, w_cur, q_cur);
+    read = read_nxt;
+  } else if (UNI) {
     issue(read, w_cur, q_cur);
   } else {
     m_cur = fetch_meta(P, read);
@@ -480,7 +541,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   retire(w_cur, q_cur);
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
   for (;;) {
-    const uint32_t nxt = n32 - read > stride ? read + stride : n32;   // saturates at n32
+    const uint32_t nxt = n32 - it > stride ? it + stride : n32;   // saturates at n32
     const bool have_nxt = nxt < n32;
     Raw8 w_nxt[G], q_nxt[G];
 #pragma unroll
@@ -488,7 +549,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     ReadMetaRaw r_nn{};
     uint32_t nn = n32;
     uint4 pl_nxt = make_uint4(0u, 0u, 0u, 0u);
-    if (UNI) {
+    if (CLS) {
+      if (have_nxt) entry_fetch(nxt, w_nxt, q_nxt);
+    } else if (UNI) {
       if (have_nxt) issue(nxt, w_nxt, q_nxt);
     } else {
       if (have_nxt) { fetch_groups(m_nxt, w_nxt, q_nxt); pl_nxt = plan_issue(m_nxt); }
@@ -1530,15 +1593,39 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       m_nxt = meta_finish(r_nn);
       pl_cur = pl_nxt;
     }
-    read = nxt;
+    it = nxt;
+    read = CLS ? read_nxt : it;
 #pragma unroll
     for (int g = 0; g < G; ++g) { w_cur[g] = w_nxt[g]; q_cur[g] = q_nxt[g]; }
   }
+  if (!CLS) break;
+  // the next class of the share, or the wave's next share
+  if (ent_end < share_end) {
+    ++cls_j;
+  } else {
+    share += n_waves;
+    if (share >= CLS_SHARES || (uint64_t)share * share_len >= P.n) break;
+    ent_end = share * share_len;
+    share_end = (uint64_t)ent_end + share_len < P.n ? ent_end + share_len : (uint32_t)P.n;
+    cls_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.cls_share_first[share]);
+  }
+  }   // segments
 }
 
+// rmode: 0 = the ragged instantiation, 1 = the uniform one, 2 = by classes (CLS: exact-table instantiations only)
 template <int U>
-static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s)
+static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s)
 {
+  if (rmode == 2) {
+    if constexpr (U <= 5 || U == 10) {
+      if (lx && mode == PM_LDS_TAB) {
+        if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, true, 21, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+        else hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+      }
+    }
+    return;
+  }
+  const bool uni = rmode == 1;
 #define LU4(M_, L_, HQ_, UN_) hipLaunchKernelGGL((classify_uni_kernel<U, M_, HQ_, L_, UN_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p)
 #define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
                         else if (L_ != 20) { if (hasq) LU4(M_, L_, true, false); else LU4(M_, L_, false, false); } } while (0)

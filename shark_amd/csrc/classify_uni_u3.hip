@@ -2,8 +2,8 @@
 #include "classify_uni.hpp"
 
 namespace shk {
-void launch_uni_u3(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, bool uni, unsigned grid, hipStream_t s)
+void launch_uni_u3(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s)
 {
-  launch_uni_u<3>(p, mode, hasq, big, lx, uni, grid, s);
+  launch_uni_u<3>(p, mode, hasq, big, lx, rmode, grid, s);
 }
 }  // namespace shk

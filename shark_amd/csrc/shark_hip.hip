@@ -96,7 +96,7 @@ static int slot_init(Ctx *ctx, Slot &s)
 {
   SHK_HIP(ctx, hipMalloc((void **)&s.d_counters, CTR_WORDS * sizeof(uint32_t)));
   SHK_HIP(ctx, hipMalloc((void **)&s.d_out, sizeof(ClassifyOut)));
-  SHK_HIP(ctx, hipMalloc((void **)&s.d_uni_flag, 8 * sizeof(uint32_t)));
+  SHK_HIP(ctx, hipMalloc((void **)&s.d_uni_flag, UNI_FLAG_WORDS * sizeof(uint32_t)));
   SHK_HIP(ctx, hipHostMalloc((void **)&s.h_counters, CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
   SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -108,7 +108,7 @@ static void slot_free(Slot &s)
 {
   hipFree(s.d_seq1); hipFree(s.d_seq2); hipFree(s.d_qual1); hipFree(s.d_qual2); hipFree(s.d_off1); hipFree(s.d_off2);
   hipFree(s.d_count); hipFree(s.d_inl); hipFree(s.d_gene_off); hipFree(s.d_gene_ids);
-  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_uni_flag); hipFree(s.d_plan);
+  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_uni_flag); hipFree(s.d_plan); hipFree(s.d_cls_entries); hipFree(s.d_cls_list); hipFree(s.d_cls_share); hipFree(s.d_cls_hist);
   if (s.h_counters) (void)hipHostFree(s.h_counters);
   if (s.h_gene_off) (void)hipHostFree(s.h_gene_off);
   if (s.h_gene_ids) (void)hipHostFree(s.h_gene_ids);
@@ -278,33 +278,41 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   // an index with a position table: classify_uni_kernel, uniform or not -- unless the batch is known to hold reads of more
   // than 64 staging groups (> 512 bases per pair), which only classify_fast_kernel stages without the general kernel's help
   const bool table_kernel = uni_kernel_available(ctx) && n != 0 && groups_fit;
+  // a batch of mixed lengths on an index whose uniform batches take the exact table in LDS: sorted by the pairs' two lengths on
+  // the device and classified class by class (classify_uni_kernel's CLS instantiation) -- when the classes are few enough for
+  // the histogram (the caller's bound on the read length says) and, the device decides, full enough; also when the host knows
+  // the batch is ragged: it has not counted
+  const uint64_t classes = (table_kernel && uni_L1) ? ((uint64_t)uni_L1 + 1) * ((uint64_t)(b->seq2 ? uni_L2 : 0) + 1) : 0;
+  const bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && classes != 0 && classes <= (1ull << 20) &&
+                          n < (1ull << 31) && ctx->env_cls_min_fill != 0;
+  // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
+  // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
+  const bool with_plans = table_kernel && uni_mode != UNI_YES && classes != 0 && classes <= (1ull << 20);
+  if (by_classes) {
+    if ((rc = ensure_capacity(ctx, &s.d_cls_entries, &s.cap_cls_entries, (size_t)(2 * n)))) return rc;
+    if ((rc = ensure_capacity(ctx, &s.d_cls_list, &s.cap_cls_list, (size_t)classes))) return rc;
+    if ((rc = ensure_capacity(ctx, &s.d_cls_hist, &s.cap_cls_hist, (size_t)(2 * classes)))) return rc;
+    if (!s.d_cls_share) SHK_HIP(ctx, hipMalloc((void **)&s.d_cls_share, CLS_SHARES * sizeof(uint32_t)));
+    s.p.cls_entries = s.d_cls_entries;
+    s.p.cls_list = s.d_cls_list;
+    s.p.cls_share_first = s.d_cls_share;
+    s.p.cls_hist = s.d_cls_hist;
+    s.p.cls_cap = (uint32_t)classes;
+    s.p.cls_min_fill = ctx->env_cls_min_fill;
+  }
+  if (with_plans) {
+    if ((rc = ensure_capacity(ctx, &s.d_plan, &s.cap_plan, (size_t)classes))) return rc;
+    s.p.plan_tab = s.d_plan;
+    s.p.plan_cap = (uint32_t)classes;
+  }
   if (!table_kernel) {
     uni_mode = UNI_NO;
     SHK_HIP(ctx, hipMemsetAsync(s.d_count + n, 0, sizeof(uint32_t), st));
   } else {
     // classify_uni_kernel writes count[] only for reads with associations
     SHK_HIP(ctx, hipMemsetAsync(s.d_count, 0, (n + 1) * sizeof(uint32_t), st));
-    if (uni_mode == UNI_ASK_DEVICE) {
-      if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
-      s.p.uni_flag = s.d_uni_flag;
-    } else {
-      // the one length per mate (UNI_YES), or the longest mates: the ragged instantiation stages the batch in their layout
-      s.p.uni_L1 = uni_L1;
-      s.p.uni_L2 = uni_L2;
-    }
-    if (uni_mode != UNI_YES) {
-      // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
-      // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
-      const uint64_t entries = uni_L1 ? ((uint64_t)uni_L1 + 1) * ((uint64_t)(b->seq2 ? uni_L2 : 0) + 1) : 0;
-      if (entries && entries <= (1ull << 20)) {
-        if ((rc = ensure_capacity(ctx, &s.d_plan, &s.cap_plan, (size_t)entries))) return rc;
-        SHK_HIP(ctx, hipMemsetAsync(s.d_plan, 0, entries * sizeof(uint4), st));
-        s.p.plan_tab = s.d_plan;
-        s.p.plan_cap = (uint32_t)entries;
-      }
-    }
   }
-
+  // timed: the classify launches and, for a batch the device has to look at first, the passes over its offsets
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
     if (ctx->ev_used == ctx->ev_start.size()) {
@@ -319,6 +327,23 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     ctx->ev_used++;
     SHK_HIP(ctx, hipEventRecord(e0, st));
   }
+  if (table_kernel) {
+    if (by_classes) {
+      uni_mode = UNI_ASK_DEVICE;
+      SHK_HIP(ctx, hipMemsetAsync(s.d_cls_hist, 0, classes * sizeof(uint32_t), st));
+    }
+    if (uni_mode == UNI_ASK_DEVICE) {
+      if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
+      if (by_classes && (rc = launch_class_prepass(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
+      s.p.uni_flag = s.d_uni_flag;
+    } else {
+      // the one length per mate (UNI_YES), or the longest mates: the ragged instantiation stages the batch in their layout
+      s.p.uni_L1 = uni_L1;
+      s.p.uni_L2 = uni_L2;
+    }
+    if (with_plans) SHK_HIP(ctx, hipMemsetAsync(s.d_plan, 0, classes * sizeof(uint4), st));
+  }
+
   // the timed launch is the one that does the work: the uniform kernel when the host knows it applies (or has to ask
   // the device: then the generic kernel is launched behind it and returns at once for a uniform batch)
   if (ctx->idx.wrap) {
@@ -338,8 +363,9 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
       if ((rc = launch_classify_fast(ctx, s.p, max_slots, st))) return rc;           // bit-vector probe chains
     } else {
       // what the host knows decides the launch; when only the device knows, both are made and one returns at once
-      if (uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, true, st))) return rc;
-      if (uni_mode != UNI_YES && (rc = launch_classify_uni(ctx, s.p, max_slots, false, st))) return rc;
+      if (uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, 1, st))) return rc;
+      if (by_classes && (rc = launch_classify_uni(ctx, s.p, max_slots, 2, st))) return rc;
+      if (uni_mode != UNI_YES && (rc = launch_classify_uni(ctx, s.p, max_slots, 0, st))) return rc;
     }
   }
   if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
@@ -550,6 +576,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     const char *e = getenv("SHK_FORCE_GENERIC");
     ctx->env_force_generic = e && e[0] == '1';
     ctx->env_big_lds_always = getenv("SHK_BIG_LDS_ALWAYS") != nullptr;
+    if (const char *f = getenv("SHK_CLS_MIN_FILL")) ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10);
   }
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };
 #define CR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP); } while (0)

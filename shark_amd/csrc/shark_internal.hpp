@@ -156,6 +156,16 @@ struct ClassifyParams {
   // cleared by the host and filled by the kernel itself (classify_uni.hpp); nullptr / 0 = every read computes its plan
   uint4 *plan_tab;
   uint32_t plan_cap;               // entries
+  // batches taken class by class (uni_flag[0] == 2; classify_uni_kernel's CLS instantiation): the pairs sorted by their two lengths,
+  // 2 x uint4 per entry {o1, o2 | read index, "unguarded loads are safe", -, -}; cls_list: the non-empty classes in that order
+  // {l1, l2, first entry, entries}; cls_share_first[s]: the class that entry s * ceil(n / CLS_SHARES) belongs to;
+  // cls_hist: 2 x cls_cap words (pairs per class | the scatter's cursors)
+  uint4 *cls_entries;
+  uint4 *cls_list;
+  uint32_t *cls_share_first;
+  uint32_t *cls_hist;
+  uint32_t cls_cap;                // classes the histogram holds: a batch with (L1 + 1) (L2 + 1) beyond that stays ragged
+  uint32_t cls_min_fill;           // pairs per non-empty class the batch needs on average
   // per-read results and queues (device copy of ClassifyOut)
   const ClassifyOut *out;
   unsigned long long *gene_counts;  // 65536 (general kernel, EMIT mode)
@@ -190,6 +200,10 @@ enum {
   CTR_WORDS = 8
 };
 
+constexpr uint32_t UNI_FLAG_WORDS = 16;
+constexpr uint32_t CLS_SHARES = 4096;     // equal shares of a sorted batch: one per wave of the exact-table kernels' grid
+constexpr uint32_t CLS_MIN_FILL = 16;     // by classes only if a non-empty class holds that many pairs on average
+
 // ---- one batch in flight ---------------------------------------------------------------------
 constexpr int PIPE_DEPTH = 3;      // batches shk_classify_submit keeps in flight per context
 
@@ -206,8 +220,13 @@ struct Slot {
   uint32_t *d_long_queue = nullptr; size_t cap_long_queue = 0;
   uint32_t *d_tie_queue = nullptr;  size_t cap_tie_queue = 0;
   uint32_t *d_counters = nullptr;
-  uint32_t *d_uni_flag = nullptr;  // 8 words: verdict of uniform_check_kernel
+  uint32_t *d_uni_flag = nullptr;  // UNI_FLAG_WORDS words: verdict of uniform_check_kernel / class_plan_kernel (0 ragged, 1 uniform, 2 by classes), lengths, scratch
   uint4 *d_plan = nullptr; size_t cap_plan = 0;   // read plans of a ragged batch (ClassifyParams::plan_tab)
+  // a batch taken class by class (ClassifyParams::cls_*)
+  uint4 *d_cls_entries = nullptr; size_t cap_cls_entries = 0;
+  uint4 *d_cls_list = nullptr;    size_t cap_cls_list = 0;
+  uint32_t *d_cls_share = nullptr;
+  uint32_t *d_cls_hist = nullptr; size_t cap_cls_hist = 0;
   uint64_t *d_scan_temp = nullptr; size_t cap_scan_temp = 0;
   ClassifyOut *d_out = nullptr;
   ClassifyOut out_shadow{};        // what *d_out holds (rewritten only when a buffer moved)
@@ -241,7 +260,9 @@ int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool sk
 int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
 int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
                            const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, hipStream_t stream);
-int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, bool uni, hipStream_t stream);
+int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, int rmode, hipStream_t stream);   // 0 ragged, 1 uniform, 2 by classes (CLS)
+int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);   // behind launch_uniform_check: histogram, plan, scatter
+bool class_kernel_available(const Ctx *ctx, uint32_t max_slots);
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);
 bool uni_kernel_available(const Ctx *ctx);
 uint32_t fast_kernel_max_slots();
@@ -281,6 +302,7 @@ struct Ctx {
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
   bool env_force_generic = false, env_big_lds_always = false;
+  uint32_t env_cls_min_fill = CLS_MIN_FILL;   // SHK_CLS_MIN_FILL: pairs per non-empty class a batch needs to go class by class (0: never; tests: 1)
   // which classify kernel the last batch's main launch was (shk_last_kernel): the choice can depend on the batch before it
   char last_kernel[96] = "";
 

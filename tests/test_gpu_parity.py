@@ -918,6 +918,56 @@ def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
     h.close()
 
 
+@pytest.mark.parametrize("n_genes,k,q,fill,L", [(1, 17, 0, 1, 150), (1, 21, 20, 1, 150), (1, 17, 0, 16, 150), (1, 17, 0, 1, 300), (1, 17, 20, 4, 90), (6, 17, 0, 1, 150)])
+def test_trimmed_batches_go_class_by_class(oracle, monkeypatch, n_genes, k, q, fill, L):
+    """trimmed samples: a share of the mates is shorter than the rest.  On an index whose uniform batches take the exact table in
+    LDS the device sorts such a batch by the pairs' two lengths (class_hist / class_plan / class_scatter kernels) and the CLS
+    instantiation classifies it class by class, in the uniform layout of each class -- if the classes are full enough
+    (SHK_CLS_MIN_FILL pairs per unit: 1 here, so that every shape below takes that path, and the default 16, where most of these
+    small batches stay with the ragged instantiation).  1 %, 20 %, 50 %, 80 % and 100 % trimmed mates (either mate, both, down to
+    shorter than k), paired and single-end, host batches and batches resident in HBM, one gene (sparse first round) and several
+    genes (no CLS instantiation there: the LDS-summary ragged kernel), 2 x 90, 2 x 150 and 2 x 300 bp (the last: more classes than the
+    pre-pass counts in LDS, the shortest mates take the global counters): the oracle's associations every time."""
+    monkeypatch.setenv("SHK_CLS_MIN_FILL", str(fill))
+    from shark_amd.capi import hip_memcpy_dtoh
+    rng = np.random.default_rng(4242 + n_genes + k)
+    genes = synth.make_genes(rng, n_genes, 2500, 2600)
+    o, h, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, min_quality=q, c=0.5)
+    assert h.probe_mode() == "lds-table", h.probe_mode()
+    dev = torch.device("cuda:0")
+    n = 3000
+    for paired in (True, False):
+        base = synth.make_reads(rng, genes, n, read_len=L, paired=paired, on_target=0.7, qual=q > 0)
+        for frac in (0.01, 0.2, 0.5, 0.8, 1.0):
+            def trim(seq, off, qual):
+                m = [bytes(seq[int(off[i]):int(off[i + 1])]) for i in range(n)]
+                qq = [bytes(qual[int(off[i]):int(off[i + 1])]) for i in range(n)] if qual is not None else None
+                for i in range(n):
+                    if rng.random() < frac:
+                        keep = int(rng.integers(k - 3 if rng.random() < 0.05 else min(60, L // 2), L))
+                        m[i] = m[i][:keep]
+                        if qq is not None:
+                            qq[i] = qq[i][:keep]
+                return m, qq
+            a, qa = trim(base["seq1"], base["off1"], base["qual1"])
+            b, qb = trim(base["seq2"], base["off2"], base["qual2"]) if paired else (None, None)
+            bt = synth.batch_from_lists(a, b, qa, qb)
+            og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"], bt["qual1"], bt["qual2"])
+            hg, hi = h.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"], bt["qual1"], bt["qual2"])
+            assert np.array_equal(hg, og) and np.array_equal(hi, oi), ("host", paired, frac)
+            t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in bt.items()}
+            pt = {kk: (v.data_ptr() if v is not None else 0) for kk, v in t.items()}
+            torch.cuda.synchronize()
+            r = h.classify_device(n, pt["seq1"], pt["off1"], pt["seq2"], pt["off2"], pt["qual1"], pt["qual2"], max_read_len=L)
+            goff = np.empty(n + 1, np.uint32)
+            hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+            gids = np.empty(int(r.n_assoc), np.uint16)
+            hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+            assert np.array_equal(goff, og) and np.array_equal(gids, oi), ("resident", paired, frac)
+            assert int(og[-1]) > n // 4
+    h.close()
+
+
 @pytest.mark.parametrize("q", [94, 95, 100, 222, 223, 256, 300])
 def test_min_quality_wraps_like_the_reference_char(oracle, q):
     """argument_parser.hpp:144 stores -q in a `char` and FastqSplitter.hpp:70 adds 33 in a `char`: values above 94 wrap

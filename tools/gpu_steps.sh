@@ -10,8 +10,10 @@
 #   land:<args>      tools/landscape.py <args> (separated by @)         ragged:<genes>  tools/ragged_rate.py (GENES=<genes>)
 #   ab:<ot>:<lib>... bench workload at on-target <ot> on library variants (base = in-tree, else tools/variants/<lib>.so), interleaved
 #   abpy:<libs>:<script+args>  a script on several library variants (tools/variants/<lib>.so, base = in-tree; libs joined by +), interleaved
+#   kt:<script+args>  rocprofv3 --kernel-trace --stats of a python script: the classify kernels' rows
 #   pmc:<script+args> one SQ counter pass (rocprofv3 --pmc) of a python script: instructions per pair of the classify kernels
 #   py:<script+args> python3 <script> <args> (separated by @)           mem        memory / tmpfs / cpu figures of the box
+#   env:VAR=VALUE    exported for the steps behind it
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
@@ -57,6 +59,11 @@ for (k, c), v in sorted(acc.items()):
     if max(v) > 1e6: print(k, c, round(max(v) / 1e7, 1), "per pair (of 10 M)")
 PY
                  rm -rf $out/pmc_tmp ;;
+    kt:*)        # kernel trace with per-kernel statistics of a python script (rocprofv3 --kernel-trace --stats): the classify kernels' rows
+                 rm -rf $out/kt_tmp; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_tmp -- python3 $(echo "${step#kt:}" | tr '@' ' ') > $log.out 2> $log \
+                 && { f=$(find $out/kt_tmp -name "*_kernel_stats.csv" | head -1); head -1 $f >> $log.out; grep -E "classify|uniform_check|class_" $f >> $log.out; }
+                 rm -rf $out/kt_tmp ;;
+    env:*)       export "${step#env:}"; echo "exported ${step#env:}" > $log ;;   # for the steps behind it
     mem)         { nproc; free -g; df -h /dev/shm /tmp; cat /sys/fs/cgroup/memory.max /sys/fs/cgroup/cpu.max 2>/dev/null; grep -c processor /proc/cpuinfo; which rocprofv3; } > $log 2>&1 ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac

@@ -29,6 +29,8 @@ for key in ("seq1", "seq2"):
     off[1:] = torch.cumsum(L, 0)
     out["off" + key[-1]] = off
 torch.cuda.synchronize()
+# (one untimed call: buffers, code objects)
+h.classify_device(n, out["seq1"].data_ptr(), out["off1"].data_ptr(), out["seq2"].data_ptr(), out["off2"].data_ptr(), max_read_len=150)
 h.timing_enable(True)
 for _ in range(4):
     r = h.classify_device(n, out["seq1"].data_ptr(), out["off1"].data_ptr(), out["seq2"].data_ptr(), out["off2"].data_ptr(), max_read_len=150)
