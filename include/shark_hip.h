@@ -203,7 +203,11 @@ int shk_dist_info(const shk_ctx *ctx, int *rank, int *world);
  * stream.  enable=1 starts recording one event pair per launch. */
 int shk_timing_enable(shk_ctx *ctx, int enable);
 /* n_launches classify-kernel launches since enable, their summed duration,
- * and the algorithmic work counters of the LAST classify call. */
+ * and the algorithmic work counters of the LAST classify call.  prepass_ms:
+ * what ran in front of those launches for batches whose read lengths only the
+ * device sees (shk_classify_device) or that are known to be ragged -- the
+ * uniformity check over the offsets and, for batches of mixed lengths on small
+ * indices, the sort by length; 0 for batches the host knows to be uniform. */
 typedef struct shk_timing {
   uint64_t n_launches;
   double   total_ms;
@@ -211,6 +215,7 @@ typedef struct shk_timing {
   uint64_t last_n_long;      /* reads routed to the general kernel */
   uint64_t last_n_tie;       /* reads with more than SHK_INLINE_IDS genes */
   uint64_t last_n_assoc;
+  double   prepass_ms;
 } shk_timing;
 int shk_timing_get(shk_ctx *ctx, shk_timing *t);
 

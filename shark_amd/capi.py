@@ -36,7 +36,7 @@ class ShkResult(C.Structure):
 
 class ShkTiming(C.Structure):
     _fields_ = [("n_launches", C.c_uint64), ("total_ms", C.c_double), ("last_n_reads", C.c_uint64),
-                ("last_n_long", C.c_uint64), ("last_n_tie", C.c_uint64), ("last_n_assoc", C.c_uint64)]
+                ("last_n_long", C.c_uint64), ("last_n_tie", C.c_uint64), ("last_n_assoc", C.c_uint64), ("prepass_ms", C.c_double)]
 
 
 class ShkWorkCounters(C.Structure):

@@ -994,7 +994,8 @@ __global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *_
 // counters (8 words) -> host; gene_off[0..n] -> host; gene_ids[0..total) -> host (unless the batch overflowed)
 __global__ __launch_bounds__(256) void publish_results_kernel(const uint32_t *__restrict__ counters, uint32_t *__restrict__ h_counters,
                                                              const uint32_t *__restrict__ gene_off, uint32_t *__restrict__ h_gene_off, uint64_t n_off,
-                                                             const uint16_t *__restrict__ gene_ids, uint16_t *__restrict__ h_gene_ids, uint64_t h_ids_cap)
+                                                             const uint16_t *__restrict__ gene_ids, uint16_t *__restrict__ h_gene_ids, uint64_t h_ids_cap,
+                                                             const uint32_t *__restrict__ uni_flag)
 {
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
   if (h_gene_off) {
@@ -1014,7 +1015,7 @@ __global__ __launch_bounds__(256) void publish_results_kernel(const uint32_t *__
       for (uint64_t i = m8 * 8 + tid; i < m; i += nth) h_gene_ids[i] = gene_ids[i];
     }
   }
-  if (tid < CTR_WORDS) h_counters[tid] = counters[tid];
+  if (tid < CTR_WORDS) h_counters[tid] = tid == CTR_VERDICT ? (uni_flag ? 1u + uni_flag[0] : 0u) : counters[tid];
 }
 
 // off[i] = i * stride: batches whose reads all have one length need no offsets over PCIe
@@ -1250,11 +1251,11 @@ int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool sk
 }
 
 int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
-                           const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, hipStream_t stream)
+                           const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, const uint32_t *uni_flag, hipStream_t stream)
 {
   const uint64_t want = h_gene_off ? (n_off / 4 + 255) / 256 : 1;
   hipLaunchKernelGGL(publish_results_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 512 ? want : 512))), dim3(256), 0, stream, counters, h_counters,
-                     gene_off, h_gene_off, n_off, gene_ids, h_gene_ids, h_ids_cap);
+                     gene_off, h_gene_off, n_off, gene_ids, h_gene_ids, h_ids_cap, uni_flag);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

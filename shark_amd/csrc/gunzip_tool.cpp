@@ -24,6 +24,9 @@ int main(int argc, char **argv)
     if (!count_only && fwrite(d, 1, n, stdout) != n) return 1;
   }
   const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  fprintf(stderr, "shark-gunzip: %zu bytes in %.3f s (%.1f MB/s), %u threads\n", total, s, total / s / 1e6, threads);
+  double cs = 0, c1 = 0, c2 = 0;
+  z.cpu_seconds(cs, c1, c2);
+  fprintf(stderr, "shark-gunzip: %zu bytes in %.3f s (%.1f MB/s), %u threads; worker CPU s: search %.3f, pass 1 %.3f, pass 2 %.3f\n", total, s,
+          total / s / 1e6, threads, cs, c1, c2);
   return 0;
 }

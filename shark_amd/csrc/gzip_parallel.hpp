@@ -27,6 +27,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -253,6 +254,7 @@ struct Inflater {
       (void)d;
       if (!dist.build(d32, 32, 8)) return BAD;
       have_dist = true;
+      if (!text_only) build_multi();
       return OK;
     }
     in.refill();
@@ -303,7 +305,67 @@ struct Inflater {
     for (unsigned k = 0; k < hdist; ++k) nz += lens[hlit + k] != 0;
     have_dist = nz != 0;
     if (have_dist && !dist.build(lens + hlit, hdist, 8)) return BAD;
+    if (!text_only) build_multi();
     return OK;
+  }
+
+  // Runs of literals -- a FASTQ record's bases are 150 of them, at two to three bits each --: for every MULTI_BITS-bit pattern of
+  // the input, the literals it holds whole (up to four: one 8-byte store of 16-bit symbols), their count and their bits.  Built per
+  // block from the literal table (1 024 patterns, a few microseconds against the 16 384 symbols of a gzip -1 block); the fast loop
+  // of huffman_body asks it first.
+  static constexpr unsigned MULTI_BITS = 10;
+  uint64_t multi_syms[1u << MULTI_BITS];
+  uint8_t multi_info[1u << MULTI_BITS];      // count (low 3 bits) | bits << 3; 0: the pattern does not start with a whole literal
+  // ... and the two tables with what the fast loop would otherwise look up behind them folded in: an entry of a length code
+  // carries the base length and its number of extra bits, one of a distance code the base distance and its extra bits
+  //   [15:0] literal / base length / base distance (sub-table link: its index)   [19:16] code bits at this level   [20] link
+  //   [24:21] extra bits   [26:25] kind: 0 literal, 1 length (distance table: a distance), 2 end of block, 3 not a code of a valid stream
+  std::vector<uint32_t> lit_fast, dist_fast;
+  void build_fast_tables()
+  {
+    lit_fast = lit.tab;
+    for (uint32_t &e : lit_fast) {
+      if (e & (1u << 20)) continue;
+      const unsigned sym = e & 0xFFFF;
+      if (!((e >> 16) & 15) || sym < 256) continue;          // (unused slot: stays 0, "no code"; literal: as it is)
+      if (sym == 256) e = (e & 0xF0000u) | (2u << 25);
+      else if (sym > 285) e = (e & 0xF0000u) | (3u << 25);
+      else e = (e & 0xF0000u) | LEN_BASE[sym - 257] | ((uint32_t)LEN_EXTRA[sym - 257] << 21) | (1u << 25);
+    }
+    dist_fast.clear();
+    if (have_dist) {
+      dist_fast = dist.tab;
+      for (uint32_t &e : dist_fast) {
+        if (e & (1u << 20)) continue;
+        const unsigned sym = e & 0xFFFF;
+        if (!((e >> 16) & 15)) continue;
+        if (sym > 29) e = (e & 0xF0000u) | (3u << 25);
+        else e = (e & 0xF0000u) | DIST_BASE[sym] | ((uint32_t)DIST_EXTRA[sym] << 21) | (1u << 25);
+      }
+    }
+  }
+
+  void build_multi()
+  {
+    build_fast_tables();
+    const uint32_t *lt = lit.tab.data();
+    const unsigned lp = lit.primary;
+    for (unsigned idx = 0; idx < (1u << MULTI_BITS); ++idx) {
+      unsigned bits = 0, k = 0;
+      uint64_t syms = 0;
+      while (k < 4 && bits < MULTI_BITS) {
+        const unsigned rem = MULTI_BITS - bits;
+        // (fewer known bits than the table's index: an entry whose code fits into them is the same under every extension)
+        const uint32_t e = lt[(idx >> bits) & ((1u << (rem < lp ? rem : lp)) - 1)];
+        const unsigned l = (e >> 16) & 15;
+        if ((e & (1u << 20)) || !l || l > rem || (e & 0xFFFF) >= 256) break;
+        syms |= (uint64_t)(e & 0xFFFF) << (16 * k);
+        ++k;
+        bits += l;
+      }
+      multi_syms[idx] = syms;
+      multi_info[idx] = (uint8_t)(k ? (k | (bits << 3)) : 0);
+    }
   }
 
   // the body of a stored block (the header has been read)
@@ -340,7 +402,99 @@ struct Inflater {
       uint16_t *o = out.data();
       size_t w = n;
       const size_t w_stop = out.size() - 300;
-      // the inner loop: up to a few hundred symbols without capacity checks
+      // the fast loop (decoding proper, away from the end of the input): the bit buffer in locals, no bookkeeping per symbol -- the
+      // position is 8 bp - cnt at any time --, one refill (56 bits) per run of literals or per length and distance with their
+      // extra bits (48 at most).  A code the table does not know ends it with BAD as below.
+      if (!text_only && in.bp + 16 <= in.n) {
+        uint64_t buf = in.buf;
+        unsigned cnt = in.cnt;
+        size_t bp = in.bp;
+        const uint8_t *const ip = in.p;
+        const size_t bp_stop = in.n - 16;
+        const uint32_t *const ltf = lit_fast.data(), *const dtf = have_dist ? dist_fast.data() : nullptr;
+        Rc rc = OK;
+        bool ended = false;
+        while (w < w_stop && bp <= bp_stop) {
+          {
+            uint64_t x;
+            memcpy(&x, ip + bp, 8);
+            buf |= x << cnt;
+            const unsigned add = (63u - cnt) >> 3;
+            bp += add;
+            cnt += add * 8;
+          }
+          // literals first, up to four per look (five looks fit the 56 bits: up to 20 symbols per refill; the capacity margin of
+          // 300 symbols covers them and the 8-byte stores)
+          unsigned mi = multi_info[buf & ((1u << MULTI_BITS) - 1)];
+          if (mi) {
+            for (int look = 0; look < 5 && mi; ++look) {
+              memcpy(o + w, &multi_syms[buf & ((1u << MULTI_BITS) - 1)], 8);
+              w += mi & 7u;
+              buf >>= mi >> 3;
+              cnt -= mi >> 3;
+              mi = multi_info[buf & ((1u << MULTI_BITS) - 1)];
+            }
+            continue;
+          }
+          uint32_t e = ltf[buf & lmask];
+          if (__builtin_expect(e & (1u << 20), 0)) {
+            const unsigned sub = (e >> 16) & 15;
+            e = ltf[(e & 0xFFFF) + ((buf >> lp) & ((1u << sub) - 1))];
+            buf >>= lp;
+            cnt -= lp;
+          }
+          unsigned l = (e >> 16) & 15;
+          if (__builtin_expect(!l, 0)) { rc = BAD; ended = true; break; }
+          buf >>= l;
+          cnt -= l;
+          const unsigned kind = (e >> 25) & 3u;
+          if (kind == 0) {       // (a literal with a code longer than MULTI_BITS)
+            o[w++] = (uint16_t)(e & 0xFFFF);
+            continue;
+          }
+          if (__builtin_expect(kind != 1, 0)) {
+            if (kind == 3 || !dtf) rc = BAD;
+            ended = true;
+            break;
+          }
+          if (__builtin_expect(!dtf, 0)) { rc = BAD; ended = true; break; }
+          const unsigned le = (e >> 21) & 15u;
+          const unsigned len = (e & 0xFFFF) + (unsigned)(buf & ((1u << le) - 1));
+          buf >>= le;
+          cnt -= le;
+          uint32_t d = dtf[buf & dmask];
+          if (__builtin_expect(d & (1u << 20), 0)) {
+            const unsigned sub = (d >> 16) & 15;
+            d = dtf[(d & 0xFFFF) + ((buf >> dp) & ((1u << sub) - 1))];
+            buf >>= dp;
+            cnt -= dp;
+          }
+          l = (d >> 16) & 15;
+          if (__builtin_expect(!l || ((d >> 25) & 3u) != 1u, 0)) { rc = BAD; ended = true; break; }
+          buf >>= l;
+          cnt -= l;
+          const unsigned de = (d >> 21) & 15u;
+          const unsigned dd = (d & 0xFFFF) + (unsigned)(buf & ((1u << de) - 1));
+          buf >>= de;
+          cnt -= de;
+          if (__builtin_expect(dd > w - floor, 0)) { rc = BAD; ended = true; break; }
+          const uint16_t *s = o + w - dd;
+          uint16_t *t = o + w;
+          if (dd >= 8) {
+            for (unsigned i = 0; i < len; i += 8) memcpy(t + i, s + i, 16);
+          } else {
+            for (unsigned i = 0; i < len; ++i) t[i] = s[i];
+          }
+          w += len;
+        }
+        in.buf = buf;
+        in.cnt = cnt;
+        in.bp = bp;
+        in.pos = 8ull * bp - cnt;
+        if (ended) { n = w; return rc; }
+        if (w >= w_stop) { n = w; continue; }      // (more room, then on)
+      }
+      // the careful loop: the end of the input, and the block search's trial decoding
       while (w < w_stop) {
         in.refill();
         uint32_t e = lt[in.buf & lmask];
@@ -479,21 +633,33 @@ class ParallelGunzip {
     }
     cv_.notify_all();
     for (auto &t : th_) t.join();
+    for (auto &b : pool_) free(b.first);
     if (p_) munmap(const_cast<uint8_t *>(p_), n_);
     if (fd_ >= 0) ::close(fd_);
   }
   ParallelGunzip(const ParallelGunzip &) = delete;
   ParallelGunzip &operator=(const ParallelGunzip &) = delete;
   bool usable() const { return usable_; }
+  // CPU seconds the workers spent: looking for block starts, decoding (pass 1), translating symbols to bytes (pass 2)
+  void cpu_seconds(double &search, double &pass1, double &pass2) const
+  {
+    search = 1e-9 * (double)ns_search_.load();
+    pass1 = 1e-9 * (double)ns_pass1_.load();
+    pass2 = 1e-9 * (double)ns_pass2_.load();
+  }
 
   // the next piece of uncompressed text, in file order (valid until the next call); false at the end of the stream
   bool next(const char *&data, size_t &len)
   {
     for (;;) {
       std::unique_lock<std::mutex> l(m_);
-      if (handed_) {   // give the chunk handed out last time back
-        free(ch_[consume_ - 1]->bytes);
-        ch_[consume_ - 1]->bytes = nullptr;
+      if (handed_) {   // the chunk handed out last time: its buffer goes back to the pool (pages already touched)
+        Chunk &old = *ch_[consume_ - 1];
+        if (old.bytes) {
+          if (pool_.size() < threads_ + 6) pool_.push_back({old.bytes, old.cap_bytes});
+          else free(old.bytes);
+        }
+        old.bytes = nullptr;
         handed_ = false;
         cv_.notify_all();
       }
@@ -527,7 +693,7 @@ class ParallelGunzip {
     bool stream_ends = false;            // the gzip stream ends, or is corrupt, inside this chunk
     std::vector<uint8_t> window_in;      // the WIN bytes in front of the chunk's text
     char *bytes = nullptr;               // malloc'ed text of the chunk
-    size_t n_bytes = 0;
+    size_t n_bytes = 0, cap_bytes = 0;
     ~Chunk() { free(bytes); }
   };
 
@@ -555,6 +721,7 @@ class ParallelGunzip {
       if (t.n - gzp::WIN < 1024) continue;                                 // (a real block of a compressed sample is not this short)
       // a valid header must follow
       gzp::Inflater u;
+      u.text_only = true;      // (tables only)
       u.in.p = p_;
       u.in.n = n_;
       u.in.seek(t.in.pos);
@@ -591,15 +758,51 @@ class ParallelGunzip {
     cv_.notify_all();
   }
 
+  // pass 2: symbols to bytes through the table (literals map to themselves, markers to the window's bytes)
+  static void translate(const uint16_t *s, char *o, size_t total, const uint8_t *L)
+  {
+    size_t k = 0;
+    for (; k + 8 <= total; k += 8) {
+      o[k] = (char)L[s[k]]; o[k + 1] = (char)L[s[k + 1]]; o[k + 2] = (char)L[s[k + 2]]; o[k + 3] = (char)L[s[k + 3]];
+      o[k + 4] = (char)L[s[k + 4]]; o[k + 5] = (char)L[s[k + 5]]; o[k + 6] = (char)L[s[k + 6]]; o[k + 7] = (char)L[s[k + 7]];
+    }
+    for (; k < total; ++k) o[k] = (char)L[s[k]];
+  }
+  // ... 32 symbols at a time where none of them is a marker (one pack instead of 32 look-ups)
+  __attribute__((target("avx2"))) static void translate_avx2(const uint16_t *s, char *o, size_t total, const uint8_t *L)
+  {
+    size_t k = 0;
+    for (; k + 32 <= total; k += 32) {
+      const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k));
+      const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k + 16));
+      if (_mm256_testz_si256(_mm256_or_si256(a, b), _mm256_set1_epi16((short)0xFF00))) {
+        const __m256i p = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(o + k), p);
+      } else {
+        for (size_t j = k; j < k + 32; ++j) o[j] = (char)L[s[j]];
+      }
+    }
+    for (; k < total; ++k) o[k] = (char)L[s[k]];
+  }
+
+  static uint64_t thread_ns()
+  {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+  }
+
   void run_chunk(size_t i, gzp::Inflater &z, gzp::Inflater &t)
   {
     Chunk &c = *ch_[i];
+    uint64_t t0 = thread_ns();
     // 1. where it starts
     if (i > 0) {
       uint64_t bit = 0;
       const bool found = find_block(t, i * CHUNK, std::min(n_, (i + 1) * CHUNK), bit);
       c.start_bit = bit;
       c.start_known.store(found ? 1 : -1, std::memory_order_release);
+      ns_search_ += thread_ns() - t0;
       {
         std::lock_guard<std::mutex> l(m_);
         cv_.notify_all();
@@ -614,6 +817,7 @@ class ParallelGunzip {
       }
     }
     // 2. pass 1: symbols, up to the start of the next chunk that has one
+    t0 = thread_ns();
     z.in.p = p_;
     z.in.n = n_;
     z.in.seek(c.start_bit);
@@ -657,6 +861,7 @@ class ParallelGunzip {
         z.floor = z.n;
       }
     }
+    ns_pass1_ += thread_ns() - t0;
     // 3. the window in front of this chunk's text (the chunk in front of it publishes it)
     if (!c.clean_start) {
       std::unique_lock<std::mutex> l(m_);
@@ -665,6 +870,7 @@ class ParallelGunzip {
       if (c.absorbed) { c.done = true; cv_.notify_all(); return; }   // (the chunk in front went through this territory itself)
     }
     // 4. translation table: literals + window; then the window for the next chunk, then this chunk's bytes
+    t0 = thread_ns();
     std::vector<uint8_t> lut(65536, 0);
     for (unsigned s = 0; s < 256; ++s) lut[s] = (uint8_t)s;
     if (!c.clean_start) memcpy(lut.data() + 0x8000, c.window_in.data(), gzp::WIN);
@@ -680,21 +886,31 @@ class ParallelGunzip {
       d.have_window = true;
       cv_.notify_all();
     }
-    c.bytes = static_cast<char *>(malloc(total ? total : 1));
-    if (!c.bytes) throw std::bad_alloc();
+    {
+      // (a buffer the consumer has given back, if one is large enough: a fresh 20 MB allocation is 5 000 page faults)
+      std::lock_guard<std::mutex> l(m_);
+      for (size_t k = 0; k < pool_.size(); ++k)
+        if (pool_[k].second >= total) {
+          c.bytes = pool_[k].first;
+          c.cap_bytes = pool_[k].second;
+          pool_[k] = pool_.back();
+          pool_.pop_back();
+          break;
+        }
+    }
+    if (!c.bytes) {
+      c.cap_bytes = (total ? total : 1) + (total >> 3);
+      c.bytes = static_cast<char *>(malloc(c.cap_bytes));
+      if (!c.bytes) throw std::bad_alloc();
+    }
     c.n_bytes = total;
     {
-      const uint16_t *s = z.out.data() + gzp::WIN;
-      char *o = c.bytes;
-      const uint8_t *L = lut.data();
-      size_t k = 0;
-      for (; k + 8 <= total; k += 8) {
-        o[k] = (char)L[s[k]]; o[k + 1] = (char)L[s[k + 1]]; o[k + 2] = (char)L[s[k + 2]]; o[k + 3] = (char)L[s[k + 3]];
-        o[k + 4] = (char)L[s[k + 4]]; o[k + 5] = (char)L[s[k + 5]]; o[k + 6] = (char)L[s[k + 6]]; o[k + 7] = (char)L[s[k + 7]];
-      }
-      for (; k < total; ++k) o[k] = (char)L[s[k]];
+      static const bool avx2 = __builtin_cpu_supports("avx2");
+      if (avx2) translate_avx2(z.out.data() + gzp::WIN, c.bytes, total, lut.data());
+      else translate(z.out.data() + gzp::WIN, c.bytes, total, lut.data());
     }
     c.stream_ends = ends || nxt >= n_chunks_;
+    ns_pass2_ += thread_ns() - t0;
     finish(c);
   }
 
@@ -710,6 +926,8 @@ class ParallelGunzip {
   std::condition_variable cv_;
   size_t next_chunk_ = 0, consume_ = 0;
   bool handed_ = false, quit_ = false;
+  std::vector<std::pair<char *, size_t>> pool_;       // byte buffers given back by the consumer (guarded by m_)
+  std::atomic<uint64_t> ns_search_{0}, ns_pass1_{0}, ns_pass2_{0};
 };
 
 }  // namespace shk

@@ -241,7 +241,7 @@ static int enqueue_tail(Ctx *ctx, Slot &s, bool skip_hist_if_long, bool count_ge
     if ((rc = ensure_pinned(ctx, &s.h_gene_ids, &s.cap_h_gene_ids, s.cap_gene_ids))) return rc;
   }
   if ((rc = launch_publish_results(s.d_counters, s.h_counters, s.d_gene_off, s.host_batch ? s.h_gene_off : nullptr, n + 1, s.d_gene_ids,
-                                   s.h_gene_ids, s.cap_h_gene_ids, st)))
+                                   s.h_gene_ids, s.cap_h_gene_ids, s.p.uni_flag, st)))
     return rc;
   SHK_HIP(ctx, hipEventRecord(s.ev_done, st));
   return SHK_OK;
@@ -252,6 +252,17 @@ enum LongMode {
   LONG_KNOWN = 1,           // the host has counted the reads that do not fit (host batches)
   LONG_UNKNOWN = 2          // no bound: one host round trip behind the fast kernel
 };
+
+// what the device said about the batch just finished (0: the host knew); shk_last_kernel() carries it
+static void note_verdict(Ctx *ctx, uint32_t v)
+{
+  ctx->last_verdict = v;
+  if (char *e = strstr(ctx->last_kernel, " verdict=")) *e = 0;
+  if (v) {
+    const size_t l = strlen(ctx->last_kernel);
+    snprintf(ctx->last_kernel + l, sizeof(ctx->last_kernel) - l, " verdict=%s", v == 1u ? "ragged" : (v == 2u ? "uniform" : "classes"));
+  }
+}
 
 // all kernels of one batch whose inputs are (or will be, in stream order) resident in HBM; batch pointers are device
 // pointers.  Returns with the work enqueued on ctx->stream; finish_classify() completes the rare slow paths.
@@ -283,8 +294,12 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   // the histogram (the caller's bound on the read length says) and, the device decides, full enough; also when the host knows
   // the batch is ragged: it has not counted
   const uint64_t classes = (table_kernel && uni_L1) ? ((uint64_t)uni_L1 + 1) * ((uint64_t)(b->seq2 ? uni_L2 : 0) + 1) : 0;
+  // (a batch only the device can judge, in a stream whose last batch was uniform -- a sequencer's output --: the four launches of
+  //  this path are left out, 2 % of such a batch; should it be ragged after all, the ragged instantiation takes it, and the next one
+  //  comes here again)
+  const bool stream_is_uniform = uni_mode == UNI_ASK_DEVICE && ctx->last_verdict == 2u && !ctx->env_cls_always;
   const bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && classes != 0 && classes <= (1ull << 20) &&
-                          n < (1ull << 31) && ctx->env_cls_min_fill != 0;
+                          n < (1ull << 31) && ctx->env_cls_min_fill != 0 && !stream_is_uniform;
   // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
   // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
   const bool with_plans = table_kernel && uni_mode != UNI_YES && classes != 0 && classes <= (1ull << 20);
@@ -312,20 +327,23 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     // classify_uni_kernel writes count[] only for reads with associations
     SHK_HIP(ctx, hipMemsetAsync(s.d_count, 0, (n + 1) * sizeof(uint32_t), st));
   }
-  // timed: the classify launches and, for a batch the device has to look at first, the passes over its offsets
+  // timed: the classify launches (shk_timing::total_ms) and, for a batch the device has to look at first, the passes over its
+  // offsets in front of them (prepass_ms)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->timing) {
     if (ctx->ev_used == ctx->ev_start.size()) {
-      hipEvent_t a, c;
+      hipEvent_t a, c, d;
       SHK_HIP(ctx, hipEventCreate(&a));
       SHK_HIP(ctx, hipEventCreate(&c));
+      SHK_HIP(ctx, hipEventCreate(&d));
       ctx->ev_start.push_back(a);
       ctx->ev_stop.push_back(c);
+      ctx->ev_pre.push_back(d);
     }
     e0 = ctx->ev_start[ctx->ev_used];
     e1 = ctx->ev_stop[ctx->ev_used];
+    SHK_HIP(ctx, hipEventRecord(ctx->ev_pre[ctx->ev_used], st));
     ctx->ev_used++;
-    SHK_HIP(ctx, hipEventRecord(e0, st));
   }
   if (table_kernel) {
     if (by_classes) {
@@ -343,6 +361,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     }
     if (with_plans) SHK_HIP(ctx, hipMemsetAsync(s.d_plan, 0, classes * sizeof(uint4), st));
   }
+  if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e0, st));
 
   // the timed launch is the one that does the work: the uniform kernel when the host knows it applies (or has to ask
   // the device: then the generic kernel is launched behind it and returns at once for a uniform batch)
@@ -372,7 +391,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
 
   uint32_t n_long = 0;
   if (long_mode == LONG_UNKNOWN) {
-    if ((rc = launch_publish_results(s.d_counters, s.h_counters, nullptr, nullptr, 0, nullptr, nullptr, 0, st))) return rc;
+    if ((rc = launch_publish_results(s.d_counters, s.h_counters, nullptr, nullptr, 0, nullptr, nullptr, 0, s.p.uni_flag, st))) return rc;
     SHK_HIP(ctx, hipStreamSynchronize(st));
     n_long = s.h_counters[CTR_LONG];
     s.gen_slots = std::max(s.fast_cap, s.h_counters[CTR_MAX_SLOTS]);
@@ -455,6 +474,7 @@ static int classify_resident(Ctx *ctx, const shk_batch *b, uint32_t max_read_len
   ctx->last.last_n_reads = n;
   ctx->last.last_n_long = s.h_counters[CTR_LONG];
   ctx->last.last_n_tie = s.h_counters[CTR_TIE];
+  note_verdict(ctx, s.h_counters[CTR_VERDICT]);
 #ifdef SHK_ANCH_STATS   // (experiments: reads the anchored extension settled early / settled after probing its open slots)
   ctx->last.last_n_long = s.h_counters[CTR_UNUSED3];
   ctx->last.last_n_tie = s.h_counters[CTR_UNUSED5];
@@ -576,7 +596,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     const char *e = getenv("SHK_FORCE_GENERIC");
     ctx->env_force_generic = e && e[0] == '1';
     ctx->env_big_lds_always = getenv("SHK_BIG_LDS_ALWAYS") != nullptr;
-    if (const char *f = getenv("SHK_CLS_MIN_FILL")) ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10);
+    if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };
 #define CR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP); } while (0)
@@ -618,6 +638,7 @@ void shk_destroy(shk_ctx *ctx)
   dist_release(ctx);
   for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
+  for (auto e : ctx->ev_pre) (void)hipEventDestroy(e);
   if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -851,6 +872,7 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
   ctx->last.last_n_reads = n;
   ctx->last.last_n_long = s.h_counters[CTR_LONG];
   ctx->last.last_n_tie = s.h_counters[CTR_TIE];
+  note_verdict(ctx, s.h_counters[CTR_VERDICT]);
   ctx->last.last_n_assoc = n_assoc;
   result->n = n;
   result->gene_off = s.h_gene_off;
@@ -1035,15 +1057,18 @@ int shk_timing_get(shk_ctx *ctx, shk_timing *t)
   if (!ctx || !t) return SHK_ERR_ARG;
   SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
   SHK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  double total = 0.0;
+  double total = 0.0, pre = 0.0;
   for (size_t i = 0; i < ctx->ev_used; ++i) {
     float ms = 0.f;
     SHK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
     total += ms;
+    SHK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pre[i], ctx->ev_start[i]));
+    pre += ms;
   }
   *t = ctx->last;
   t->n_launches = ctx->ev_used;
   t->total_ms = total;
+  t->prepass_ms = pre;
   return SHK_OK;
 }
 

@@ -197,7 +197,8 @@ enum {
   CTR_UNUSED5 = 5,
   CTR_ASSOC_LO = 6,  // number of associations of the batch (the scan's total), 64 bits
   CTR_ASSOC_HI = 7,
-  CTR_WORDS = 8
+  CTR_VERDICT = 8,   // (host copy only) 1 + uni_flag[0] of a batch the device looked at: 1 ragged, 2 uniform, 3 by classes; 0: the host knew
+  CTR_WORDS = 9
 };
 
 constexpr uint32_t UNI_FLAG_WORDS = 16;
@@ -259,7 +260,7 @@ int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t ge
 int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, hipStream_t stream);
 int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
 int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
-                           const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, hipStream_t stream);
+                           const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, const uint32_t *uni_flag, hipStream_t stream);
 int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, int rmode, hipStream_t stream);   // 0 ragged, 1 uniform, 2 by classes (CLS)
 int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);   // behind launch_uniform_check: histogram, plan, scatter
 bool class_kernel_available(const Ctx *ctx, uint32_t max_slots);
@@ -301,14 +302,15 @@ struct Ctx {
   // test / A-B switches of the environment, read ONCE when the context is created (never per launch):
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
-  bool env_force_generic = false, env_big_lds_always = false;
+  bool env_force_generic = false, env_big_lds_always = false, env_cls_always = false;   // SHK_CLS_MIN_FILL given: no adapting to the stream
+  uint32_t last_verdict = 0;        // CTR_VERDICT of the last batch finished
   uint32_t env_cls_min_fill = CLS_MIN_FILL;   // SHK_CLS_MIN_FILL: pairs per non-empty class a batch needs to go class by class (0: never; tests: 1)
   // which classify kernel the last batch's main launch was (shk_last_kernel): the choice can depend on the batch before it
   char last_kernel[96] = "";
 
   // timing
   bool timing = false;
-  std::vector<hipEvent_t> ev_start, ev_stop;
+  std::vector<hipEvent_t> ev_start, ev_stop, ev_pre;   // per launch: in front of the classify launches, behind them, in front of the passes over the offsets
   size_t ev_used = 0;
   shk_timing last{};
 };

@@ -887,8 +887,9 @@ def test_device_api_with_a_wrong_length_bound(oracle):
 def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
     """device-resident batches: uniform_check_kernel decides on the device whether every read has one length per mate (two offsets
     per thread, the third from the next lane).  One read a base shorter -- first, last, odd / even index, either side of a wave and
-    of a workgroup of the check, in either mate -- makes the batch ragged; an all-equal batch with an odd read count stays uniform.
-    The associations are the oracle's every time (a wrong verdict would read every later read at the wrong place)."""
+    of a workgroup of the check, in either mate -- makes the batch ragged; an all-equal batch with an odd read count stays uniform;
+    1 %, 20 % and 50 % of the reads a few bases shorter go class by class.  The associations are the oracle's every time (a wrong
+    verdict would read every later read at the wrong place)."""
     from shark_amd.capi import hip_memcpy_dtoh
     rng = np.random.default_rng(977)
     genes = synth.make_genes(rng, 1, 5000, 5000)
@@ -915,6 +916,29 @@ def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
                 gids = np.empty(int(r.n_assoc), np.uint16)
                 hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
                 assert np.array_equal(goff, og) and np.array_equal(gids, oi), (n, odd, mate)
+                assert ("verdict=uniform" in h.last_kernel()) == (odd is None), h.last_kernel()
+        # 1 %, 20 %, 50 % odd reads, one to three bases shorter in either mate: a handful of classes, sorted and classified class by class
+        said = set()
+        for frac in (0.01, 0.2, 0.5):
+            for rep in range(2):      # (behind a uniform batch the first ragged one takes the ragged instantiation)
+                a, b = list(m1), list(m2)
+                for i in np.flatnonzero(rng.random(n) < frac):
+                    cut = int(rng.integers(1, 4))
+                    if rng.random() < 0.5:
+                        a[i] = a[i][:-cut]
+                    else:
+                        b[i] = b[i][:-cut]
+                bt = synth.batch_from_lists(a, b)
+                og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"])
+                t = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for k, v in bt.items() if v is not None}
+                r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=120)
+                goff = np.empty(n + 1, np.uint32)
+                hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+                gids = np.empty(int(r.n_assoc), np.uint16)
+                hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+                assert np.array_equal(goff, og) and np.array_equal(gids, oi), (n, frac, rep)
+                said.add(h.last_kernel().split("verdict=")[-1])
+        assert "classes" in said and "uniform" not in said, said
     h.close()
 
 
@@ -926,7 +950,7 @@ def test_trimmed_batches_go_class_by_class(oracle, monkeypatch, n_genes, k, q, f
     (SHK_CLS_MIN_FILL pairs per unit: 1 here, so that every shape below takes that path, and the default 16, where most of these
     small batches stay with the ragged instantiation).  1 %, 20 %, 50 %, 80 % and 100 % trimmed mates (either mate, both, down to
     shorter than k), paired and single-end, host batches and batches resident in HBM, one gene (sparse first round) and several
-    genes (no CLS instantiation there: the LDS-summary ragged kernel), 2 x 90, 2 x 150 and 2 x 300 bp (the last: more classes than the
+    genes (the exact table without it), 2 x 90, 2 x 150 and 2 x 300 bp (the last: more classes than the
     pre-pass counts in LDS, the shortest mates take the global counters): the oracle's associations every time."""
     monkeypatch.setenv("SHK_CLS_MIN_FILL", str(fill))
     from shark_amd.capi import hip_memcpy_dtoh
@@ -955,6 +979,8 @@ def test_trimmed_batches_go_class_by_class(oracle, monkeypatch, n_genes, k, q, f
             og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"], bt["qual1"], bt["qual2"])
             hg, hi = h.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"], bt["qual1"], bt["qual2"])
             assert np.array_equal(hg, og) and np.array_equal(hi, oi), ("host", paired, frac)
+            if fill == 1:     # what the device said about the batch (shk_last_kernel)
+                assert "verdict=classes" in h.last_kernel(), h.last_kernel()
             t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in bt.items()}
             pt = {kk: (v.data_ptr() if v is not None else 0) for kk, v in t.items()}
             torch.cuda.synchronize()
@@ -964,7 +990,41 @@ def test_trimmed_batches_go_class_by_class(oracle, monkeypatch, n_genes, k, q, f
             gids = np.empty(int(r.n_assoc), np.uint16)
             hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
             assert np.array_equal(goff, og) and np.array_equal(gids, oi), ("resident", paired, frac)
+            if fill == 1:
+                assert "verdict=classes" in h.last_kernel(), h.last_kernel()
             assert int(og[-1]) > n // 4
+    h.close()
+
+
+def test_class_path_follows_the_stream(oracle):
+    """batches resident in HBM, whose lengths only the device sees: behind a uniform batch the launches of the class-by-class path are
+    left out (a sequencer's stream pays nothing for them), so the first trimmed batch of a stream takes the ragged instantiation and
+    the ones behind it go class by class; a uniform batch in between is still recognised.  Same associations either way."""
+    from shark_amd.capi import hip_memcpy_dtoh
+    rng = np.random.default_rng(77)
+    genes = synth.make_genes(rng, 1, 2500, 2600)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 30, c=0.5)
+    dev = torch.device("cuda:0")
+    n, L = 4000, 150
+    base = synth.make_reads(rng, genes, n, read_len=L, paired=True, on_target=0.7)
+    def cut(seq, off, lens):
+        return [bytes(seq[int(off[i]):int(off[i]) + int(lens[i])]) for i in range(n)]
+    full = np.full(n, L)
+    some = np.where(rng.random(n) < 0.3, rng.choice([100, 120, 140], size=n), L)
+    said = []
+    for lens1, lens2 in ((full, full), (full, full), (some, full), (some, some), (full, full), (some, some), (some, some)):
+        bt = synth.batch_from_lists(cut(base["seq1"], base["off1"], lens1), cut(base["seq2"], base["off2"], lens2), None, None)
+        og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"], None, None)
+        t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in bt.items()}
+        torch.cuda.synchronize()
+        r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), 0, 0, max_read_len=L)
+        goff = np.empty(n + 1, np.uint32)
+        hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+        gids = np.empty(int(r.n_assoc), np.uint16)
+        hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+        assert np.array_equal(goff, og) and np.array_equal(gids, oi), said
+        said.append(h.last_kernel().split("verdict=")[-1])
+    assert said == ["uniform", "uniform", "ragged", "classes", "uniform", "ragged", "classes"], said
     h.close()
 
 

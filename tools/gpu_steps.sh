@@ -18,9 +18,11 @@ tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
+i=0
 for step in "$@"; do
+  i=$((i + 1))
   echo "== $step $(date +%T)"
-  log=$out/$(echo "$step" | tr ':/ ,' '____').log
+  log=$out/$(printf %02d $i)_$(echo "$step" | tr ':/ ,' '____').log
   case $step in
     suite)       timeout -k 10 1150 python3 -m pytest tests -m gpu -x -q --durations=15 > $log 2>&1 ;;
     scale)       timeout -k 10 1150 python3 -m pytest tests/test_gpu_scale.py -x -q --durations=5 > $log 2>&1 ;;
