@@ -452,8 +452,8 @@ struct Inflater {
             o[w++] = (uint16_t)(e & 0xFFFF);
             continue;
           }
-          if (__builtin_expect(kind != 1, 0)) {
-            if (kind == 3 || !dtf) rc = BAD;
+          if (__builtin_expect(kind != 1, 0)) {      // end of block, or a length code no valid stream uses
+            if (kind == 3) rc = BAD;
             ended = true;
             break;
           }
@@ -480,8 +480,13 @@ struct Inflater {
           if (__builtin_expect(dd > w - floor, 0)) { rc = BAD; ended = true; break; }
           const uint16_t *s = o + w - dd;
           uint16_t *t = o + w;
-          if (dd >= 8) {
-            for (unsigned i = 0; i < len; i += 8) memcpy(t + i, s + i, 16);
+          if (__builtin_expect(dd >= 8, 1)) {
+            // sixteen symbols without asking (the bases of a FASTQ record come as matches of 3 to 16 symbols: a trip count that
+            // follows len is a misprediction per match), in two steps of eight so that a distance of 8 to 15 copies what the
+            // first step wrote; the rest, rarely, eight at a time.  (Up to 15 symbols past len: the capacity margin covers them.)
+            memcpy(t, s, 16);
+            memcpy(t + 8, s + 8, 16);
+            for (unsigned i = 16; i < len; i += 8) memcpy(t + i, s + i, 16);
           } else {
             for (unsigned i = 0; i < len; ++i) t[i] = s[i];
           }
