@@ -1578,6 +1578,7 @@ int main(int argc, char *argv[])
     to_format.close();
     for (auto &t : formatters) t.join();
     fflush(stdout);
+    timeline("pipeline threads joined");
     if (serial_failed) {
       std::cerr << "shark: cannot open the sample" << std::endl;
       return EXIT_FAILURE;
@@ -1608,6 +1609,7 @@ int main(int argc, char *argv[])
       std::cerr << "shark: classification failed: " << shk_strerror(failed) << std::endl;
       return EXIT_FAILURE;
     }
+    timeline("output files closed");
   }
   timeline("outputs closed");
   pelapsed("Sample completed");
