@@ -1093,7 +1093,11 @@ int main(int argc, char *argv[])
     unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, hw);
     // (the reference opens its outputs unchecked and writes nothing to a file it could not open, main.cpp:99-106: same here)
     OffsetWriter w1, w2;
-    const unsigned write_helpers = 3;   // (six per file measured slower on a 16-core share: readers, formatters and writers compete)
+    // one writer thread per output file: tmpfs takes 8.7 GB/s from ONE thread writing a file and 3.6-4.6 GB/s from 2-12 threads
+    // writing disjoint parts of it (tools/tmpfs_write_bench.cpp); the command with half the sample written out again, 32 M pairs,
+    // the same files: 2.74 / 2.80 s with one helper per file, 2.93-3.38 s with three, 3.65 s with two
+    unsigned write_helpers = 1;
+    if (const char *e = getenv("SHARK_WRITE_HELPERS")) write_helpers = (unsigned)std::max(1, atoi(e));
     w1.open(opt.out1_path, write_helpers);
     if (opt.paired_flag && opt.out2_path != "") w2.open(opt.out2_path, write_helpers);
     OffsetWriter *out1 = w1.is_open() ? &w1 : nullptr, *out2 = w2.is_open() ? &w2 : nullptr;

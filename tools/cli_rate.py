@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs.
-usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var, GZ=1 (the sample files gzip -1 compressed: the inflate-bound path)"""
+usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var, GZ=1 (the sample files gzip -1 compressed: the inflate-bound path), RUN_ENVS="V=1;V=3" (the same files once per setting)"""
 import json, os, subprocess, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -62,18 +62,22 @@ if os.environ.get('WARM', '1') == '1':      # read the files once, untimed: the 
     for f in ('r1.fq', 'r2.fq'):
         subprocess.run(['cat', os.path.join(td, f + SUFFIX)], stdout=subprocess.DEVNULL)
 # CLI_T=16,64 runs the same files once per thread count
-for t in [x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]:
+# RUN_ENVS="A=1;A=3;A=1" repeats every run once per entry with that variable set (A/B on the same files)
+for t, run_env in [(t, e) for t in ([x for x in os.environ.get("CLI_T", "").split(",") if x] or [None]) for e in (os.environ.get("RUN_ENVS", "").split(";") if os.environ.get("RUN_ENVS") else [""])]:
     args = extra + (["-t", t] if t else [])
+    env = dict(os.environ)
+    if run_env:
+        env[run_env.split("=")[0]] = run_env.split("=", 1)[1]
     t0 = time.time()
     with open(os.path.join(td, "out.ssv"), "wb") as so:
         r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq" + SUFFIX),
                             "-2", os.path.join(td, "r2.fq" + SUFFIX), "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-v"] + args,
-                           stdout=so, stderr=subprocess.PIPE)
+                           stdout=so, stderr=subprocess.PIPE, env=env)
     t1 = time.time()
     dt = t1 - t0
     ep = [float(l.split("(epoch ")[1].rstrip(")")) for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]") and "(epoch " in l]
     gaps = {"before_main_ms": round((ep[0] - t0) * 1e3, 1), "after_last_ms": round((t1 - ep[-1]) * 1e3, 1)} if ep else {}
     print(json.dumps({"pairs": n, "gaps": gaps, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
-                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "headers": "var" if VAR else "fixed", "gz": SUFFIX == ".gz",
+                      "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "run_env": run_env, "headers": "var" if VAR else "fixed", "gz": SUFFIX == ".gz",
                       "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:].split(" (epoch")[0] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
 subprocess.run(["rm", "-rf", td])
