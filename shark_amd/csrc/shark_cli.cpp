@@ -931,6 +931,7 @@ class ReadOutput {
       FormattedSegment &sg = out.segs.back();
       sg.carries = g % 50000 != 0;                  // continues the previous batch's chunk: previd is known only when the batches are written
       std::string previd;
+      bool reserved = false;
       if (b.lean) {
         // many associated reads in this segment: its byte range in one read; few: one read per record
         const size_t n_assoc = b.gene_off[last] - b.gene_off[first];
@@ -971,6 +972,16 @@ class ReadOutput {
             } else {
               if (out1_) record(o1, b.id1, b.seq1, b.qual1, b.qual_as_read1, i);
               if (out2_) record(o2, b.id2, b.seq2, b.qual2, b.qual_as_read2, i);
+            }
+            // (the segment's text in one allocation: by its first record and the reads it has left -- a string that doubles its way
+            //  to 8 MB copies itself twice over and page-faults every step)
+            if (!reserved && &o1 == &sg.fq1) {
+              reserved = true;
+              size_t left = 0;
+              for (size_t r = i; r < last; ++r) left += b.gene_off[r] != b.gene_off[r + 1];
+              if (out1_) sg.fq1.reserve(sg.fq1.size() * left + (sg.fq1.size() * left >> 4) + 64);
+              if (out2_) sg.fq2.reserve(sg.fq2.size() * left + (sg.fq2.size() * left >> 4) + 64);
+              sg.ssv.reserve(sg.ssv.size() * left + (sg.ssv.size() * left >> 3) + 64);
             }
           }
           if (head) sg.head_id.assign(id, id_len);
