@@ -5,6 +5,7 @@ Usage: python tools/collect_profiles.py [tag]        (tag defaults to r02)
 Writes
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
   profiles/<tag>_bench_profiled.json the bench line printed by that profiled run
+  profiles/<tag>_trimmed_kernel_stats.csv  the same trace of a batch with 20 % of its mates trimmed (tools/ragged_rate.py 10000000 100 0.8)
   profiles/pmc_counters.json        per-launch counters of the classify kernels, stamped with the commit and with
                                     the hash of the kernel sources they were taken on; bench.py uses the file only
                                     when that hash equals the hash of the sources it runs (no stale traffic figures)
@@ -41,6 +42,14 @@ def newest(pattern):
 raw = json.load(open(os.path.join(src, "counters_raw.json")))
 stats = newest(src + "/kt/*/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
+if glob.glob(src + "/kt_trimmed/*/*_kernel_stats.csv"):     # tools/ragged_rate.py 10000000 100 0.8: rows of the classify and pre-pass kernels
+    rows = list(csv.reader(open(newest(src + "/kt_trimmed/*/*_kernel_stats.csv"))))
+    with open(os.path.join(ROOT, "profiles", "%s_trimmed_kernel_stats.csv" % tag), "w") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if any(x in r[0] for x in ("classify", "uniform_check", "class_")):
+                w.writerow(r)
 bench = json.loads([l for l in open(os.path.join(src, "kt.json")) if l.startswith("{")][-1])
 json.dump(bench, open(os.path.join(ROOT, "profiles", "%s_bench_profiled.json" % tag), "w"), indent=1)
 avg_ms = {}
