@@ -832,6 +832,44 @@ def main():
     kern_ms = tm["total_ms"] / max(tm["n_launches"], 1)
     headline_kernel = h.last_kernel()
 
+    # ---- trimmed samples on the headline index: the first chunk with a share of its mates cut to 100-150 bases (rank 0, N = 1) -----
+    # (reads of any length in one stream, FastqSplitter.hpp:47-93; DESIGN.md 3: sorted by length on the device, classified class by class)
+    trimmed = None
+    if world == 1 and not args.no_configs and L == 150 and batches:
+        log("trimmed batches")
+        trimmed = {"what": "the headline workload's first %d pairs with a share of the mates cut to a random length in [100, 150] (offsets from HBM: the device "
+                           "decides what the batch is); ms per launch = the classify launches + the passes over the offsets in front of them "
+                           "(shk_timing.prepass_ms), two untimed calls first" % chunk_pairs, "runs": []}
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(7)
+        for share in (0.2, 1.0):
+            tb = {}
+            for key in ("seq1", "seq2"):
+                ln = torch.randint(100, 151, (chunk_pairs,), generator=gq, device=dev)
+                ln = torch.where(torch.rand(chunk_pairs, generator=gq, device=dev) < 1.0 - share, torch.full_like(ln, L), ln)
+                keep = torch.arange(L, device=dev)[None, :] < ln[:, None]
+                tb[key] = batches[0][key].view(chunk_pairs, L)[keep].contiguous()
+                off = torch.zeros(chunk_pairs + 1, dtype=torch.int64, device=dev)
+                off[1:] = torch.cumsum(ln, 0)
+                tb["off" + key[-1]] = off
+                del keep, ln
+            torch.cuda.synchronize()
+            call = lambda: h.classify_device(chunk_pairs, tb["seq1"].data_ptr(), tb["off1"].data_ptr(), tb["seq2"].data_ptr(), tb["off2"].data_ptr(), 0, 0, max_read_len=L)
+            call()
+            call()          # (the class-by-class path follows the stream: the first ragged batch behind uniform ones takes the ragged instantiation)
+            h.timing_enable(True)
+            for _ in range(4):
+                rt = call()
+            tmt = h.timing()
+            h.timing_enable(False)
+            nl = max(tmt["n_launches"], 1)
+            trimmed["runs"].append({"mates_trimmed": share, "ms_per_launch": round((tmt["total_ms"] + tmt["prepass_ms"]) / nl, 3),
+                                    "of_which_prepass_ms": round(tmt["prepass_ms"] / nl, 3), "kernel": h.last_kernel(), "n_assoc": int(rt.n_assoc),
+                                    "reads_per_s": round(2 * chunk_pairs / ((tmt["total_ms"] + tmt["prepass_ms"]) / nl / 1e3), 1)})
+            del tb
+        trimmed["untrimmed_ms_per_launch"] = round(kern_ms, 3)
+        torch.cuda.empty_cache()
+
     # ---- BASELINE configs[2] index (60 000 genes, 2^36 bits): every rank, 10 M-pair steps -----
     cfg2 = cfg4 = None
     big = {}
@@ -1148,6 +1186,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "configs": [cfg2, cfg4] if cfg2 else [],
+        "trimmed_reads": trimmed,
         "batch_boundary": boundary,
         "cli_end_to_end": cli,
     }
