@@ -615,24 +615,62 @@ __global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams
   uint32_t bad = 0;
   uint64_t mx1 = 0, mx2 = 0;   // the longest mates: the ragged instantiation stages the whole batch in their layout
   if (blockIdx.x == 0 && threadIdx.x == 0 && n) bad |= (P.off1[0] != 0) | (P.seq2 && P.off2[0] != 0);
-  // (a read's end is the next one's start: one coalesced load per read and mate, the neighbour's by shuffle, lane 63's from memory)
+  // (a read's end is the next one's start.  Offsets on a 16-byte boundary -- whole allocations are --: two reads per lane from one
+  //  16-byte load, the third offset from the next lane; else one read per lane from an 8-byte load.  Lane 63's last offset, and the
+  //  last lanes' at the end of the batch, come from memory.)
   const int lane_u = threadIdx.x & 63;
-  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = i0 + threadIdx.x;
-    const bool valid = i < n;
-    const uint64_t a1 = P.off1[valid ? i : n];
-    uint64_t b1 = __shfl_down(a1, 1);
-    if (lane_u == 63) b1 = P.off1[valid ? i + 1 : n];
-    const uint64_t l1 = valid ? b1 - a1 : L1;
-    bad |= l1 != L1;
-    mx1 = l1 > mx1 ? l1 : mx1;
-    if (P.seq2) {
-      const uint64_t a2 = P.off2[valid ? i : n];
-      uint64_t b2 = __shfl_down(a2, 1);
-      if (lane_u == 63) b2 = P.off2[valid ? i + 1 : n];
-      const uint64_t l2 = valid ? b2 - a2 : L2;
-      bad |= l2 != L2;
-      mx2 = l2 > mx2 ? l2 : mx2;
+  const bool wide = ((reinterpret_cast<uintptr_t>(P.off1) | (P.seq2 ? reinterpret_cast<uintptr_t>(P.off2) : 0)) & 15u) == 0;
+  if (wide) {
+    // (four strides per trip, every load of the trip issued before the first is used: 160 MB of offsets per 10 M pairs want more
+    //  in flight than one 16-byte load per lane)
+    constexpr int TRIP = 4;
+    const uint64_t stride = 2ull * gridDim.x * blockDim.x;
+    auto mate = [&](const uint64_t *__restrict__ off, const uint64_t i_first, const uint64_t L, uint64_t &mx) {
+      // per stride u: entries off[i], off[i + 1], off[i + 2] -> the reads i and i + 1 (i even)
+      ulonglong2 a[TRIP];
+      uint64_t tail[TRIP];
+#pragma unroll
+      for (int u = 0; u < TRIP; ++u) {
+        const uint64_t i = i_first + (uint64_t)u * stride;
+        a[u] = make_ulonglong2(0, 0);
+        tail[u] = 0;
+        if (i + 1 <= n) a[u] = *reinterpret_cast<const ulonglong2 *>(off + i);
+        if ((lane_u == 63 || i + 3 > n) && i + 2 <= n) tail[u] = off[i + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < TRIP; ++u) {
+        const uint64_t i = i_first + (uint64_t)u * stride;
+        uint64_t c = __shfl_down(a[u].x, 1);
+        if (lane_u == 63 || i + 3 > n) c = tail[u];
+        const uint64_t la = i < n ? a[u].y - a[u].x : L, lb = i + 1 < n ? c - a[u].y : L;
+        bad |= (la != L) | (lb != L);
+        mx = la > mx ? la : mx;
+        mx = lb > mx ? lb : mx;
+      }
+    };
+    for (uint64_t i0 = 2ull * blockIdx.x * blockDim.x; i0 < n; i0 += TRIP * stride) {
+      const uint64_t i = i0 + 2ull * threadIdx.x;
+      mate(P.off1, i, L1, mx1);
+      if (P.seq2) mate(P.off2, i, L2, mx2);
+    }
+  } else {
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+      const uint64_t i = i0 + threadIdx.x;
+      const bool valid = i < n;
+      const uint64_t a1 = P.off1[valid ? i : n];
+      uint64_t b1 = __shfl_down(a1, 1);
+      if (lane_u == 63) b1 = P.off1[valid ? i + 1 : n];
+      const uint64_t l1 = valid ? b1 - a1 : L1;
+      bad |= l1 != L1;
+      mx1 = l1 > mx1 ? l1 : mx1;
+      if (P.seq2) {
+        const uint64_t a2 = P.off2[valid ? i : n];
+        uint64_t b2 = __shfl_down(a2, 1);
+        if (lane_u == 63) b2 = P.off2[valid ? i + 1 : n];
+        const uint64_t l2 = valid ? b2 - a2 : L2;
+        bad |= l2 != L2;
+        mx2 = l2 > mx2 ? l2 : mx2;
+      }
     }
   }
   // (per wave, then per workgroup)
@@ -956,6 +994,24 @@ __global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *_
   for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS) { h_key[i] = 0xFFFFFFFFu; h_cnt[i] = 0; }
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  // a wave's count of the gene it met last stays in a register until another gene comes (a one-gene index: one LDS update per wave
+  // and launch instead of one per 64 associations; with the 1 024 workgroups of the first version, each flushing the same counter,
+  // 0.13 ms per 5 M associations)
+  uint32_t run_gene = 0xFFFFFFFFu, run_cnt = 0;          // (wave-uniform)
+  auto flush = [&](const uint32_t lg, const uint32_t add) {
+    if (lane != 0 || !add) return;
+    uint32_t slot = (lg * 2654435761u) >> 21;   // 11 bits
+    bool done = false;
+    for (uint32_t probe = 0; probe < 16 && !done; ++probe) {
+      const uint32_t old = atomicCAS(&h_key[slot], 0xFFFFFFFFu, lg);
+      if (old == 0xFFFFFFFFu || old == lg) {
+        atomicAdd(&h_cnt[slot], add);
+        done = true;
+      }
+      slot = (slot + 1) & (GI_TABLE - 1);
+    }
+    if (!done) atomicAdd(&gene_counts[lg], (unsigned long long)add);   // table crowded: straight to HBM
+  };
   const uint64_t n_round = (n + GI_THREADS - 1) / GI_THREADS * GI_THREADS;   // keep whole waves in the loop (ballots)
   for (uint64_t i = (uint64_t)blockIdx.x * GI_THREADS + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * GI_THREADS) {
     const bool pending = i < n;
@@ -963,25 +1019,20 @@ __global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *_
     unsigned long long todo = __ballot(pending);
     while (todo) {
       const int leader = __builtin_ctzll(todo);
-      const uint32_t lg = __shfl(g, leader, 64);
+      const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)g, leader);
       const unsigned long long same = __ballot(pending && g == lg);
-      if (lane == leader) {
-        const uint32_t add = (uint32_t)__builtin_popcountll(same);
-        uint32_t slot = (lg * 2654435761u) >> 21;   // 11 bits
-        bool done = false;
-        for (uint32_t probe = 0; probe < 16 && !done; ++probe) {
-          const uint32_t old = atomicCAS(&h_key[slot], 0xFFFFFFFFu, lg);
-          if (old == 0xFFFFFFFFu || old == lg) {
-            atomicAdd(&h_cnt[slot], add);
-            done = true;
-          }
-          slot = (slot + 1) & (GI_TABLE - 1);
-        }
-        if (!done) atomicAdd(&gene_counts[lg], (unsigned long long)add);   // table crowded: straight to HBM
+      const uint32_t add = (uint32_t)__builtin_popcountll(same);
+      if (lg == run_gene) {
+        run_cnt += add;
+      } else {
+        flush(run_gene, run_cnt);
+        run_gene = lg;
+        run_cnt = add;
       }
       todo &= ~same;
     }
   }
+  flush(run_gene, run_cnt);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS)
     if (h_cnt[i]) atomicAdd(&gene_counts[h_key[i]], (unsigned long long)h_cnt[i]);
@@ -1199,9 +1250,11 @@ int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *f
 
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream)
 {
-  if (hipMemsetAsync(flag, 0, UNI_FLAG_WORDS * sizeof(uint32_t), stream) != hipSuccess) return SHK_ERR_HIP;
+  // (flag[] is zero: cleared with the batch's counters, shark_hip.hip enqueue_classify)
   const uint64_t want = (p.n + 255) / 256;
-  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024))), dim3(256), 0, stream, p, slot_cap, flag);
+  // (every workgroup ends with an atomic on the same word -- and three more when the batch is ragged --, 40-50 ns each one after the
+  //  other: 1 024 workgroups spent half of the kernel's 0.08 ms there)
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 256 ? want : 256))), dim3(256), 0, stream, p, slot_cap, flag);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 
@@ -1245,7 +1298,7 @@ int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool sk
 {
   // the number of associations is only known on the device; it is of the order of the number of reads
   const uint64_t want = (n_reads + GI_THREADS - 1) / GI_THREADS;
-  const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024));
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 512 ? want : 512));
   hipLaunchKernelGGL(gene_hist_kernel, dim3(grid), dim3(GI_THREADS), 0, stream, gene_ids, counters, skip_if_long ? 1u : 0u, gene_counts);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }

@@ -94,9 +94,10 @@ static int ensure_pinned(Ctx *ctx, T **ptr, size_t *cap, size_t need)
 
 static int slot_init(Ctx *ctx, Slot &s)
 {
-  SHK_HIP(ctx, hipMalloc((void **)&s.d_counters, CTR_WORDS * sizeof(uint32_t)));
+  // (the batch's counters and, behind them, the words of the uniformity check: one allocation, cleared by one memset per batch)
+  SHK_HIP(ctx, hipMalloc((void **)&s.d_counters, (COUNTER_BLOCK_WORDS + UNI_FLAG_WORDS) * sizeof(uint32_t)));
+  s.d_uni_flag = s.d_counters + COUNTER_BLOCK_WORDS;
   SHK_HIP(ctx, hipMalloc((void **)&s.d_out, sizeof(ClassifyOut)));
-  SHK_HIP(ctx, hipMalloc((void **)&s.d_uni_flag, UNI_FLAG_WORDS * sizeof(uint32_t)));
   SHK_HIP(ctx, hipHostMalloc((void **)&s.h_counters, CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
   SHK_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -108,7 +109,7 @@ static void slot_free(Slot &s)
 {
   hipFree(s.d_seq1); hipFree(s.d_seq2); hipFree(s.d_qual1); hipFree(s.d_qual2); hipFree(s.d_off1); hipFree(s.d_off2);
   hipFree(s.d_count); hipFree(s.d_inl); hipFree(s.d_gene_off); hipFree(s.d_gene_ids);
-  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_uni_flag); hipFree(s.d_plan); hipFree(s.d_cls_entries); hipFree(s.d_cls_list); hipFree(s.d_cls_share); hipFree(s.d_cls_hist);
+  hipFree(s.d_long_queue); hipFree(s.d_tie_queue); hipFree(s.d_counters); hipFree(s.d_scan_temp); hipFree(s.d_out); hipFree(s.d_plan); hipFree(s.d_cls_entries); hipFree(s.d_cls_list); hipFree(s.d_cls_share); hipFree(s.d_cls_hist);
   if (s.h_counters) (void)hipHostFree(s.h_counters);
   if (s.h_gene_off) (void)hipHostFree(s.h_gene_off);
   if (s.h_gene_ids) (void)hipHostFree(s.h_gene_ids);
@@ -282,7 +283,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   if ((rc = slot_reserve(ctx, s, n))) return rc;
   s.n = n;
   fill_params(ctx, s, b);
-  SHK_HIP(ctx, hipMemsetAsync(s.d_counters, 0, CTR_WORDS * sizeof(uint32_t), st));
+  SHK_HIP(ctx, hipMemsetAsync(s.d_counters, 0, (COUNTER_BLOCK_WORDS + UNI_FLAG_WORDS) * sizeof(uint32_t), st));
   if (max_slots > fast_kernel_max_slots()) max_slots = fast_kernel_max_slots();
   s.fast_cap = 64 * fast_kernel_unroll(max_slots);
   s.gen_slots = s.fast_cap;

@@ -63,7 +63,7 @@ PY
                  rm -rf $out/pmc_tmp ;;
     kt:*)        # kernel trace with per-kernel statistics of a python script (rocprofv3 --kernel-trace --stats): the classify kernels' rows
                  rm -rf $out/kt_tmp; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_tmp -- python3 $(echo "${step#kt:}" | tr '@' ' ') > $log.out 2> $log \
-                 && { f=$(find $out/kt_tmp -name "*_kernel_stats.csv" | head -1); head -1 $f >> $log.out; grep -E "classify|uniform_check|class_" $f >> $log.out; }
+                 && { f=$(find $out/kt_tmp -name "*_kernel_stats.csv" | head -1); head -1 $f >> $log.out; grep -E "shk::|rocclr" $f >> $log.out; }
                  rm -rf $out/kt_tmp ;;
     env:*)       export "${step#env:}"; echo "exported ${step#env:}" > $log ;;   # for the steps behind it
     mem)         { nproc; free -g; df -h /dev/shm /tmp; cat /sys/fs/cgroup/memory.max /sys/fs/cgroup/cpu.max 2>/dev/null; grep -c processor /proc/cpuinfo; which rocprofv3; } > $log 2>&1 ;;
