@@ -984,11 +984,29 @@ __global__ void finalize_total_kernel(const uint64_t *__restrict__ total, uint32
 // finished by the host's slow path (overflow, or queued long reads the launch did not expect), which
 // then runs it itself -- so a batch is never counted twice.
 constexpr uint32_t GI_TABLE = 2048;   // LDS histogram slots per workgroup
+// DIRECT (an index of thousands of genes): a workgroup's few thousand associations hardly ever repeat a gene, the table would only
+// fill up and pass everything on -- equal genes inside a wave are combined, then the counter in HBM is touched at once.
+template <bool DIRECT>
 __global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *__restrict__ gene_ids, const uint32_t *__restrict__ counters,
                                                                uint32_t skip_if_long, unsigned long long *__restrict__ gene_counts)
 {
   if (counters[CTR_OVERFLOW] || (skip_if_long && counters[CTR_LONG])) return;
   const uint64_t n = ((uint64_t)counters[CTR_ASSOC_HI] << 32) | counters[CTR_ASSOC_LO];
+  if (DIRECT) {
+    const int lane_d = threadIdx.x & 63;
+    const uint64_t n_round_d = (n + GI_THREADS - 1) / GI_THREADS * GI_THREADS;
+    for (uint64_t i = (uint64_t)blockIdx.x * GI_THREADS + threadIdx.x; i < n_round_d; i += (uint64_t)gridDim.x * GI_THREADS) {
+      const bool pending = i < n;
+      const uint32_t g = pending ? gene_ids[i] : 0xFFFFFFFFu;
+      // (a lane adds for the lanes above it that hold the same gene -- neighbours in a read's list never do, reads of one gene do)
+      const uint32_t up = (uint32_t)__shfl_down((int)g, 1);
+      const bool first = lane_d == 0 || (uint32_t)__shfl_up((int)g, 1) != g;
+      // length of the run of equal genes that starts here (within the wave)
+      const unsigned long long differs = __ballot(up != g) | (1ull << 63);
+      if (pending && first) atomicAdd(&gene_counts[g], (unsigned long long)(__builtin_ctzll(differs >> lane_d) + 1));
+    }
+    return;
+  }
   __shared__ uint32_t h_key[GI_TABLE];
   __shared__ uint32_t h_cnt[GI_TABLE];
   for (uint32_t i = threadIdx.x; i < GI_TABLE; i += GI_THREADS) { h_key[i] = 0xFFFFFFFFu; h_cnt[i] = 0; }
@@ -1294,12 +1312,18 @@ int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t ge
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 
-int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, hipStream_t stream)
+int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, uint64_t n_genes,
+                     hipStream_t stream)
 {
   // the number of associations is only known on the device; it is of the order of the number of reads
   const uint64_t want = (n_reads + GI_THREADS - 1) / GI_THREADS;
+  if (n_genes > GI_TABLE) {
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+    hipLaunchKernelGGL(gene_hist_kernel<true>, dim3(grid), dim3(GI_THREADS), 0, stream, gene_ids, counters, skip_if_long ? 1u : 0u, gene_counts);
+    return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+  }
   const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 512 ? want : 512));
-  hipLaunchKernelGGL(gene_hist_kernel, dim3(grid), dim3(GI_THREADS), 0, stream, gene_ids, counters, skip_if_long ? 1u : 0u, gene_counts);
+  hipLaunchKernelGGL(gene_hist_kernel<false>, dim3(grid), dim3(GI_THREADS), 0, stream, gene_ids, counters, skip_if_long ? 1u : 0u, gene_counts);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

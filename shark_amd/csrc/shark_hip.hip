@@ -234,7 +234,7 @@ static int enqueue_tail(Ctx *ctx, Slot &s, bool skip_hist_if_long, bool count_ge
     p.gene_ids = s.d_gene_ids;
     if ((rc = launch_classify_general(ctx, p, true, n_waves, st))) return rc;
   }
-  if (count_genes && (rc = launch_gene_hist(s.d_gene_ids, s.d_counters, skip_hist_if_long, ctx->d_gene_counts, n, st))) return rc;
+  if (count_genes && (rc = launch_gene_hist(s.d_gene_ids, s.d_counters, skip_hist_if_long, ctx->d_gene_counts, n, ctx->n_records, st))) return rc;
   // counters (and, for host batches, the associations) are stored into pinned host memory by a kernel: no copy-engine
   // command ever sits in this stream waiting for kernels (see publish_results_kernel)
   if (s.host_batch) {

@@ -259,7 +259,8 @@ int launch_classify_general(Ctx *ctx, const ClassifyParams &p, bool emit, unsign
 int launch_gather_inline(const uint32_t *count, const uint16_t *inl, const uint32_t *gene_off, uint16_t *gene_ids, uint64_t n,
                          const uint32_t *counters, hipStream_t stream);
 int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t gene_ids_cap, hipStream_t stream);
-int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, hipStream_t stream);
+int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, uint64_t n_genes,
+                     hipStream_t stream);
 int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
 int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
                            const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, const uint32_t *uni_flag, hipStream_t stream);
