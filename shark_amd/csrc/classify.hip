@@ -999,8 +999,10 @@ __global__ __launch_bounds__(GI_THREADS) void gene_hist_kernel(const uint16_t *_
       const bool pending = i < n;
       const uint32_t g = pending ? gene_ids[i] : 0xFFFFFFFFu;
       // (a lane adds for the lanes above it that hold the same gene -- neighbours in a read's list never do, reads of one gene do)
-      const uint32_t up = (uint32_t)__shfl_down((int)g, 1);
-      const bool first = lane_d == 0 || (uint32_t)__shfl_up((int)g, 1) != g;
+      // (both shuffles by every lane, outside any condition: a lane that sits out a shuffle hands its neighbour 0 -- with the second
+      //  one behind `lane_d == 0 ||`, lane 1 took lane 0 for gene 0 and a read of gene 0 there went uncounted)
+      const uint32_t up = (uint32_t)__shfl_down((int)g, 1), down = (uint32_t)__shfl_up((int)g, 1);
+      const bool first = lane_d == 0 || down != g;
       // length of the run of equal genes that starts here (within the wave)
       const unsigned long long differs = __ballot(up != g) | (1ull << 63);
       if (pending && first) atomicAdd(&gene_counts[g], (unsigned long long)(__builtin_ctzll(differs >> lane_d) + 1));

@@ -659,6 +659,32 @@ def test_full_size_config2_equals_the_oracle(oracle):
     h.close()
 
 
+@pytest.mark.parametrize("n_genes", [40, 3000, 6000])
+def test_gene_counts_equal_the_histogram_of_the_gene_lists(n_genes):
+    """per-gene assigned-read counters (gene_hist_kernel): the histogram of the batch's gene ids, whatever the number of genes --
+    few (every workgroup's LDS table holds them all), and thousands (runs of equal genes combined in the wave, added to the counters
+    directly); reads drawn from consecutive genes so that neighbouring reads often share a gene; two batches accumulate."""
+    from shark_amd.capi import hip_memcpy_dtoh
+    from shark_amd import synth as dsynth
+    genes = dsynth.make_gencode_like_reference(n_genes)
+    h = _hip(k=17, c=0.6, bf_bits=1 << 31)
+    h.build([g.tobytes() for g in genes])
+    dev = torch.device("cuda:0")
+    n = 300_000
+    want = np.zeros(65536, np.uint64)
+    for seed in (5, 6):
+        b = dsynth.make_pairs_device(n, genes[:64] if seed == 6 else genes, dev, seed=seed, on_target=0.9)
+        r = h.classify_device(n, b["seq1"].data_ptr(), b["off1"].data_ptr(), b["seq2"].data_ptr(), b["off2"].data_ptr(), 0, 0, max_read_len=150)
+        gids = np.empty(int(r.n_assoc), np.uint16)
+        hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+        assert len(gids) > n // 2
+        want += np.bincount(gids, minlength=65536).astype(np.uint64)
+        got = h.gene_counts(65536)
+        bad = np.flatnonzero(want != got)
+        assert len(bad) == 0, (n_genes, seed, len(bad), int(bad[0]), int(want[bad[0]]), int(got[bad[0]]))
+    h.close()
+
+
 def test_gene_counts_allreduce_over_rccl(oracle, tmp_path, monkeypatch):
     """the sharded run's one exchange step: RCCL all-reduce of the per-gene counters (forced on with one GPU),
     through the ABI and through `shark --gene-counts`"""
