@@ -695,6 +695,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[2] / configs[4] workloads")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-trimmed", action="store_true", help="skip the trimmed-batch leg (its launches include no-op launches of the headline kernel: "
+                                                              "a kernel trace of the run then averages them in)")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the shark command line")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (committed counters are used when they match)")
     ap.add_argument("--cli-pairs", type=int, default=16_000_000)
@@ -835,7 +837,7 @@ def main():
     # ---- trimmed samples on the headline index: the first chunk with a share of its mates cut to 100-150 bases (rank 0, N = 1) -----
     # (reads of any length in one stream, FastqSplitter.hpp:47-93; DESIGN.md 3: sorted by length on the device, classified class by class)
     trimmed = None
-    if world == 1 and not args.no_configs and L == 150 and batches:
+    if world == 1 and not args.no_configs and not args.no_trimmed and L == 150 and batches:
         log("trimmed batches")
         trimmed = {"what": "the headline workload's first %d pairs with a share of the mates cut to a random length in [100, 150] (offsets from HBM: the device "
                            "decides what the batch is); ms per launch = the classify launches + the passes over the offsets in front of them "

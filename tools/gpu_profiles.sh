@@ -8,7 +8,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 2 --warmup 1 --reps-per-step 4 --no-cpu-baseline --no-boundary --no-cli --no-live-counters > $OUT/kt.json 2> $OUT/kt.err || { tail -5 $OUT/kt.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 2 --warmup 1 --reps-per-step 4 --no-cpu-baseline --no-boundary --no-cli --no-live-counters --no-trimmed > $OUT/kt.json 2> $OUT/kt.err || { tail -5 $OUT/kt.err; exit 1; }
 # keep only the stats summary of the trace (the per-dispatch CSVs are large)
 find $OUT/kt -name "*_kernel_trace.csv" -delete
 # a trimmed batch (20 % of the mates cut to 100-150 bases): the passes over the offsets and the class-by-class instantiation
