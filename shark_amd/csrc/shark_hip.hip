@@ -299,16 +299,23 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   //  this path are left out, 2 % of such a batch; should it be ragged after all, the ragged instantiation takes it, and the next one
   //  comes here again)
   const bool stream_is_uniform = uni_mode == UNI_ASK_DEVICE && ctx->last_verdict == 2u && !ctx->env_cls_always;
-  const bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && classes != 0 && classes <= (1ull << 20) &&
-                          n < (1ull << 31) && ctx->env_cls_min_fill != 0 && !stream_is_uniform;
+  bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && classes != 0 && classes <= (1ull << 20) &&
+                    n < (1ull << 31) && ctx->env_cls_min_fill != 0 && !stream_is_uniform;
   // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
   // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
   const bool with_plans = table_kernel && uni_mode != UNI_YES && classes != 0 && classes <= (1ull << 20);
   if (by_classes) {
-    if ((rc = ensure_capacity(ctx, &s.d_cls_entries, &s.cap_cls_entries, (size_t)(2 * n)))) return rc;
-    if ((rc = ensure_capacity(ctx, &s.d_cls_list, &s.cap_cls_list, (size_t)classes))) return rc;
-    if ((rc = ensure_capacity(ctx, &s.d_cls_hist, &s.cap_cls_hist, (size_t)(2 * classes)))) return rc;
-    if (!s.d_cls_share) SHK_HIP(ctx, hipMalloc((void **)&s.d_cls_share, CLS_SHARES * sizeof(uint32_t)));
+    // (32 bytes per pair of extra HBM: a device too full for them classifies the batch with the ragged instantiation instead)
+    if (ensure_capacity(ctx, &s.d_cls_entries, &s.cap_cls_entries, (size_t)(2 * n)) != SHK_OK ||
+        ensure_capacity(ctx, &s.d_cls_list, &s.cap_cls_list, (size_t)classes) != SHK_OK ||
+        ensure_capacity(ctx, &s.d_cls_hist, &s.cap_cls_hist, (size_t)(2 * classes)) != SHK_OK ||
+        (!s.d_cls_share && hipMalloc((void **)&s.d_cls_share, CLS_SHARES * sizeof(uint32_t)) != hipSuccess)) {
+      (void)hipGetLastError();
+      ctx->last_error.clear();
+      by_classes = false;
+    }
+  }
+  if (by_classes) {
     s.p.cls_entries = s.d_cls_entries;
     s.p.cls_list = s.d_cls_list;
     s.p.cls_share_first = s.d_cls_share;
