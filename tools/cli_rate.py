@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end rate of the `shark` CLI (FASTQ files in, ssv + FASTQ files out) on synthetic 2x150 bp pairs.
-usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var, GZ=1 (the sample files gzip -1 compressed: the inflate-bound path), RUN_ENVS="V=1;V=3" (the same files once per setting)"""
+usage: python tools/cli_rate.py [pairs] [extra shark args...]     env: ON_TARGET (default 0.02), CLI_T (e.g. "16,64,128"), HEADERS=var, GZ=1 (the sample files gzip -1 compressed: the inflate-bound path), RUN_ENVS="V=1;V=3" (the same files once per setting), TRIM=0.2 (that share of each mate file's reads cut to 100-150 bases)"""
 import json, os, subprocess, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +19,7 @@ open(os.path.join(td, "g.fa"), "wb").write(b">gene0\n" + gene.tobytes() + b"\n")
 
 
 VAR = os.environ.get("HEADERS", "fixed") == "var"   # read names without zero padding: records of several widths (the general reader)
+TRIM = float(os.environ.get("TRIM", "0"))           # share of the pairs cut to 100-150 bases (both mates alike)
 
 
 def write_fastq(path, mate):
@@ -45,6 +46,14 @@ def write_fastq(path, mate):
             rec[:, H + L] = 10; rec[:, H + L + 1] = ord("+"); rec[:, H + L + 2] = 10
             rec[:, H + L + 3:H + 2 * L + 3] = ord("I")
             rec[:, H + 2 * L + 3] = 10
+            if TRIM > 0:
+                # a share of the reads cut to a random length in [100, 150]: records of mixed widths (a trimmed sample)
+                ln = np.where(prng.random(m) < TRIM, prng.integers(100, L + 1, size=m), L)
+                col = np.arange(W)[None, :]
+                keep = (col < H + ln[:, None]) | ((col >= H + L) & (col < H + L + 3 + ln[:, None])) | (col == W - 1)
+                rec[keep].tofile(f)
+                b0 += m
+                continue
             rec.tofile(f)
             b0 += m
 
