@@ -689,6 +689,7 @@ class ParallelGunzip {
  private:
   struct Chunk {
     std::atomic<int> start_known{0};     // 0 = still searching, 1 = start_bit valid, -1 = no block start found in its territory
+    std::atomic<int> search_state{0};    // 0 = nobody has searched its block start yet, 1 = somebody has or is at it
     uint64_t start_bit = 0;
     bool clean_start = false;            // starts at a member's first block: no window in front of it
     bool absorbed = false;               // the chunk in front of it did not arrive at start_bit: it inflated this territory itself
@@ -745,15 +746,39 @@ class ParallelGunzip {
     gzp::Inflater z, t;      // this thread's decoder and its search decoder: their buffers are reused from chunk to chunk
     for (;;) {
       size_t i;
+      bool inflate;
       {
         std::unique_lock<std::mutex> l(m_);
-        // not too far ahead of the consumer: every chunk in flight holds tens of megabytes of symbols
-        cv_.wait(l, [&] { return quit_ || next_chunk_ >= n_chunks_ || next_chunk_ < consume_ + threads_ + 4; });
+        // Inflating runs not too far ahead of the consumer: every chunk in flight holds tens of megabytes of symbols.  SEARCHING a
+        // chunk's block start costs no memory and has no such limit: a worker the limit keeps from inflating searches ahead -- and it
+        // has to: a chunk that inflates through a stretch without block starts (a member of fixed-Huffman or stored blocks) waits
+        // for the verdict of every chunk on its way, however far ahead of the consumer that is (with the searches tied to the
+        // inflating, 24 such chunks of 64 KiB were a deadlock).
+        cv_.wait(l, [&] { return quit_ || next_chunk_ >= n_chunks_ || next_chunk_ < consume_ + threads_ + 4 || next_search_ < n_chunks_; });
         if (quit_ || next_chunk_ >= n_chunks_) return;
-        i = next_chunk_++;
+        inflate = next_chunk_ < consume_ + threads_ + 4;
+        if (inflate) i = next_chunk_++;
+        else i = next_search_++;
       }
-      run_chunk(i, z, t);
+      if (inflate) run_chunk(i, z, t);
+      else search_chunk(i, t);
     }
+  }
+
+  // the block start of chunk i, by whoever comes first (a worker about to inflate it, or one searching ahead)
+  void search_chunk(size_t i, gzp::Inflater &t)
+  {
+    Chunk &c = *ch_[i];
+    int expected = 0;
+    if (i == 0 || !c.search_state.compare_exchange_strong(expected, 1)) return;
+    const uint64_t t0 = thread_ns();
+    uint64_t bit = 0;
+    const bool found = find_block(t, i * CHUNK, std::min(n_, (i + 1) * CHUNK), bit);
+    c.start_bit = bit;
+    c.start_known.store(found ? 1 : -1, std::memory_order_release);
+    ns_search_ += thread_ns() - t0;
+    std::lock_guard<std::mutex> l(m_);
+    cv_.notify_all();
   }
 
   void finish(Chunk &c)
@@ -801,17 +826,16 @@ class ParallelGunzip {
   {
     Chunk &c = *ch_[i];
     uint64_t t0 = thread_ns();
-    // 1. where it starts
+    // 1. where it starts (searched here, unless a worker searching ahead has done it or is at it)
     if (i > 0) {
-      uint64_t bit = 0;
-      const bool found = find_block(t, i * CHUNK, std::min(n_, (i + 1) * CHUNK), bit);
-      c.start_bit = bit;
-      c.start_known.store(found ? 1 : -1, std::memory_order_release);
-      ns_search_ += thread_ns() - t0;
-      {
-        std::lock_guard<std::mutex> l(m_);
-        cv_.notify_all();
+      search_chunk(i, t);
+      int k;
+      while ((k = c.start_known.load(std::memory_order_acquire)) == 0) {
+        std::unique_lock<std::mutex> l(m_);
+        if (quit_) return;
+        cv_.wait_for(l, std::chrono::milliseconds(1));
       }
+      const bool found = k == 1;
       if (!found) {
         // nothing to start from in its territory (a long stored block, the tail of the file): the chunk in front inflates through it
         std::unique_lock<std::mutex> l(m_);
@@ -929,7 +953,7 @@ class ParallelGunzip {
   std::vector<std::thread> th_;
   std::mutex m_;
   std::condition_variable cv_;
-  size_t next_chunk_ = 0, consume_ = 0;
+  size_t next_chunk_ = 0, consume_ = 0, next_search_ = 1;
   bool handed_ = false, quit_ = false;
   std::vector<std::pair<char *, size_t>> pool_;       // byte buffers given back by the consumer (guarded by m_)
   std::atomic<uint64_t> ns_search_{0}, ns_pass1_{0}, ns_pass2_{0};

@@ -273,7 +273,8 @@ def _fastq_text(rng, n, L=150, real_names=True):
     return b"".join(out)
 
 
-@pytest.mark.parametrize("shape", ["gzip_-1", "gzip_-6", "gzip_-9", "gzip_multi_member", "stored_member_in_the_middle", "synthetic_names_constant_quality"])
+@pytest.mark.parametrize("shape", ["gzip_-1", "gzip_-6", "gzip_-9", "gzip_multi_member", "stored_member_in_the_middle", "synthetic_names_constant_quality",
+                                   "huffman_only", "fixed_huffman_member"])
 def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
     """every chunking (chunks of 64 KiB ... 1 MiB of compressed bytes: hundreds of block searches, windows handed from chunk to
     chunk) and every thread count gives exactly the bytes zlib gives: the levels gzip writes, several members in one file (a new
@@ -292,6 +293,16 @@ def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
     elif shape == "gzip_multi_member":
         cut = [0, len(text) // 5, len(text) // 5 + 1, len(text) // 2, len(text)]
         open(path, "wb").write(b"".join(gzip.compress(text[a:b], compresslevel=lv) for a, b, lv in zip(cut, cut[1:], (6, 1, 9, 4))))
+    elif shape == "huffman_only":
+        # literals only: every block is a dynamic block WITHOUT distance codes (the decoder's run-of-literals table does all the work,
+        # and the end-of-block symbol arrives in a block that has no distance table)
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_HUFFMAN_ONLY)
+        open(path, "wb").write(co.compress(text) + co.flush())
+    elif shape == "fixed_huffman_member":
+        # a member of fixed-Huffman blocks (Z_FIXED) between two ordinary ones
+        a, b = len(text) // 3, 2 * len(text) // 3
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+        open(path, "wb").write(gzip.compress(text[:a], 6) + co.compress(text[a:b]) + co.flush() + gzip.compress(text[b:], 1))
     elif shape == "stored_member_in_the_middle":
         a, b = len(text) // 3, len(text) // 3 + 600_000
         open(path, "wb").write(gzip.compress(text[:a], 6) + gzip.compress(text[a:b], 0) + gzip.compress(text[b:], 6))
