@@ -274,7 +274,7 @@ def _fastq_text(rng, n, L=150, real_names=True):
 
 
 @pytest.mark.parametrize("shape", ["gzip_-1", "gzip_-6", "gzip_-9", "gzip_multi_member", "stored_member_in_the_middle", "synthetic_names_constant_quality",
-                                   "huffman_only", "fixed_huffman_member"])
+                                   "huffman_only", "fixed_huffman_member", "stored_only", "sync_flush_points"])
 def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
     """every chunking (chunks of 64 KiB ... 1 MiB of compressed bytes: hundreds of block searches, windows handed from chunk to
     chunk) and every thread count gives exactly the bytes zlib gives: the levels gzip writes, several members in one file (a new
@@ -303,6 +303,13 @@ def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
         a, b = len(text) // 3, 2 * len(text) // 3
         co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
         open(path, "wb").write(gzip.compress(text[:a], 6) + co.compress(text[a:b]) + co.flush() + gzip.compress(text[b:], 1))
+    elif shape == "stored_only":
+        # no block start anywhere: the first chunk inflates the whole file, every other chunk's search comes back empty
+        open(path, "wb").write(gzip.compress(text, 0))
+    elif shape == "sync_flush_points":
+        # Z_SYNC_FLUSH every 300 000 bytes: empty stored blocks, byte-aligned block starts
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        open(path, "wb").write(b"".join(co.compress(text[i:i + 300000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(text), 300000)) + co.flush())
     elif shape == "stored_member_in_the_middle":
         a, b = len(text) // 3, len(text) // 3 + 600_000
         open(path, "wb").write(gzip.compress(text[:a], 6) + gzip.compress(text[a:b], 0) + gzip.compress(text[b:], 6))
