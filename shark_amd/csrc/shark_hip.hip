@@ -268,7 +268,7 @@ static void note_verdict(Ctx *ctx, uint32_t v)
 // all kernels of one batch whose inputs are (or will be, in stream order) resident in HBM; batch pointers are device
 // pointers.  Returns with the work enqueued on ctx->stream; finish_classify() completes the rare slow paths.
 enum UniMode {
-  UNI_ASK_DEVICE = 0,  // lengths unknown on the host: uniform_check_kernel decides, both kernels are launched, one returns at once
+  UNI_ASK_DEVICE = 0,  // lengths unknown on the host: the device decides (uniform / ragged / by classes), every candidate kernel is launched, all but one return at once
   UNI_YES = 1,         // the host has seen the offsets: one length per mate (uni_L1, uni_L2), and such a read fits
   UNI_NO = 2
 };
