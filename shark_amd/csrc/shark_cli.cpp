@@ -154,6 +154,9 @@ const OptionRow OPTION_TABLE[] = {
 // records, estimated from the first record of a plain file.
 inline uint64_t auto_batch(const std::string &sample1, uint64_t fallback)
 {
+  // (a regular file only: reading the head of a pipe would take it away from the reader)
+  struct stat st;
+  if (stat(sample1.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return fallback;
   FILE *f = fopen(sample1.c_str(), "rb");
   if (!f) return fallback;
   std::vector<char> head(1u << 16);
