@@ -198,6 +198,9 @@ class FastqMmap {   // (historic name: the window is now filled with parallel pr
  public:
   explicit FastqMmap(const std::string &path, unsigned threads) : threads_(threads)
   {
+    // (a pipe is not even opened here: the open would wait for its writer and, closed again, break it)
+    struct stat st0;
+    if (stat(path.c_str(), &st0) != 0 || !S_ISREG(st0.st_mode)) return;
     fd_ = ::open(path.c_str(), O_RDONLY);
     if (fd_ < 0) return;
     struct stat st;

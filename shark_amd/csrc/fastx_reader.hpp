@@ -41,10 +41,23 @@ namespace shk {
 //     buffered, so that inflating overlaps parsing.
 // seek() (uncompressed offsets; used when the block reader hands a plain file over) restarts the read-ahead.
 // ---------------------------------------------------------------------------
+// A sample may be a pipe (`-1 <(zcat a.fq.gz)`: the reference's gzopen reads those too): whatever is read from a pipe is gone, and a
+// second open waits for a writer that never comes -- so only regular files are looked into ahead of the reader, or opened twice.
+inline bool regular_file(const std::string &path)
+{
+  struct stat st;
+  return stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
 class InflateAhead {
  public:
   explicit InflateAhead(const std::string &path, unsigned bgzf_threads = 4) : path_(path), bgzf_threads_(bgzf_threads ? bgzf_threads : 1)
   {
+    regular_ = regular_file(path);
+    if (!regular_) {       // straight to zlib's gzread, which takes gzip and plain text alike, opened once
+      ok_ = start(0);
+      return;
+    }
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return;
     unsigned char h[18];
@@ -95,7 +108,7 @@ class InflateAhead {
     fallback_gz_ = false;   // (a restart reads the file from `off` again: whatever made the last pass fall back is met again)
     full_[0] = full_[1] = false;
     pg_.reset();
-    if (!bgzf_ && off == 0 && !getenv("SHARK_GZ_SERIAL")) {
+    if (regular_ && !bgzf_ && off == 0 && !getenv("SHARK_GZ_SERIAL")) {
       // ordinary gzip: the parallel two-pass inflate when the file qualifies (a gzip member of text, more than a few chunks)
       pg_.reset(new ParallelGunzip(path_, bgzf_threads_));
       if (pg_->usable()) return true;
@@ -247,7 +260,7 @@ class InflateAhead {
   std::string path_;
   unsigned bgzf_threads_;
   std::unique_ptr<ParallelGunzip> pg_;   // ordinary gzip, inflated in parallel (then none of the members below is in use)
-  bool bgzf_ = false, ok_ = false, fallback_gz_ = false;
+  bool bgzf_ = false, ok_ = false, fallback_gz_ = false, regular_ = true;
   gzFile gz_ = nullptr;
   FILE *raw_ = nullptr;
   std::vector<char> buf_[2], cbuf_;

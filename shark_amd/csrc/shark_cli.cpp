@@ -1067,6 +1067,13 @@ int main(int argc, char *argv[])
   // sample that cannot be opened is reported before any work is done
   for (const std::string *path : {&opt.sample1_path, &opt.sample2_path}) {
     if (path->empty()) continue;
+    // (a pipe is not opened for the check: it can be opened once.  access() says whether it may be read.)
+    struct stat st;
+    if (stat(path->c_str(), &st) == 0 && !S_ISREG(st.st_mode) && !S_ISDIR(st.st_mode)) {
+      if (access(path->c_str(), R_OK) == 0) continue;
+      std::cerr << "shark: cannot open the sample " << *path << std::endl;
+      return EXIT_FAILURE;
+    }
     FILE *f = fopen(path->c_str(), "rb");
     if (!f) {
       std::cerr << "shark: cannot open the sample " << *path << std::endl;
@@ -1164,7 +1171,10 @@ int main(int argc, char *argv[])
 
     // ---- the parallel feed -------------------------------------------------------
     shk::BatchTable tab1, tab2;
-    bool parallel_feed = !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");
+    // (the parallel feeds look into the sample files, read them twice and seek in them: regular files only -- a pipe goes to the
+    //  serial reader, which opens it once and keeps names and qualities in memory)
+    const bool samples_are_files = shk::regular_file(opt.sample1_path) && (!opt.paired_flag || shk::regular_file(opt.sample2_path));
+    bool parallel_feed = samples_are_files && !getenv("SHARK_SERIAL_READER") && !getenv("SHARK_SINGLE_SPLITTER");
     // compressed samples (gzip magic in both mate files): inflated in parallel, cut and parsed from memory (GzCutter above);
     // SHARK_GZ_SERIAL_PARSE=1: the serial kseq-rule reader behind the inflaters, as in round 3 (the tests run both)
     auto is_gzip = [](const std::string &path) {

@@ -294,6 +294,52 @@ def test_cli_example_byte_identical(example_dir, tmp_path, extra):
     assert b"[shark/Association done] Time elapsed" in r.stderr
 
 
+@pytest.mark.parametrize("gz", [False, True])
+def test_cli_reads_samples_from_named_pipes(example_dir, tmp_path, gz):
+    """the reference opens its samples with gzopen, which reads pipes as well as files (`-1 <(zcat a.fq.gz)`): nothing in front of
+    the reader may look into a pipe (two bytes taken to see whether it is gzip, or 64 KiB to guess the batch size, would be gone),
+    and everything that wants to seek has to stand back.  The bundled example through two named pipes, plain and compressed:
+    the truth files byte for byte."""
+    import gzip
+    import threading
+    fifos = []
+    feeders = []
+    for m in (1, 2):
+        data = open(os.path.join(example_dir, "sample_%d.fq" % m), "rb").read()
+        if gz:
+            data = gzip.compress(data, 6)
+        path = str(tmp_path / ("pipe_%d" % m))
+        os.mkfifo(path)
+        fifos.append(path)
+
+        def feed(path=path, data=data):
+            with open(path, "wb") as f:      # (blocks until the command opens the pipe)
+                f.write(data)
+        t = threading.Thread(target=feed, daemon=True)
+        t.start()
+        feeders.append(t)
+    o1, o2 = tmp_path / "o1.fq", tmp_path / "o2.fq"
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shark_amd", "bin", "shark")
+    try:
+        r = subprocess.run([exe, "-r", os.path.join(example_dir, "ENSG00000277117.fa"), "-1", fifos[0], "-2", fifos[1], "-o", str(o1), "-p", str(o2)],
+                           cwd=str(tmp_path), capture_output=True, timeout=90)
+    except subprocess.TimeoutExpired:
+        for path in fifos:      # (release feeders that nobody has opened for)
+            try:
+                fd = os.open(path, os.O_RDONLY | os.O_NONBLOCK)
+                os.close(fd)
+            except OSError:
+                pass
+        pytest.fail("shark did not finish on named pipes (a second open of a pipe waits for a writer that never comes)")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for t in feeders:
+        t.join(timeout=30)
+    assert r.stdout == open(os.path.join(example_dir, "ENSG00000277117.truth.ssv"), "rb").read()
+    assert o1.read_bytes() == open(os.path.join(example_dir, "sharked.sample_1.truth.fq"), "rb").read()
+    assert o2.read_bytes() == open(os.path.join(example_dir, "sharked.sample_2.truth.fq"), "rb").read()
+
+
 def test_cli_matches_oracle_cli_on_options(oracle, tmp_path):
     """-q / -s / -k / single-end / gz / multi-gene with the numbering quirk: the HIP CLI and the oracle CLI
     must print the same bytes (ssv on stdout, FASTQ files)"""
