@@ -880,16 +880,21 @@ def test_cli_filter_size_not_a_power_of_two(oracle, bf_bits):
 # ---------------------------------------------------------------------------
 # the pipelined boundary (shk_classify_submit / shk_classify_wait) and the paths without a host round trip
 # ---------------------------------------------------------------------------
-def test_pipelined_submit_wait_equals_oracle(oracle):
+@pytest.mark.parametrize("trimmed", [False, True])
+def test_pipelined_submit_wait_equals_oracle(oracle, monkeypatch, trimmed):
     """PIPE_DEPTH batches in flight; every batch equals the oracle; tickets are waited in order; a fourth
-    outstanding submit is refused; gene counters equal the histogram over all batches"""
+    outstanding submit is refused; gene counters equal the histogram over all batches.  `trimmed`: most batches of mixed read
+    lengths, and every one of them sorted by length and classified class by class (SHK_CLS_MIN_FILL=1) -- three of those in
+    flight, each with its own lists, beside uniform batches"""
     from shark_amd import SharkHipError
     from shark_amd.capi import SHK_PIPE_DEPTH
+    if trimmed:
+        monkeypatch.setenv("SHK_CLS_MIN_FILL", "1")
     rng = np.random.default_rng(31)
     genes = synth.make_genes(rng, 20, 300, 1500, share_every=3)
     o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 24)
     batches = [synth.make_reads(rng, genes, 700 + 200 * i, read_len=150 if i % 2 == 0 else 100, paired=True, on_target=0.7,
-                                var_len=(i == 3)) for i in range(7)]
+                                var_len=(i == 3) or (trimmed and i != 4)) for i in range(7)]
     batches.append(synth.batch_from_lists([], []))                     # an empty batch in the middle of a stream
     batches.append(synth.make_reads(rng, genes, 300, read_len=80, paired=False, on_target=0.7))
     want = [o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"]) if len(b["off1"]) > 1 else (np.zeros(1, np.uint32), np.zeros(0, np.uint16))
@@ -908,6 +913,8 @@ def test_pipelined_submit_wait_equals_oracle(oracle):
         assert np.array_equal(wg, gg) and np.array_equal(wi, gi)
     allids = np.concatenate([w[1] for w in want])
     assert np.array_equal(h.gene_counts(32), np.bincount(allids, minlength=32)[:32].astype(np.uint64))
+    if trimmed and h.probe_mode() == "lds-table":
+        assert "verdict=" in h.last_kernel(), h.last_kernel()
 
 
 def test_more_associations_than_reserved(oracle):
