@@ -294,16 +294,19 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   // the device and classified class by class (classify_uni_kernel's CLS instantiation) -- when the classes are few enough for
   // the histogram (the caller's bound on the read length says) and, the device decides, full enough; also when the host knows
   // the batch is ragged: it has not counted
-  const uint64_t classes = (table_kernel && uni_L1) ? ((uint64_t)uni_L1 + 1) * ((uint64_t)(b->seq2 ? uni_L2 : 0) + 1) : 0;
+  // ((l1, l2) tables -- the classes' counters, the ragged instantiation's plans -- are sized by the caller's bound on the read length,
+  //  2^20 entries at most and when there is no bound or a loose one; the device checks the batch's longest mates against them)
+  const uint64_t hint_classes = uni_L1 ? ((uint64_t)uni_L1 + 1) * ((uint64_t)(b->seq2 ? uni_L2 : 0) + 1) : 0;
+  const uint64_t classes = table_kernel ? std::min<uint64_t>(hint_classes ? hint_classes : (1ull << 20), 1ull << 20) : 0;
   // (a batch only the device can judge, in a stream whose last batch was uniform -- a sequencer's output --: the four launches of
   //  this path are left out, 2 % of such a batch; should it be ragged after all, the ragged instantiation takes it, and the next one
   //  comes here again)
   const bool stream_is_uniform = uni_mode == UNI_ASK_DEVICE && ctx->last_verdict == 2u && !ctx->env_cls_always;
-  bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && classes != 0 && classes <= (1ull << 20) &&
-                    n < (1ull << 31) && ctx->env_cls_min_fill != 0 && !stream_is_uniform;
+  bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && n < (1ull << 31) && ctx->env_cls_min_fill != 0 &&
+                    !stream_is_uniform;
   // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
   // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
-  const bool with_plans = table_kernel && uni_mode != UNI_YES && classes != 0 && classes <= (1ull << 20);
+  const bool with_plans = table_kernel && uni_mode != UNI_YES;
   if (by_classes) {
     // (32 bytes per pair of extra HBM: a device too full for them classifies the batch with the ragged instantiation instead)
     if (ensure_capacity(ctx, &s.d_cls_entries, &s.cap_cls_entries, (size_t)(2 * n)) != SHK_OK ||

@@ -1096,7 +1096,10 @@ def test_class_path_follows_the_stream(oracle):
         og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"], None, None)
         t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in bt.items()}
         torch.cuda.synchronize()
-        r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), 0, 0, max_read_len=L)
+        # (the caller's bound on the read length: tight, or none -- the (l1, l2) tables are then 2^20 entries and the device checks
+        #  the batch's longest mates against them)
+        bound = (L, 0)[len(said) % 2]
+        r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), 0, 0, max_read_len=bound)
         goff = np.empty(n + 1, np.uint32)
         hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
         gids = np.empty(int(r.n_assoc), np.uint16)
