@@ -305,7 +305,8 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   bool by_classes = table_kernel && uni_mode != UNI_YES && class_kernel_available(ctx, max_slots) && n < (1ull << 31) && ctx->env_cls_min_fill != 0 &&
                     !stream_is_uniform;
   // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
-  // a resident batch; 0 = no bound: no table, every read computes its plan).  Cleared per launch, filled by the kernel.
+  // a resident batch; no bound, or a loose one: 2^20 entries, of which the batch's own longest mates decide how many are used).
+  // Cleared per launch, filled by the kernel.
   const bool with_plans = table_kernel && uni_mode != UNI_YES;
   if (by_classes) {
     // (32 bytes per pair of extra HBM: a device too full for them classifies the batch with the ragged instantiation instead)
