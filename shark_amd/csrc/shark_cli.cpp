@@ -64,6 +64,8 @@ const char *USAGE_MESSAGE =
     "\n"
     "MI355X build only:\n"
     "          --gpus N                      number of GPUs to shard the reads over (default:1)\n"
+    "          --devices LIST                the devices of the N workers, comma separated (default:0,1,...,N-1; a device may be\n"
+    "                                        named more than once: several workers then share it)\n"
     "          --batch N                     reads per device batch (default:65536, up to 262144 for large plain samples)\n"
     "          --gene-counts FILE            write <gene> <assigned reads> per gene (summed over the GPUs with RCCL)\n"
     "      -t N also sets the number of host threads that parse FASTQ / format output (default: up to 16)\n";
@@ -78,6 +80,8 @@ struct Options {
   bool single = false, verbose = false;
   int nThreads = 1;
   int gpus = 1;
+  bool gpus_given = false;
+  std::vector<int> devices;     // --devices: worker g runs on devices[g] (empty: worker g on device g)
   uint64_t batch = 1u << 16;
   bool batch_given = false;     // (--batch; otherwise the sample's size decides: auto_batch below)
   std::string gene_counts_path;
@@ -141,7 +145,22 @@ const OptionRow OPTION_TABLE[] = {
     {'s', "single", false, [](Options &o, const char *) { o.single = true; }},
     {'v', "verbose", false, [](Options &o, const char *) { o.verbose = true; }},
     {'h', "help", false, [](Options &, const char *) { std::cerr << USAGE_MESSAGE; exit(EXIT_SUCCESS); }},
-    {1000, "gpus", true, [](Options &o, const char *v) { o.gpus = std::max(1, value_of<int>(v)); }},
+    {1000, "gpus", true, [](Options &o, const char *v) { o.gpus = std::max(1, value_of<int>(v)); o.gpus_given = true; }},
+    {1003, "devices", true,
+     [](Options &o, const char *v) {
+       // a list of non-negative device numbers; anything else is refused (a typo must not silently become device 0)
+       o.devices.clear();
+       const std::string text = v ? v : "";
+       size_t at = 0;
+       while (at <= text.size()) {
+         const size_t comma = std::min(text.find(',', at), text.size());
+         const std::string item = text.substr(at, comma - at);
+         if (item.empty() || item.size() > 4 || item.find_first_not_of("0123456789") != std::string::npos)
+           reject("", "shark: --devices takes a comma separated list of device numbers.");
+         o.devices.push_back(atoi(item.c_str()));
+         at = comma + 1;
+       }
+     }},
     {1001, "batch", true, [](Options &o, const char *v) { o.batch = std::max<uint64_t>(1, value_of<uint64_t>(v)); o.batch_given = true; }},
     {1002, "gene-counts", true, [](Options &o, const char *v) { o.gene_counts_path = value_of<std::string>(v); }},
 };
@@ -206,6 +225,13 @@ Options parse_arguments(int argc, char **argv)
   }
   if (opt.out1_path.empty()) opt.out1_path = "sharked_sample.1";
   if (opt.out2_path.empty() && !opt.sample2_path.empty()) opt.out2_path = "sharked_sample.2";
+  // --devices alone says how many workers there are; with --gpus N it has to name N devices
+  if (!opt.devices.empty()) {
+    if (!opt.gpus_given) opt.gpus = (int)opt.devices.size();
+    if ((size_t)opt.gpus != opt.devices.size()) reject("", "shark: --devices must name as many devices as --gpus says.");
+  } else {
+    for (int g = 0; g < opt.gpus; ++g) opt.devices.push_back(g);
+  }
   return opt;
 }
 
@@ -1060,7 +1086,9 @@ int main(int argc, char *argv[])
     std::cerr << "shark (MI355X): reference " << opt.fasta_path << ", sample " << opt.sample1_path;
     if (opt.paired_flag) std::cerr << " + " << opt.sample2_path;
     std::cerr << "; k=" << opt.k << " c=" << opt.c << " q=" << opt.min_quality << (opt.single ? " single" : "") << " bf=" << (opt.bf_size >> 33)
-              << "GB gpus=" << opt.gpus << "\n" << std::endl;
+              << "GB gpus=" << opt.gpus << " devices=";
+    for (size_t g = 0; g < opt.devices.size(); ++g) std::cerr << (g ? "," : "") << opt.devices[g];
+    std::cerr << "\n" << std::endl;
   }
 
   // the reference opens its inputs unchecked (main.cpp:88-106) and then reads nothing from a file that is not there; here a
@@ -1102,7 +1130,8 @@ int main(int argc, char *argv[])
   std::thread ctx_thread([&] {
     for (int g = 0; g < n_gpus; ++g) {
       shk_params p{};
-      p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single; p.device = g;
+      p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single;
+      p.device = opt.devices[(size_t)g];   // worker g's device (--devices; the reference's N workers come from one command line too, main.cpp:219-223)
       const int rc = shk_create(&p, &ctxs[(size_t)g]);
       if (rc != SHK_OK) { ctx_rc = rc; ctx_bad = g; break; }
     }
@@ -1448,7 +1477,7 @@ int main(int argc, char *argv[])
       }
       if (ctx_rc != SHK_OK) {
         stop_feed();
-        std::cerr << "shark: cannot create a context on GPU " << ctx_bad << ": " << shk_strerror(ctx_rc) << std::endl;
+        std::cerr << "shark: cannot create a context on GPU " << opt.devices[(size_t)ctx_bad] << ": " << shk_strerror(ctx_rc) << std::endl;
         return EXIT_FAILURE;
       }
       shk::FastxRecord rec;
@@ -1674,6 +1703,14 @@ int main(int argc, char *argv[])
   if (opt.gene_counts_path != "" || (opt.verbose && n_gpus > 1)) {
     std::vector<uint64_t> totals(legend_ID.size() ? legend_ID.size() : 1, 0);
     const uint32_t ng = (uint32_t)std::min<size_t>(legend_ID.size(), 65536);
+    {
+      std::vector<int> distinct(opt.devices);
+      std::sort(distinct.begin(), distinct.end());
+      distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+      if (distinct.size() != opt.devices.size())
+        std::cerr << "shark: " << n_gpus << " workers on " << distinct.size() << " device(s): the per-gene counts of workers that share a device are "
+                  << "added on it" << (distinct.size() > 1 ? ", RCCL reduces over the distinct devices" : " (no collective)") << std::endl;
+    }
     const int rc = shk_gene_counts_allreduce(ctxs.data(), n_gpus, totals.data(), ng);
     if (rc != SHK_OK) {
       std::cerr << "shark: gene count reduction failed: " << shk_strerror(rc) << " " << shk_last_error(ctxs[0]) << std::endl;
@@ -1702,5 +1739,9 @@ int main(int argc, char *argv[])
   // statics, which costs more than a tenth of a second and changes nothing
   fflush(stdout);
   fflush(stderr);
+  // (a profiler or another preloaded tool writes its results from exit handlers: under one, leave the ordinary way)
+  for (const char *var : {"ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "SHARK_CLEAN_EXIT"})
+    if (const char *v = getenv(var))
+      if (v[0]) exit(0);
   _exit(0);
 }

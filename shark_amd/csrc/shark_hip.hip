@@ -924,7 +924,16 @@ int shk_gene_counts_reset(shk_ctx *ctx)
 // Both forms reduce INTO the contexts' separate totals buffers: the per-GPU counters stay local, so classifying more
 // reads and reducing again gives the totals again (not totals times the number of GPUs).
 
-// one process, several GPUs (one context per GPU): `shark --gpus N`
+// contexts that share a device: their counters are added on that device (RCCL takes a device once per communicator)
+__global__ void gene_counts_add_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+// one process, several contexts (`shark --gpus N [--devices ...]`): normally one context per GPU; contexts that share a GPU
+// (--devices 0,0: the N-context code paths rehearsed on one device) are summed on it first, and the collective runs over
+// the distinct devices' first contexts
 int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint32_t n)
 {
   if (!ctxs || n_ctx < 1 || n > 65536) return SHK_ERR_ARG;
@@ -935,50 +944,98 @@ int shk_gene_counts_allreduce(shk_ctx **ctxs, int n_ctx, uint64_t *totals, uint3
     SHK_HIP(ctxs[i], hipSetDevice(ctxs[i]->prm.device));
     SHK_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
   }
+  // leaders: the first context of every distinct device, in the order given
+  std::vector<int> leader_of((size_t)n_ctx, 0), leaders;
+  for (int i = 0; i < n_ctx; ++i) {
+    int l = -1;
+    for (int j : leaders)
+      if (ctxs[j]->prm.device == ctxs[i]->prm.device) { l = j; break; }
+    if (l < 0) { l = i; leaders.push_back(i); }
+    leader_of[(size_t)i] = l;
+  }
+  const int n_lead = (int)leaders.size();
+  const bool shared = n_lead != n_ctx;
+  const size_t bytes = 65536 * sizeof(unsigned long long);
+  if (shared) {
+    // per device: totals of the leader = sum of the counters of the contexts on it (the streams are idle: synchronised above)
+    for (int l : leaders) {
+      shk_ctx *lc = ctxs[l];
+      SHK_HIP(lc, hipSetDevice(lc->prm.device));
+      SHK_HIP(lc, hipMemcpyAsync(lc->d_gene_totals, lc->d_gene_counts, bytes, hipMemcpyDeviceToDevice, lc->stream));
+      for (int i = 0; i < n_ctx; ++i)
+        if (i != l && leader_of[(size_t)i] == l)
+          gene_counts_add_kernel<<<65536 / 256, 256, 0, lc->stream>>>(lc->d_gene_totals, ctxs[i]->d_gene_counts, 65536);
+      SHK_HIP(lc, hipGetLastError());
+      SHK_HIP(lc, hipStreamSynchronize(lc->stream));
+    }
+  }
   const char *force = getenv("SHK_FORCE_RCCL");
-  const unsigned long long *src = c0->d_gene_counts;
-  if (n_ctx > 1 || (force && force[0] == '1')) {
+  const unsigned long long *src = shared ? c0->d_gene_totals : c0->d_gene_counts;
+  if (n_lead > 1 || (force && force[0] == '1')) {
     RcclApi &api = rccl();
     if (!api.ok) { c0->last_error = "librccl.so.1 could not be loaded"; return SHK_ERR_HIP; }
-    std::vector<int> devs((size_t)n_ctx);
-    for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->prm.device;
-    // the communicators of a group of contexts are created once and live in the contexts
+    std::vector<int> devs((size_t)n_lead);
+    for (int i = 0; i < n_lead; ++i) devs[(size_t)i] = ctxs[leaders[(size_t)i]]->prm.device;
+    // the communicators of a group of contexts are created once and live in the (leading) contexts
     bool have = true;
-    for (int i = 0; i < n_ctx; ++i) have = have && ctxs[i]->group_comm && ctxs[i]->group_devs == devs;
+    for (int l : leaders) have = have && ctxs[l]->group_comm && ctxs[l]->group_devs == devs;
     if (!have) {
       for (int i = 0; i < n_ctx; ++i)
         if (ctxs[i]->group_comm) { (void)api.CommDestroy(ctxs[i]->group_comm); ctxs[i]->group_comm = nullptr; }
-      std::vector<rccl_comm_t> comms((size_t)n_ctx, nullptr);
-      const int init_rc = with_stdout_on_stderr([&] { return api.CommInitAll(comms.data(), n_ctx, devs.data()); });
+      std::vector<rccl_comm_t> comms((size_t)n_lead, nullptr);
+      const int init_rc = with_stdout_on_stderr([&] { return api.CommInitAll(comms.data(), n_lead, devs.data()); });
       if (init_rc != 0) { c0->last_error = "ncclCommInitAll failed"; return SHK_ERR_HIP; }
-      for (int i = 0; i < n_ctx; ++i) { ctxs[i]->group_comm = comms[(size_t)i]; ctxs[i]->group_devs = devs; }
+      for (int i = 0; i < n_lead; ++i) { ctxs[leaders[(size_t)i]]->group_comm = comms[(size_t)i]; ctxs[leaders[(size_t)i]]->group_devs = devs; }
       // RCCL sets its channels up on a communicator's FIRST collective (of the order of the whole reduction of 512 KiB, or more): one
-      // throw-away all-reduce of the totals buffers, so that the reduction a caller times is a steady-state one
+      // throw-away all-reduce (of a scratch-free kind: the totals buffers onto themselves, before they hold anything when no device is
+      // shared; with shared devices their sums are made again below), so that the reduction a caller times is a steady-state one
       int wrc = api.GroupStart();
-      for (int i = 0; i < n_ctx && wrc == 0; ++i) {
+      for (int i = 0; i < n_lead && wrc == 0; ++i) {
+        shk_ctx *lc = ctxs[leaders[(size_t)i]];
         (void)hipSetDevice(devs[(size_t)i]);
-        wrc = api.AllReduce(ctxs[i]->d_gene_totals, ctxs[i]->d_gene_totals, 65536, 5, 0, ctxs[i]->group_comm, ctxs[i]->stream);
+        wrc = api.AllReduce(lc->d_gene_totals, lc->d_gene_totals, 65536, 5, 0, lc->group_comm, lc->stream);
       }
       if (wrc == 0) wrc = api.GroupEnd();
-      for (int i = 0; i < n_ctx; ++i) {
+      for (int i = 0; i < n_lead; ++i) {
         (void)hipSetDevice(devs[(size_t)i]);
-        (void)hipStreamSynchronize(ctxs[i]->stream);
+        (void)hipStreamSynchronize(ctxs[leaders[(size_t)i]]->stream);
       }
       if (wrc != 0) { c0->last_error = "ncclAllReduce (warm-up) failed"; return SHK_ERR_HIP; }
+      if (shared) {   // the warm-up has overwritten the per-device sums: make them again
+        for (int l : leaders) {
+          shk_ctx *lc = ctxs[l];
+          SHK_HIP(lc, hipSetDevice(lc->prm.device));
+          SHK_HIP(lc, hipMemcpyAsync(lc->d_gene_totals, lc->d_gene_counts, bytes, hipMemcpyDeviceToDevice, lc->stream));
+          for (int i = 0; i < n_ctx; ++i)
+            if (i != l && leader_of[(size_t)i] == l)
+              gene_counts_add_kernel<<<65536 / 256, 256, 0, lc->stream>>>(lc->d_gene_totals, ctxs[i]->d_gene_counts, 65536);
+          SHK_HIP(lc, hipGetLastError());
+          SHK_HIP(lc, hipStreamSynchronize(lc->stream));
+        }
+      }
     }
     int rc = api.GroupStart();
-    for (int i = 0; i < n_ctx && rc == 0; ++i) {
+    for (int i = 0; i < n_lead && rc == 0; ++i) {
+      shk_ctx *lc = ctxs[leaders[(size_t)i]];
       (void)hipSetDevice(devs[(size_t)i]);
-      // ncclUint64 = 5, ncclSum = 0; 65 536 x 8 B per GPU
-      rc = api.AllReduce(ctxs[i]->d_gene_counts, ctxs[i]->d_gene_totals, 65536, 5, 0, ctxs[i]->group_comm, ctxs[i]->stream);
+      // ncclUint64 = 5, ncclSum = 0; 65 536 x 8 B per GPU (in place over the per-device sums when contexts share a device)
+      rc = api.AllReduce(shared ? lc->d_gene_totals : lc->d_gene_counts, lc->d_gene_totals, 65536, 5, 0, lc->group_comm, lc->stream);
     }
     if (rc == 0) rc = api.GroupEnd();
-    for (int i = 0; i < n_ctx; ++i) {
+    for (int i = 0; i < n_lead; ++i) {
       (void)hipSetDevice(devs[(size_t)i]);
-      (void)hipStreamSynchronize(ctxs[i]->stream);
+      (void)hipStreamSynchronize(ctxs[leaders[(size_t)i]]->stream);
     }
     if (rc != 0) { c0->last_error = "ncclAllReduce failed"; return SHK_ERR_HIP; }
     src = c0->d_gene_totals;
+  }
+  if (shared) {   // every context's totals buffer holds the totals, as with one context per device
+    for (int i = 0; i < n_ctx; ++i) {
+      const int l = leader_of[(size_t)i];
+      if (l == i) continue;
+      SHK_HIP(ctxs[i], hipSetDevice(ctxs[i]->prm.device));
+      SHK_HIP(ctxs[i], hipMemcpy(ctxs[i]->d_gene_totals, ctxs[l]->d_gene_totals, bytes, hipMemcpyDeviceToDevice));
+    }
   }
   if (totals) {
     SHK_HIP(c0, hipSetDevice(c0->prm.device));
