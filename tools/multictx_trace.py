@@ -19,7 +19,7 @@ genes = synth.make_genes(rng, 40, 600, 3000, share_every=3)
 _write_fasta(td / "g.fa", genes)
 f1, f2 = _write_pairs(td, rng, genes, pairs, 100, 0.4)
 exe = os.path.join(root, "shark_amd", "bin", "shark")
-common = ["-r", str(td / "g.fa"), "-1", f1, "-2", f2, "-t", "8", "--batch", "20000"]
+common = ["-r", str(td / "g.fa"), "-1", f1, "-2", f2, "-t", "8", "--batch", os.environ.get("TRACE_BATCH", "20000")]
 one = subprocess.run([exe] + common + ["-o", str(td / "a1"), "-p", str(td / "a2"), "--gpus", "1"], capture_output=True)
 assert one.returncode == 0, one.stderr.decode()[-2000:]
 prof = out / "kt"
@@ -48,7 +48,15 @@ for t, d, s in ev:
         if n >= 2: overlap_ns += t - last
     live[s] = live.get(s, 0) + d
     last = t
-res = {"command": " ".join(cmd[6:]).replace(str(td), "<tmp>"), "workers": workers, "pairs": pairs, "outputs_equal_to_one_worker": bool(same),
+# the workers' pipelines in time: each stream's span from its first to its last classify kernel, and how often the stream changes
+# from one classify kernel to the next in start order (one worker after the other would change once)
+spans = {s: [min(a for s2, k, a, b, q in cls if s2 == s), max(b for s2, k, a, b, q in cls if s2 == s)] for s in streams}
+t0 = min(v[0] for v in spans.values()) if spans else 0
+order = [s for s, k, a, b, q in sorted(cls, key=lambda x: x[2])]
+changes = sum(1 for i in range(1, len(order)) if order[i] != order[i - 1])
+for s in streams:
+    streams[s]["span_ms"] = [(spans[s][0] - t0) / 1e6, (spans[s][1] - t0) / 1e6]
+res = {"stream_changes_in_start_order": changes, "command": " ".join(cmd[6:]).replace(str(td), "<tmp>"), "workers": workers, "pairs": pairs, "outputs_equal_to_one_worker": bool(same),
        "classify_kernel_streams": streams, "classify_busy_any_ms": any_ns / 1e6, "classify_overlap_of_two_or_more_streams_ms": overlap_ns / 1e6,
        "overlap_fraction": (overlap_ns / any_ns) if any_ns else None, "kernel_rows": len(rows)}
 (out / "multictx_trace.json").write_text(json.dumps(res, indent=1))
