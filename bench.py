@@ -559,7 +559,12 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                 if n != n_big:
                     for mate in (1, 2):
                         os.truncate(os.path.join(td, "r%d.fq" % mate), n * W)
-                for threads in threads_list:
+                # workers: the command's own N (one per GPU), or -- on one GPU, small sample at 0.02 -- also two workers SHARING the
+                # device (`--devices 0,0`): the N-worker code paths (queues, ordered drain, parallel finalize) in front of the driver
+                worker_sets = [args.cli_devices]
+                if n_gpus == 1 and ot == 0.02 and n == small and not args.cli_devices:
+                    worker_sets.append("0,0")
+                for threads, devices in [(t, d) for t in threads_list for d in worker_sets]:
                     for fn in ("o1.fq", "o2.fq", "out.ssv"):
                         try:
                             os.unlink(os.path.join(td, fn))
@@ -567,9 +572,11 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                             pass
                     cmd = [exe, "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"), "-2", os.path.join(td, "r2.fq"),
                            "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-k", str(args.k), "-v", "-t", str(threads)]
-                    if n_gpus > 1:
+                    if devices:
+                        cmd += ["--devices", devices]
+                    elif n_gpus > 1:
                         cmd += ["--gpus", str(n_gpus)]
-                    log("  cli: running on %d pairs" % n)
+                    log("  cli: running on %d pairs%s" % (n, " (--devices %s)" % devices if devices else ""))
                     t0 = time.time()
                     with open(os.path.join(td, "out.ssv"), "wb") as so:
                         pr = subprocess.run(cmd, stdout=so, stderr=subprocess.PIPE)
@@ -589,7 +596,7 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                     fq_bytes = sum(os.path.getsize(os.path.join(td, fn)) if os.path.exists(os.path.join(td, fn)) else 0 for fn in ("o1.fq", "o2.fq"))
                     ok_md5 = (got_md5.hexdigest() == md5_at[n]) if same_len_names else None
                     ok = pr.returncode == 0 and got_lines == lines_at[n] and ok_md5 is not False and fq_bytes == 2 * assoc_reads_at[n] * W
-                    run = {"pairs": n, "on_target": ot, "threads": threads, "wall_s": round(dt, 3), "value": round(2 * n / dt, 1), "unit": "reads/s", "rc": pr.returncode,
+                    run = {"pairs": n, "on_target": ot, "threads": threads, "devices": devices, "wall_s": round(dt, 3), "value": round(2 * n / dt, 1), "unit": "reads/s", "rc": pr.returncode,
                            "ssv_lines": got_lines, "expected_ssv_lines": lines_at[n], "ssv_md5": got_md5.hexdigest(), "ssv_md5_equals_device_result": ok_md5,
                            "fastq_out_bytes": fq_bytes, "fastq_out_bytes_expected": 2 * assoc_reads_at[n] * W, "valid": ok,
                            "stage_s_since_start": stages, "input_bytes": 2 * n * W, "generate_s": round(gen_s, 1)}
@@ -652,7 +659,8 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
         # two sample sizes: the slope is the steady state, the intercept the fixed cost
         by = {}
         for x in valid:
-            by.setdefault((x["on_target"], x["threads"]), []).append(x)
+            if x["devices"] == args.cli_devices:
+                by.setdefault((x["on_target"], x["threads"]), []).append(x)
         slopes = []
         for (ot, th), xs in sorted(by.items()):
             xs.sort(key=lambda x: x["pairs"])
@@ -662,12 +670,16 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                                "fixed_s_from_two_sizes": round(xs[0]["wall_s"] - 2 * xs[0]["pairs"] / sl, 3)})
         out["two_size_fit"] = slopes
         # headline of this leg: the run a user's sample looks like least flattering -- the SMALL sample at 0.02 (fixed costs included)
-        pick = [x for x in valid if x["on_target"] == 0.02 and x["pairs"] == small]
+        pick = [x for x in valid if x["on_target"] == 0.02 and x["pairs"] == small and x["devices"] == args.cli_devices]
         if pick:
             best = max(pick, key=lambda x: x["value"])
             out.update({k: best[k] for k in ("pairs", "on_target", "threads", "wall_s", "value", "unit")})
         else:
             out.update({"value": None, "unit": "reads/s", "error": "no valid run: see runs[].rc / ssv_md5_equals_device_result / fastq_out_bytes"})
+        shared = [x for x in out["runs"] if x["devices"] and x["devices"] != args.cli_devices]
+        if shared:
+            out["two_workers_on_one_device"] = {"value": shared[0]["value"], "unit": "reads/s", "valid": shared[0]["valid"], "gpu_busy_s": shared[0].get("gpu_busy_s"),
+                                                "what": "--devices 0,0: two workers (contexts, pipelines) sharing the GPU; ssv md5 / FASTQ bytes checked like every run"}
         half = [x for x in valid if x["on_target"] == 0.50]
         if half:
             out["value_at_on_target_0.50"] = max(x["value"] for x in half)
@@ -700,6 +712,8 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the shark command line")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (committed counters are used when they match)")
     ap.add_argument("--cli-pairs", type=int, default=16_000_000)
+    ap.add_argument("--cli-devices", default=None, help="device list handed to `shark --devices` in the CLI leg (default: the command's own 0..N-1; "
+                    "e.g. 0,0,0,0 rehearses four workers on one GPU)")
     ap.add_argument("--cli-gz-pairs", type=int, default=8_000_000, help="pairs of the CLI leg's run on gzip-compressed files (0 = none)")
     ap.add_argument("--cli-big-pairs", type=int, default=64_000_000, help="the larger of the CLI leg's two samples (cut to what /dev/shm may hold)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = threads x 50 000 (one reference chunk per thread)")

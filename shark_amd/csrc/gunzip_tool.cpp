@@ -26,7 +26,16 @@ int main(int argc, char **argv)
   const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   double cs = 0, c1 = 0, c2 = 0;
   z.cpu_seconds(cs, c1, c2);
-  fprintf(stderr, "shark-gunzip: %zu bytes in %.3f s (%.1f MB/s), %u threads; worker CPU s: search %.3f, pass 1 %.3f, pass 2 %.3f\n", total, s,
-          total / s / 1e6, threads, cs, c1, c2);
+  // peak resident set of THIS program (VmHWM: ru_maxrss starts from what the parent had resident when it forked)
+  long hwm_kb = 0;
+  if (FILE *st = fopen("/proc/self/status", "r")) {
+    char line[256];
+    while (fgets(line, sizeof line, st))
+      if (!strncmp(line, "VmHWM:", 6)) hwm_kb = atol(line + 6);
+    fclose(st);
+  }
+  fprintf(stderr, "shark-gunzip: %zu bytes in %.3f s (%.1f MB/s), %u threads; worker CPU s: search %.3f, pass 1 %.3f, pass 2 %.3f; maxrss_kb %ld\n", total, s,
+          total / s / 1e6, threads, cs, c1, c2, hwm_kb);
+  if (z.failed()) { fprintf(stderr, "shark-gunzip: out of memory, the stream was not delivered whole\n"); return 1; }
   return 0;
 }

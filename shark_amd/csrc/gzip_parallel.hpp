@@ -36,6 +36,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -587,6 +588,14 @@ inline size_t gzip_header_end(const uint8_t *p, size_t n, size_t at)
 
 }  // namespace gzp
 
+// set when any ParallelGunzip of the process ran out of memory (its stream then ended early): whoever drives readers that sit
+// on top of one -- the CLI -- asks once, at the end, and fails instead of presenting a prefix of the sample as the sample
+inline std::atomic<bool> &parallel_gunzip_out_of_memory()
+{
+  static std::atomic<bool> flag{false};
+  return flag;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 class ParallelGunzip {
  public:
@@ -627,6 +636,25 @@ class ParallelGunzip {
     ch_[0]->start_bit = 8ull * data;
     ch_[0]->start_known = 1;
     ch_[0]->clean_start = true;
+    piece_syms_ = std::max<size_t>((size_t)64 << 20, 16 * CHUNK);   // (far above what a chunk of a compressed sample inflates to)
+    if (const char *e = getenv("SHARK_GZ_PIECE")) {
+      const long v = atol(e);
+      if (v >= (long)(2 * gzp::WIN)) piece_syms_ = (size_t)v;
+    }
+    // A stream the search finds no block start in -- fixed-Huffman or stored blocks only, many small members that are not BGZF
+    // (every block is a final one) -- would be inflated by its first chunk alone while every other chunk searches its territory
+    // bit by bit in vain: slower than gzread, for nothing.  The second chunk's search is made here: no start there, no parallel
+    // inflate (the caller falls back to gzread, constant memory, as the reference reads it).  A stream that only turns unfriendly
+    // further on stays correct and bounded: a chunk that inflates far beyond its territory hands its text out in pieces.
+    {
+      gzp::Inflater t;
+      uint64_t bit = 0;
+      const bool found = find_block(t, CHUNK, std::min(n_, 2 * CHUNK), bit);
+      ch_[1]->start_bit = bit;
+      ch_[1]->search_state.store(1);
+      ch_[1]->start_known.store(found ? 1 : -1, std::memory_order_release);
+      if (!found && !getenv("SHARK_GZ_FORCE_PARALLEL")) return;
+    }
     usable_ = true;
     for (unsigned t = 0; t < threads_; ++t) th_.emplace_back([this] { worker(); });
   }
@@ -639,12 +667,15 @@ class ParallelGunzip {
     cv_.notify_all();
     for (auto &t : th_) t.join();
     for (auto &b : pool_) free(b.first);
+    free(handed_buf_);
     if (p_) munmap(const_cast<uint8_t *>(p_), n_);
     if (fd_ >= 0) ::close(fd_);
   }
   ParallelGunzip(const ParallelGunzip &) = delete;
   ParallelGunzip &operator=(const ParallelGunzip &) = delete;
   bool usable() const { return usable_; }
+  // a worker ran out of memory: next() has returned false early and the text delivered so far is NOT the whole stream
+  bool failed() const { return failed_.load(); }
   // CPU seconds the workers spent: looking for block starts, decoding (pass 1), translating symbols to bytes (pass 2)
   void cpu_seconds(double &search, double &pass1, double &pass2) const
   {
@@ -653,40 +684,52 @@ class ParallelGunzip {
     pass2 = 1e-9 * (double)ns_pass2_.load();
   }
 
-  // the next piece of uncompressed text, in file order (valid until the next call); false at the end of the stream
+  // the next piece of uncompressed text, in file order (valid until the next call); false at the end of the stream (or when a
+  // worker failed: failed())
   bool next(const char *&data, size_t &len)
   {
     for (;;) {
       std::unique_lock<std::mutex> l(m_);
-      if (handed_) {   // the chunk handed out last time: its buffer goes back to the pool (pages already touched)
-        Chunk &old = *ch_[consume_ - 1];
-        if (old.bytes) {
-          if (pool_.size() < threads_ + 6) pool_.push_back({old.bytes, old.cap_bytes});
-          else free(old.bytes);
-        }
-        old.bytes = nullptr;
-        handed_ = false;
+      if (handed_buf_) {   // the buffer handed out last time goes back to the pool (pages already touched)
+        if (pool_.size() < threads_ + 6) pool_.push_back({handed_buf_, handed_cap_});
+        else free(handed_buf_);
+        handed_buf_ = nullptr;
         cv_.notify_all();
       }
       if (consume_ >= n_chunks_) return false;
       Chunk &c = *ch_[consume_];
-      cv_.wait(l, [&] { return c.done || quit_; });
+      cv_.wait(l, [&] { return c.done || !c.pieces.empty() || quit_; });
       if (quit_) return false;
+      if (!c.pieces.empty()) {
+        // text of a chunk that is still inflating (it went far beyond its territory: a stretch without block starts)
+        const Piece pc = c.pieces.front();
+        c.pieces.pop_front();
+        handed_buf_ = pc.p;
+        handed_cap_ = pc.cap;
+        data = pc.p;
+        len = pc.n;
+        cv_.notify_all();
+        return true;
+      }
       ++consume_;
-      handed_ = true;
       cv_.notify_all();
+      drop_pages((consume_ - 1) * CHUNK, consume_ * CHUNK);     // (nobody reads this territory any more)
       if (c.absorbed || c.n_bytes == 0) {
         if (c.stream_ends) { consume_ = n_chunks_; return false; }
         continue;                                  // (its territory was inflated by the chunk in front of it)
       }
       data = c.bytes;
       len = c.n_bytes;
+      handed_buf_ = c.bytes;                        // (remembered by itself: consume_ may jump to the end below)
+      handed_cap_ = c.cap_bytes;
+      c.bytes = nullptr;
       if (c.stream_ends) consume_ = n_chunks_;      // the stream ended (or broke) inside this chunk: nothing behind it is delivered
       return true;
     }
   }
 
  private:
+  struct Piece { char *p; size_t n, cap; };
   struct Chunk {
     std::atomic<int> start_known{0};     // 0 = still searching, 1 = start_bit valid, -1 = no block start found in its territory
     std::atomic<int> search_state{0};    // 0 = nobody has searched its block start yet, 1 = somebody has or is at it
@@ -700,7 +743,12 @@ class ParallelGunzip {
     std::vector<uint8_t> window_in;      // the WIN bytes in front of the chunk's text
     char *bytes = nullptr;               // malloc'ed text of the chunk
     size_t n_bytes = 0, cap_bytes = 0;
-    ~Chunk() { free(bytes); }
+    std::deque<Piece> pieces;            // text handed out BEFORE the chunk is done, in order (guarded by m_)
+    ~Chunk()
+    {
+      free(bytes);
+      for (const Piece &pc : pieces) free(pc.p);
+    }
   };
 
   // ---- search: a deflate block that starts at or behind byte `from` (and before byte `to`) ----
@@ -760,8 +808,18 @@ class ParallelGunzip {
         if (inflate) i = next_chunk_++;
         else i = next_search_++;
       }
-      if (inflate) run_chunk(i, z, t);
-      else search_chunk(i, t);
+      try {
+        if (inflate) run_chunk(i, z, t);
+        else search_chunk(i, t);
+      } catch (const std::bad_alloc &) {
+        // out of memory: the stream cannot be delivered; every thread stops, next() returns false, failed() says why
+        failed_.store(true);
+        parallel_gunzip_out_of_memory().store(true);
+        std::lock_guard<std::mutex> l(m_);
+        quit_ = true;
+        cv_.notify_all();
+        return;
+      }
     }
   }
 
@@ -853,7 +911,29 @@ class ParallelGunzip {
     z.reset_output();
     z.text_only = false;
     z.floor = c.clean_start ? gzp::WIN : 0;
+    // What this chunk decides about the chunks behind it (their territory is inflated here: `absorbed`) it may only say once it is
+    // AUTHORITATIVE -- once it knows that it starts at a real block start: a member's first block, or the chunk in front of it has
+    // arrived exactly at its start and handed it its window.  A chunk decoding from an impostor's start marks nothing: its own
+    // output is dropped, and so must be its opinion about others.
+    bool authoritative = c.clean_start;
+    std::vector<uint8_t> lut(65536, 0);
+    for (unsigned k = 0; k < 256; ++k) lut[k] = (uint8_t)k;
     size_t nxt = i + 1;            // the chunk whose start this one is heading for
+    size_t marked = i + 1;         // chunks [i + 1, marked) have been told that they are absorbed
+    auto mark_absorbed = [&] {     // (m_ held)
+      for (; marked < nxt; ++marked) ch_[marked]->absorbed = true;
+      cv_.notify_all();
+    };
+    // the window in front of this chunk's text (the chunk in front of it publishes it); false: absorbed after all, or quitting
+    auto become_authoritative = [&]() -> bool {
+      std::unique_lock<std::mutex> l(m_);
+      cv_.wait(l, [&] { return c.have_window || c.absorbed || quit_; });
+      if (quit_) return false;
+      if (!c.have_window) { c.done = true; cv_.notify_all(); return false; }   // (the chunk in front went through this territory itself)
+      memcpy(lut.data() + 0x8000, c.window_in.data(), gzp::WIN);
+      authoritative = true;
+      return true;
+    };
     bool ends = false;
     for (;;) {
       // arrived at the next chunk's start?
@@ -862,6 +942,9 @@ class ParallelGunzip {
         Chunk &d = *ch_[nxt];
         if (z.in.pos < 8ull * nxt * CHUNK) break;               // not in its territory yet
         int k;
+        // (nobody has looked for its start yet: this thread does -- every other worker may be waiting for a window this chunk is
+        //  on its way to deliver)
+        if (d.start_known.load(std::memory_order_acquire) == 0) search_chunk(nxt, t);
         while ((k = d.start_known.load(std::memory_order_acquire)) == 0) {
           std::unique_lock<std::mutex> l(m_);
           if (quit_) return;
@@ -870,13 +953,40 @@ class ParallelGunzip {
         if (k == 1 && d.start_bit == z.in.pos) { stop = true; break; }
         if (k == 1 && d.start_bit > z.in.pos) break;            // still in front of it
         // behind its start without having met it (an impostor), or it has none: this chunk inflates its territory too
-        {
-          std::lock_guard<std::mutex> l(m_);
-          d.absorbed = true;
-        }
         ++nxt;
       }
       if (stop) break;
+      // far beyond its own territory (a stretch without block starts): the text goes out in pieces, so that what a chunk holds stays
+      // bounded however long the stretch is -- gzread needs constant memory for the same stream
+      if (z.n - gzp::WIN >= piece_syms_) {
+        ns_pass1_ += thread_ns() - t0;
+        if (!authoritative && !become_authoritative()) return;
+        t0 = thread_ns();
+        const size_t total = z.n - gzp::WIN;
+        Piece pc{nullptr, total, 0};
+        take_buffer(pc.p, pc.cap, total);
+        to_bytes(z.out.data() + gzp::WIN, pc.p, total, lut.data());
+        // the last WIN symbols, as the bytes they stand for, are the window of what follows: from here on this decoder has seen
+        // everything it may refer to (no markers any more)
+        {
+          const uint16_t *sy = z.out.data() + z.n - gzp::WIN;
+          uint16_t *w = z.out.data();
+          for (uint32_t k = 0; k < gzp::WIN; ++k) w[k] = lut[sy[k]];
+        }
+        z.floor = z.floor > total ? z.floor - total : 0;
+        z.n = gzp::WIN;
+        drop_pages(i * CHUNK, (size_t)(z.in.pos >> 3) > (1u << 16) ? (size_t)(z.in.pos >> 3) - (1u << 16) : 0);
+        ns_pass2_ += thread_ns() - t0;
+        {
+          std::unique_lock<std::mutex> l(m_);
+          mark_absorbed();
+          cv_.wait(l, [&] { return c.pieces.size() < 2 || quit_; });      // (the consumer takes them in order; two in flight)
+          if (quit_) { free(pc.p); return; }
+          c.pieces.push_back(pc);
+          cv_.notify_all();
+        }
+        t0 = thread_ns();
+      }
       bool fin = false;
       const gzp::Inflater::Rc rc = z.block(fin);
       if (rc != gzp::Inflater::OK) { ends = true; break; }       // corrupt or truncated: the stream ends here, as zlib's would
@@ -891,56 +1001,73 @@ class ParallelGunzip {
       }
     }
     ns_pass1_ += thread_ns() - t0;
-    // 3. the window in front of this chunk's text (the chunk in front of it publishes it)
-    if (!c.clean_start) {
-      std::unique_lock<std::mutex> l(m_);
-      cv_.wait(l, [&] { return c.have_window || c.absorbed || quit_; });
-      if (quit_) return;
-      if (c.absorbed) { c.done = true; cv_.notify_all(); return; }   // (the chunk in front went through this territory itself)
-    }
-    // 4. translation table: literals + window; then the window for the next chunk, then this chunk's bytes
+    // 3. the window in front of this chunk's text
+    if (!authoritative && !become_authoritative()) return;
+    // 4. the window for the next chunk, then this chunk's bytes
     t0 = thread_ns();
-    std::vector<uint8_t> lut(65536, 0);
-    for (unsigned s = 0; s < 256; ++s) lut[s] = (uint8_t)s;
-    if (!c.clean_start) memcpy(lut.data() + 0x8000, c.window_in.data(), gzp::WIN);
     const size_t total = z.n - gzp::WIN;
-    if (!ends && nxt < n_chunks_) {
-      Chunk &d = *ch_[nxt];
-      std::vector<uint8_t> wout(gzp::WIN);
-      // the last WIN symbols (markers in front of the text included: a short chunk hands part of its own window on)
-      const uint16_t *s = z.out.data() + z.n - gzp::WIN;
-      for (uint32_t k = 0; k < gzp::WIN; ++k) wout[k] = lut[s[k]];
-      std::lock_guard<std::mutex> l(m_);
-      d.window_in.swap(wout);
-      d.have_window = true;
-      cv_.notify_all();
-    }
     {
-      // (a buffer the consumer has given back, if one is large enough: a fresh 20 MB allocation is 5 000 page faults)
+      std::vector<uint8_t> wout;
+      if (!ends && nxt < n_chunks_) {
+        // the last WIN symbols (markers in front of the text included: a short chunk hands part of its own window on)
+        wout.resize(gzp::WIN);
+        const uint16_t *sy = z.out.data() + z.n - gzp::WIN;
+        for (uint32_t k = 0; k < gzp::WIN; ++k) wout[k] = lut[sy[k]];
+      }
+      std::lock_guard<std::mutex> l(m_);
+      mark_absorbed();
+      if (!wout.empty()) {
+        Chunk &d = *ch_[nxt];
+        d.window_in.swap(wout);
+        d.have_window = true;
+        cv_.notify_all();
+      }
+    }
+    take_buffer(c.bytes, c.cap_bytes, total);
+    c.n_bytes = total;
+    to_bytes(z.out.data() + gzp::WIN, c.bytes, total, lut.data());
+    c.stream_ends = ends || nxt >= n_chunks_;
+    ns_pass2_ += thread_ns() - t0;
+    finish(c);
+  }
+
+  // the mapped input between two byte offsets is not needed any more: its pages leave the resident set (a long sample would
+  // otherwise count its whole compressed file as resident by the end; they come back from the page cache if touched again)
+  void drop_pages(size_t from, size_t to)
+  {
+    const size_t pg = 4096;
+    from = (from + pg - 1) & ~(pg - 1);
+    to = std::min(to, n_) & ~(pg - 1);
+    if (to > from) madvise(const_cast<uint8_t *>(p_) + from, to - from, MADV_DONTNEED);
+  }
+
+  // a buffer for `total` bytes of text: one the consumer has given back, if one is large enough (a fresh 20 MB allocation is 5 000
+  // page faults), else a new one
+  void take_buffer(char *&bytes, size_t &cap, size_t total)
+  {
+    bytes = nullptr;
+    {
       std::lock_guard<std::mutex> l(m_);
       for (size_t k = 0; k < pool_.size(); ++k)
         if (pool_[k].second >= total) {
-          c.bytes = pool_[k].first;
-          c.cap_bytes = pool_[k].second;
+          bytes = pool_[k].first;
+          cap = pool_[k].second;
           pool_[k] = pool_.back();
           pool_.pop_back();
           break;
         }
     }
-    if (!c.bytes) {
-      c.cap_bytes = (total ? total : 1) + (total >> 3);
-      c.bytes = static_cast<char *>(malloc(c.cap_bytes));
-      if (!c.bytes) throw std::bad_alloc();
+    if (!bytes) {
+      cap = (total ? total : 1) + (total >> 3);
+      bytes = static_cast<char *>(malloc(cap));
+      if (!bytes) throw std::bad_alloc();
     }
-    c.n_bytes = total;
-    {
-      static const bool avx2 = __builtin_cpu_supports("avx2");
-      if (avx2) translate_avx2(z.out.data() + gzp::WIN, c.bytes, total, lut.data());
-      else translate(z.out.data() + gzp::WIN, c.bytes, total, lut.data());
-    }
-    c.stream_ends = ends || nxt >= n_chunks_;
-    ns_pass2_ += thread_ns() - t0;
-    finish(c);
+  }
+  static void to_bytes(const uint16_t *sy, char *o, size_t total, const uint8_t *L)
+  {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) translate_avx2(sy, o, total, L);
+    else translate(sy, o, total, L);
   }
 
   unsigned threads_;
@@ -954,7 +1081,11 @@ class ParallelGunzip {
   std::mutex m_;
   std::condition_variable cv_;
   size_t next_chunk_ = 0, consume_ = 0, next_search_ = 1;
-  bool handed_ = false, quit_ = false;
+  bool quit_ = false;
+  char *handed_buf_ = nullptr;                        // the text buffer next() handed out last (guarded by m_)
+  size_t handed_cap_ = 0;
+  size_t piece_syms_ = (size_t)64 << 20;              // a chunk holding this many symbols hands its text out as a piece and goes on
+  std::atomic<bool> failed_{false};
   std::vector<std::pair<char *, size_t>> pool_;       // byte buffers given back by the consumer (guarded by m_)
   std::atomic<uint64_t> ns_search_{0}, ns_pass1_{0}, ns_pass2_{0};
 };

@@ -38,6 +38,7 @@
 #include "fastq_lean_reader.hpp"
 #include "fastq_partition.hpp"
 #include "fastx_reader.hpp"
+#include "gzip_parallel.hpp"
 
 namespace {
 
@@ -1670,6 +1671,10 @@ int main(int argc, char *argv[])
     }
     if (ro.failed()) {
       std::cerr << "shark: cannot read the sample again for the output" << std::endl;
+      return EXIT_FAILURE;
+    }
+    if (shk::parallel_gunzip_out_of_memory().load()) {
+      std::cerr << "shark: out of memory while inflating the sample" << std::endl;
       return EXIT_FAILURE;
     }
     if (opt.verbose) {
