@@ -301,11 +301,21 @@ def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
                                             "--genes", str(args.genes), "--gene-len", str(args.gene_len), "--on-target", str(args.on_target)]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
             env["TMPDIR"] = "/tmp"
+            # (its own session: on a timeout the whole group goes -- rocprofv3 AND the python child under it, which would otherwise
+            #  keep running on the GPU with its indices resident while the timed legs are measured)
+            pp = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp", start_new_session=True)
             try:
-                pr = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=timeout_s)
+                so, se = pp.communicate(timeout=timeout_s)
             except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pp.pid, signal.SIGKILL)      # (pid == pgid: the child leads its session)
+                except OSError:
+                    pass
+                pp.communicate()
                 notes.append("set %d timed out" % si)
                 continue
+            pr = subprocess.CompletedProcess(cmd, pp.returncode, so, se)
             order = None
             for ln in pr.stdout.splitlines():
                 if ln.startswith('{"counter_child"'):
