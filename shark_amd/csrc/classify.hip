@@ -1125,6 +1125,7 @@ const char *probe_mode_name(const Ctx *ctx)
   static const char *names[] = {"bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table",
                                 "table-mod", "lds-summary+table-mod"};
   if (ctx->idx.ltab) return "lds-table";   // (uniform batches of up to 5 rounds; other batches take lds-summary+table)
+  if (ctx->idx.ktab_lg && probe_mode(ctx->idx) == PM_TAB) return "minimiser-table";   // (classify_uni_kernel; batches of very long reads take `table`)
   return names[probe_mode(ctx->idx)];
 }
 
@@ -1209,6 +1210,8 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     f = f < 0.1 ? 0.1 : (f > 0.9 ? 0.9 : f);
     many_assigned = (double)ctx->last.last_n_assoc > f * (double)ctx->last.last_n_reads;
   }
+  // tables far beyond the caches (k = 15 ... 17): the k-mer keyed, minimiser-bucketed table
+  if (mode == PM_TAB && ctx->idx.ktab_lg) mode = PM_KTAB;
   const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10) && !many_assigned;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;

@@ -52,11 +52,12 @@ enum ProbeMode {
   PM_TAB_SUM = 4,  // summary level, then position table
   PM_LDS_TAB = 5,  // 2^18-bit summary held in LDS, then position table (small indices)
   PM_TAB_MOD = 6,      // PM_TAB for a filter size that is not a power of two (position = hash % size)
-  PM_LDS_TAB_MOD = 7   // PM_LDS_TAB, likewise
+  PM_LDS_TAB_MOD = 7,  // PM_LDS_TAB, likewise
+  PM_KTAB = 8          // the k-mer keyed, minimiser-bucketed table (classify_uni_kernel only; the other kernels take PM_TAB on such an index)
 };
 __host__ __device__ constexpr bool pm_pow2(int m) { return m != PM_BV_MOD && m != PM_TAB_MOD && m != PM_LDS_TAB_MOD; }
 __host__ __device__ constexpr bool pm_lds(int m) { return m == PM_LDS_TAB || m == PM_LDS_TAB_MOD; }
-__host__ __device__ constexpr bool pm_tab(int m) { return m == PM_TAB || m == PM_TAB_SUM || m == PM_TAB_MOD || pm_lds(m); }
+__host__ __device__ constexpr bool pm_tab(int m) { return m == PM_TAB || m == PM_TAB_SUM || m == PM_TAB_MOD || m == PM_KTAB || pm_lds(m); }
 
 // position of a hash in a filter whose size is not a power of two: hash % _size (bloomfilter.h:58,:66,:88)
 __device__ __forceinline__ uint64_t bf_pos_np(uint64_t h, const ClassifyParams &P)

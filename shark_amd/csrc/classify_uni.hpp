@@ -182,6 +182,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
+  // PM_KTAB: a table mode whose probes go to the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab) instead of the position
+  // table: no XXH64 (the key is the canonical k-mer itself; the table holds the filter's false positives too), and consecutive slots
+  // share their 128-byte line.  Everything behind the probe -- what a slot's low word means, the cut, the votes -- is the same.
+  constexpr bool KT = MODE == PM_KTAB;
   // the bound cut.  (Behind the L2-resident summary it used to be left out: an off-target pair is cheap there and the second
   // dependent step cost on-target pairs more than the cut saved.  Since the anchored extension takes the on-target pairs off this
   // path it pays: 250 / 1 000 genes at 0 % on-target 10.1 / 12.2 -> 8.2 / 9.8 ms per 10 M pairs, at 50 % 11.5 / 12.6 -> 11.2 / 12.0,
@@ -659,17 +663,22 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 #endif
     constexpr bool WALK_ROUNDS = LSUM || SHK_ROUNDS_ALL;
     constexpr bool ROUNDS = LSUM || ANCH || SHK_ROUNDS_ALL;
-    const uint4 *tab16 = reinterpret_cast<const uint4 *>(P.tab);
-    const uint32_t bmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
+    const uint4 *tab16 = reinterpret_cast<const uint4 *>(KT ? P.ktab : P.tab);
+    // (the position table: as below, for the anchored extension's sample, which probes `atab` in every table mode)
+    const uint32_t pmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
+    const uint32_t pspare = 1u << P.tab_lg;
+    const uint32_t bmask = KT ? (uint32_t)((1ull << P.ktab_lg) - 1ull) : pmask;
     const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
-    const uint32_t spare = 1u << P.tab_lg;
+    const uint32_t spare = KT ? (1u << P.ktab_lg) : pspare;
+    const bool tab_stream = KT ? (P.ktab_nt != 0u) : (P.tab_nt != 0u);
     // the word a slot's high word is compared with (0 = empty slot): tag | valid | displacement 0
     auto want_for = [&](const uint64_t ps) -> uint32_t {
       const uint32_t tag = __builtin_amdgcn_alignbit((uint32_t)(ps >> 32), (uint32_t)ps, P.tab_lg) & tagmask;
       return (tag << 8) | 0x80u;
     };
-    auto want_of = [&](const int j) -> uint32_t { return want_for(pos[j]); };
-    auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + d) & bmask; };
+    // (KT: pos[j] = the compared word << 32 | the home bucket; a key that left its home bucket is in the same bucket of a later line)
+    auto want_of = [&](const int j) -> uint32_t { return KT ? (uint32_t)(pos[j] >> 32) : want_for(pos[j]); };
+    auto bucket_of = [&](const int j, const uint32_t d) -> uint32_t { return ((uint32_t)pos[j] + (KT ? 8u * d : d)) & bmask; };
     // both orientations of the k-mer of slot (lane, j): x = its bases first-base-low (the fw stream's window), y = first-base-high
     // (the rv stream's window = the k-mer as kmer_utils.hpp:67-69 packs it); ~x is the reverse complement (kmer_utils.hpp:47-55)
     auto windows = [&](const int j, uint64_t &x, uint64_t &y) {
@@ -703,6 +712,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         uint64_t x, y;
         windows(j, x, y);
         const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+        if (KT) {
+          uint32_t hb, hw;
+          ktab_home(fwd, rc, k, P.ktab_w, P.ktab_lg - 3u, hb, hw);
+          pos[j] = ((uint64_t)hw << 32) | hb;
+          continue;
+        }
         const uint64_t canon = fwd < rc ? fwd : rc;         // KmerBuilder.hpp:49, ReadAnalyzer.hpp:55
         const uint64_t hsh = xxh64_u64(canon);
         // (LDS-summary mode with a power-of-two size keeps the raw hash: every use below masks the bits it needs)
@@ -778,7 +793,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         for (int j = JLO; j < JHI; ++j) {
           const uint32_t bb = (uint32_t)pos[j] & bmask;
           const uint32_t bi = (bb & okm[j]) | (spare & ~okm[j]);
-          if (!LSUM && P.tab_nt) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
+          if (!LSUM && tab_stream) {   // a table far beyond the caches: streaming loads (49.8 -> 54.6 G lookups/s, tools/gather_bench)
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(tab16) + bi);
             bk[j] = make_uint4(v.x, v.y, v.z, v.w);
           } else {
@@ -813,7 +828,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
               lane_more = false;
 #pragma unroll
               for (int j = JLO; j < JHI; ++j) {
-                const uint32_t want = want_of(j) | d;   // (a slot carries its displacement)
+                const uint32_t want = KT ? want_of(j) : (want_of(j) | d);   // (a slot of the position table carries its displacement)
                 const bool n0 = bk[j].y == want, n1 = bk[j].w == want;
                 const bool found = more[j] & (n0 | n1);
                 const bool ends = (bk[j].y == 0u) | (bk[j].w == 0u) | (d >= 63u);   // a free slot ends every search
@@ -828,7 +843,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
             bool walked[U];
 #pragma unroll
             for (int j = JLO; j < JHI; ++j) walked[j] = more[j];
-            walk_probe_paths<U, true>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
+            walk_probe_paths<U, !KT>(tab16, bk, more, lane_any, want_of, bucket_of, (uint32_t)JLO, (uint32_t)JHI);   // (a key found is moved into bk[j] in home form)
             if (ROUNDS) {
 #pragma unroll
               for (int j = JLO; j < JHI; ++j) {
@@ -1200,7 +1215,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       if (!__ballot(s_ok)) return false;
       // (the sample probes `atab`: the position table's buckets with a slot's occurrence in the reference in place of its list --
       //  "is this k-mer in the index" and "where in the reference" in one memory round trip instead of two dependent ones)
-      const uint32_t sb = s_ok ? ((uint32_t)s_pos & bmask) : spare;
+      const uint32_t sb = s_ok ? ((uint32_t)s_pos & pmask) : pspare;
       const uint4 *atab16 = reinterpret_cast<const uint4 *>(H->atab);
       uint4 sbk;
       if (P.tab_nt) {
@@ -1637,6 +1652,7 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
     break;
   case PM_LDS_TAB_MOD: if (big) LU(PM_LDS_TAB_MOD, 20); else LU(PM_LDS_TAB_MOD, 18); break;
   case PM_TAB: LU(PM_TAB, 18); break;
+  case PM_KTAB: LU(PM_KTAB, 18); break;
   case PM_TAB_MOD: LU(PM_TAB_MOD, 18); break;
   default: LU(PM_TAB_SUM, 18); break;
   }

@@ -340,6 +340,57 @@ __global__ __launch_bounds__(256) void ref_multi_write_kernel(uint32_t *__restri
   ent[n_set + 1 + x] = out;
 }
 
+// ---- the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab) ----
+// Every canonical k-mer x (4^k / 2 of them) is asked what the reference asks of it: is bit XXH64(x) mod size set
+// (bloomfilter.h:87-89)?  The k-mers for which it is -- the reference's own and the filter's false positives alike -- become
+// the keys; a key's payload is the low word of the position table's slot for that bit, i.e. exactly what a probe of the k-mer
+// through `tab` returns.  Nothing in the classify kernels can then tell the two tables apart but the addresses they touch.
+// A key sits in the first bucket with a free slot on its path home, home + one line, home + two lines, ... (64-bit CAS);
+// a key placed behind its home bucket marks that bucket, as in `tab`.
+__global__ __launch_bounds__(256) void ktab_build_kernel(const uint32_t k, const uint32_t w, const uint64_t *__restrict__ bf64, const uint64_t bf_mask,
+                                                         const uint64_t *__restrict__ tab, const uint32_t tab_lg, unsigned long long *__restrict__ ktab,
+                                                         const uint32_t ktab_lg, unsigned long long *__restrict__ n_keys, uint32_t *__restrict__ fail,
+                                                         uint32_t *__restrict__ lost)
+{
+  const uint64_t n = 1ull << (2u * k);
+  const uint64_t tmask = (1ull << tab_lg) - 1ull;
+  const uint32_t kmask = (uint32_t)((1ull << ktab_lg) - 1ull);
+  unsigned long long mine = 0;
+  for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t rc = revcomp_left_aligned(x << (64u - 2u * k), k);
+    if (x > rc) continue;                                    // (its reverse complement is the canonical form: enumerated there)
+    const uint64_t pos = xxh64_u64(x) & bf_mask;
+    if (!((bf64[pos >> 6] >> (pos & 63u)) & 1ull)) continue;
+    // what a probe of that position returns (the position table holds every set bit)
+    const uint32_t pwant = ((uint32_t)(pos >> tab_lg) << 8) | 0x80u;
+    uint64_t pb = pos & tmask;
+    uint32_t lo = 0;
+    bool have = false;
+    for (uint32_t d = 0; d < 64 && !have; ++d) {
+      for (uint32_t sidx = 0; sidx < 2 && !have; ++sidx) {
+        const uint64_t e = tab[2 * pb + sidx];
+        if ((uint32_t)(e >> 32) == (pwant | d)) { lo = (uint32_t)e & ~TAB_OVERFLOW; have = true; }
+      }
+      pb = (pb + 1) & tmask;
+    }
+    if (!have) { atomicAdd(lost, 1u); continue; }
+    uint32_t home, want;
+    ktab_home(x, rc, k, w, ktab_lg - 3u, home, want);
+    const unsigned long long e = ((unsigned long long)want << 32) | lo;
+    uint32_t bkt = home;
+    bool done = false;
+    for (uint32_t d = 0; d < 64 && !done; ++d) {
+      for (int sidx = 0; sidx < 2 && !done; ++sidx)
+        done = atomicCAS(&ktab[2ull * bkt + sidx], 0ull, e) == 0ull;
+      if (done && d) atomicOr(&ktab[2ull * home], (unsigned long long)TAB_OVERFLOW);
+      bkt = (bkt + 8u) & kmask;                              // the same bucket of the next line
+    }
+    if (!done) atomicAdd(fail, 1u);
+    ++mine;
+  }
+  if (mine) atomicAdd(n_keys, mine);
+}
+
 // LDS-resident exact table of a tiny index (lds_table.hpp): the keys are read back from the position table just built.
 // false = no displacement fits some group (the caller keeps the LDS-summary chain).
 // *one_gene: the payload all keys share (every probe that matches answers with that single-gene list), 0xFFFFFFFF when they differ
@@ -683,6 +734,47 @@ int build_index(Ctx *ctx)
           (void)hipFree(ent_all); (void)hipFree(ids_all); (void)hipFree(d_lens); (void)hipFree(d_stmp);
           if (!have) drop_anchor();
           if (have) ix.ref_total = (uint32_t)total;
+        }
+        // ---- the k-mer keyed, minimiser-bucketed table (k = 15 ... 17, power-of-two filters, no wrap mode): for tables far beyond
+        // the caches, where every probe of `tab` is a memory-side request of its own and their RATE is the wall;
+        // SHK_KTAB=1 builds it for any table (tests), SHK_NO_KTAB=1 never.  Optional like the anchored extension: when its memory
+        // cannot be had, or a key finds no place, the index is complete without it.
+        ix.ktab_lg = 0;
+        const bool ktab_forced = getenv("SHK_KTAB") != nullptr;
+        if (ix.pow2 && !wrap && k >= 15 && k <= 17 && !getenv("SHK_NO_KTAB") && (ktab_forced || table_bytes > (256ull << 20))) {
+          const uint32_t w = 14;
+          // keys: the set bits' own k-mers (about n_set) + the filter's false positives among the other canonical k-mers
+          const double canon = 0.5 * std::pow(4.0, (double)k);
+          const double est = (double)n_set + canon * ((double)n_set / (double)ix.bf_bits);
+          uint32_t line_lg = 6;
+          while (line_lg < 28 && (double)(16ull << line_lg) * 0.18 < est) ++line_lg;
+          const uint64_t kslots = 16ull << line_lg;
+          if ((double)kslots * 0.5 >= est && kslots * sizeof(uint64_t) <= (64ull << 30)) {
+            unsigned long long *d_nk = nullptr;
+            uint32_t *d_kf = nullptr;
+            bool have = hipMalloc((void **)&ix.ktab, (kslots + 16) * sizeof(uint64_t)) == hipSuccess &&   // (+8 buckets that stay empty: probes that need no answer)
+                        hipMalloc((void **)&d_nk, sizeof(unsigned long long)) == hipSuccess && hipMalloc((void **)&d_kf, 2 * sizeof(uint32_t)) == hipSuccess;
+            unsigned long long h_nk = 0;
+            uint32_t h_kf[2] = {0, 0};
+            have = have && hipMemsetAsync(ix.ktab, 0, (kslots + 16) * sizeof(uint64_t), st) == hipSuccess && hipMemsetAsync(d_nk, 0, sizeof(unsigned long long), st) == hipSuccess &&
+                   hipMemsetAsync(d_kf, 0, 2 * sizeof(uint32_t), st) == hipSuccess;
+            if (have) {
+              hipLaunchKernelGGL(ktab_build_kernel, dim3(256 * 16), dim3(256), 0, st, k, w, (const uint64_t *)ix.bf64, ix.bf_bits - 1, (const uint64_t *)ix.tab, lg,
+                                 reinterpret_cast<unsigned long long *>(ix.ktab), line_lg + 3u, d_nk, d_kf, d_kf + 1);
+              have = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h_nk, d_nk, sizeof(h_nk), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipMemcpyAsync(h_kf, d_kf, sizeof(h_kf), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            }
+            (void)hipGetLastError();
+            (void)hipFree(d_nk); (void)hipFree(d_kf);
+            if (have && h_kf[0] == 0 && h_kf[1] == 0) {
+              ix.ktab_lg = line_lg + 3u;
+              ix.ktab_w = w;
+              ix.ktab_keys = h_nk;
+            } else {
+              (void)hipFree(ix.ktab);
+              ix.ktab = nullptr;
+            }
+          }
         }
       } else {
         (void)hipFree(ix.tab);   // displacement overflow: keep the bit-vector path

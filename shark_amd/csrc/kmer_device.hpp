@@ -61,6 +61,36 @@ __host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t v)
 constexpr uint32_t TAB_OVERFLOW = 1u << 30, TAB_PAYLOAD = 0x3FFFFFFFu;
 
 // ---------------------------------------------------------------------------
+// The k-mer keyed table (DeviceIndex::ktab): where a canonical k-mer lives and the word its slot is compared with.
+// fwd = the k-mer as kmer_utils.hpp:67-69 packs it (first base most significant), rc = revcompl(fwd, k) (kmer_utils.hpp:47-55);
+// the key is their minimum (KmerBuilder.hpp:49).  The MINIMISER is the smallest hash among the k - w + 1 canonical w-mers of the
+// k-mer (w-mer i from the left of fwd and w-mer i from the right of rc are each other's reverse complement, so the set of
+// canonical w-mers -- and with it the minimiser -- is the same whichever strand a read shows); the hash is a multiplication by
+// an odd constant modulo 2^32, injective on w-mers of up to 16 bases, so the smallest hash names the w-mer.  Consecutive k-mers
+// of a sequence share k - 1 bases and, more often than not, their minimiser: they are looked up in the same 128-byte line.
+// w <= 14, k - w <= 3.
+// ---------------------------------------------------------------------------
+constexpr uint32_t KTAB_C1 = 0x9E3779B1u, KTAB_C2 = 0x85EBCA6Bu;
+__host__ __device__ __forceinline__ void ktab_home(const uint64_t fwd, const uint64_t rc, const uint32_t k, const uint32_t w, const uint32_t line_lg,
+                                                   uint32_t &bucket, uint32_t &want)
+{
+  const uint32_t wmask = (1u << (2u * w)) - 1u;
+  const uint32_t nw = k - w;          // w-mers per k-mer, less one
+  uint32_t mh = 0xFFFFFFFFu;
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const uint32_t sa = i <= nw ? 2u * (nw - i) : 0u;
+    const uint32_t a = (uint32_t)(fwd >> sa) & wmask, b = (uint32_t)(rc >> (2u * i)) & wmask;
+    const uint32_t h = (a < b ? a : b) * KTAB_C1;
+    mh = (i <= nw && h < mh) ? h : mh;
+  }
+  const uint64_t key = fwd < rc ? fwd : rc;
+  const uint32_t line = (mh * KTAB_C2) >> (32u - line_lg);
+  bucket = (line << 3) | ((uint32_t)key & 7u);
+  want = ((uint32_t)(key >> 3) << 1) | 1u;      // (k <= 17: 31 bits of key, and "this slot is taken")
+}
+
+// ---------------------------------------------------------------------------
 // Base classification, 4 ASCII bytes at a time (SWAR).
 // Result must agree with to_int (kmer_utils.hpp:29-41): A/a C/c G/g T/t are
 // valid with codes 0..3 (= to_int-1, kmer_utils.hpp:68), every other byte --

@@ -27,7 +27,7 @@ int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
 
 static void free_index(DeviceIndex &ix)
 {
-  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.atab);
+  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.atab); hipFree(ix.ktab);
   ix = DeviceIndex{};
 }
 
@@ -152,6 +152,8 @@ static void fill_params(Ctx *ctx, Slot &s, const shk_batch *b)
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
   p.lx_gene = 0xFFFFFFFFu;   // (launch_classify_uni sets it when it chooses the exact LDS table)
   p.ref2 = ix.ref2; p.refpay = ix.refpay; p.atab = ix.atab; p.ref_total = ix.ref_total;
+  p.ktab = ix.ktab_lg ? ix.ktab : nullptr; p.ktab_lg = ix.ktab_lg; p.ktab_w = ix.ktab_w;
+  p.ktab_nt = ctx->env_ktab_nt ? 1u : 0u;
   p.bf_bits = ix.bf_bits;
   p.bf_mask = ix.pow2 ? ix.bf_bits - 1 : ~0ull;   // (non power-of-two: positions are reduced explicitly, the masks become no-ops)
   if (!ix.pow2) {
@@ -608,6 +610,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     const char *e = getenv("SHK_FORCE_GENERIC");
     ctx->env_force_generic = e && e[0] == '1';
     ctx->env_big_lds_always = getenv("SHK_BIG_LDS_ALWAYS") != nullptr;
+    ctx->env_ktab_nt = getenv("SHK_KTAB_NT") != nullptr;
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };

@@ -87,6 +87,19 @@ struct DeviceIndex {
   uint32_t *ref2 = nullptr, *refpay = nullptr;
   uint64_t *atab = nullptr;
   uint32_t ref_total = 0;    // bases in ref2 / entries in refpay; 0 = not built
+  // ---- the index a third time, keyed by the K-MER and bucketed by its MINIMISER (k = 15 ... 17, tables beyond the caches) ----
+  //   ktab : 2^ktab_lg buckets of two 8-byte slots; eight consecutive buckets are one 128-byte LINE.  Keys: every canonical k-mer
+  //          whose filter bit is set -- the reference's k-mers AND the filter's false positives, enumerated over all 4^k / 2
+  //          canonical k-mers when the index is built --, so "is the key there" is exactly "is the bit set" (bloomfilter.h:87-89).
+  //          line = hash of the k-mer's minimiser (the smallest hash among its k - w + 1 canonical w-mers), bucket within the
+  //          line = the key's low three bits: consecutive k-mers of a read share their minimiser, hence their line -- one memory-side
+  //          request serves several probes.  slot: low word as in `tab` (what a probe of the position returns), high word
+  //          (key >> 3) << 1 | 1; a key that does not fit its bucket goes to the same bucket of the next line (so the bucket a slot
+  //          sits in always names the key's low bits), marked as in `tab`.
+  uint64_t *ktab = nullptr;
+  uint32_t ktab_lg = 0;      // log2(buckets); 0 = not built
+  uint32_t ktab_w = 0;       // w (the minimiser's length)
+  uint64_t ktab_keys = 0;    // keys it holds (reference k-mers + false positives of the filter)
 };
 constexpr uint32_t REFPAY_NONE = 0xFFFFFFFFu;   // (multi with payload 2^30-1: not a rank, n_set <= 2^30-1 entries have ranks below that)
 
@@ -146,6 +159,10 @@ struct ClassifyParams {
   const uint32_t *refpay;
   const uint64_t *atab;
   uint32_t ref_total;
+  // the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab; classify_uni_kernel's PM_KTAB instantiations)
+  const uint64_t *ktab;
+  uint32_t ktab_lg, ktab_w;
+  uint32_t ktab_nt;          // 1 = probe it with non-temporal loads
   // batches whose reads all have one length per mate (the usual sequencer output) take classify_uni_kernel's UNI instantiation,
   // the others its ragged one, which stages every read in the layout of the batch's LONGEST mates:
   // uni_flag == nullptr: the host knows (uni_L1, uni_L2) = the one length per mate, or the longest; else {1 = uniform and fits,
@@ -305,6 +322,7 @@ struct Ctx {
   // test / A-B switches of the environment, read ONCE when the context is created (never per launch):
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
+  bool env_ktab_nt = false;         // SHK_KTAB_NT=1: the minimiser table probed with non-temporal loads (A/B timing)
   bool env_force_generic = false, env_big_lds_always = false, env_cls_always = false;   // SHK_CLS_MIN_FILL given: no adapting to the stream
   uint32_t last_verdict = 0;        // CTR_VERDICT of the last batch finished
   uint32_t env_cls_min_fill = CLS_MIN_FILL;   // SHK_CLS_MIN_FILL: pairs per non-empty class a batch needs to go class by class (0: never; tests: 1)

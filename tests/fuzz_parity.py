@@ -22,15 +22,15 @@ from shark_amd.capi import hip_memcpy_dtoh
 from tests import synth
 
 ALL_MODES = ["bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table", "table-mod",
-             "lds-summary+table-mod", "lds-table"]
-ENV_KEYS = ("SHK_PROBE", "SHK_FORCE_GENERIC", "SHK_NO_LDS_TABLE")
+             "lds-summary+table-mod", "lds-table", "minimiser-table"]
+ENV_KEYS = ("SHK_PROBE", "SHK_FORCE_GENERIC", "SHK_NO_LDS_TABLE", "SHK_KTAB", "SHK_NO_LDS_SUMMARY", "SHK_NO_SUMMARY")
 
 
 def run_case(seed, bias=""):
     """one random configuration -> (ok, probe mode, one-line description).
     bias: "" = the broad distribution; "uni" = what classify_uni_kernel takes (sparse filters, one length per mate);
     "mid" = indices of 10^5 .. 10^6 k-mers in filters of 2^26 .. 2^30 bits (L2-summary + table, big LDS summary, plain table);
-    "mod" = filter sizes that are not a power of two with a table."""
+    "mod" = filter sizes that are not a power of two with a table; "ktab" = the minimiser-bucketed table (k = 15 ... 17)."""
     rng = np.random.default_rng(seed)
     env = {}
     k = int(rng.choice([1, 2, 5, 11, 16, 17, 18, 21, 25, 31, int(rng.integers(1, 32))]))
@@ -72,7 +72,16 @@ def run_case(seed, bias=""):
         n_genes = int(rng.choice([2, 40, 300]))
         gl = int(rng.choice([400, 2500]))
         var_len = bool(rng.random() < 0.3)
-    if rng.random() < 0.15 and "SHK_PROBE" not in env:
+    elif bias == "ktab":
+        # the k-mer keyed, minimiser-bucketed table: k = 15 ... 17, power-of-two filters from sparse to a quarter full (dense ones
+        # give the filter's false positives, which the table holds as keys of their own, a share of every read's k-mers)
+        env = {"SHK_KTAB": "1", "SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"}
+        k = int(rng.choice([15, 16, 17, 17]))
+        bf_bits = 1 << int(rng.integers(20, 34))
+        n_genes = int(rng.choice([1, 7, 40, 300]))
+        read_len = int(rng.choice([17, 33, 76, 100, 150, 151, 250, 300, 700]))
+        var_len = bool(rng.random() < 0.3)
+    if rng.random() < 0.15 and "SHK_PROBE" not in env and bias != "ktab":
         env["SHK_FORCE_GENERIC"] = "1"          # classify_fast_kernel's table instantiations instead of classify_uni_kernel
     if rng.random() < 0.2:
         env["SHK_NO_LDS_TABLE"] = "1"

@@ -18,16 +18,24 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["auto", "bitvector", "no-lds-table", "force-generic"])
+@pytest.fixture(params=["auto", "bitvector", "no-lds-table", "force-generic", "ktable"])
 def probe(request, monkeypatch):
     """run a test once with the index's automatic probe structure (position table where possible; tiny indices: the exact
     table in LDS for uniform batches), once forced onto the plain filter words (+rank directory), once without the
     LDS-resident table (so that tiny indices also exercise the LDS-summary + position-table chain on uniform batches), and
     once with SHK_FORCE_GENERIC=1: every batch through classify_fast_kernel / process_read, whose table-mode instantiations
-    otherwise only see batches with reads of more than 512 bases"""
+    otherwise only see batches with reads of more than 512 bases; "ktable": probes through the minimiser-bucketed table"""
     monkeypatch.delenv("SHK_PROBE", raising=False)
     monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
     monkeypatch.delenv("SHK_FORCE_GENERIC", raising=False)
+    for v in ("SHK_KTAB", "SHK_NO_LDS_SUMMARY", "SHK_NO_SUMMARY"):
+        monkeypatch.delenv(v, raising=False)
+    if request.param == "ktable":
+        # the k-mer keyed, minimiser-bucketed table (k = 15 ... 17; other k: the plain position table), which is otherwise built
+        # for tables beyond the caches only -- and used where the index's chain is `table`: no summaries in front of it
+        monkeypatch.setenv("SHK_KTAB", "1")
+        monkeypatch.setenv("SHK_NO_LDS_SUMMARY", "1")
+        monkeypatch.setenv("SHK_NO_SUMMARY", "1")
     if request.param == "bitvector":
         monkeypatch.setenv("SHK_PROBE", "bitvector")
     elif request.param == "no-lds-table":
