@@ -46,6 +46,7 @@ def lib():
         L.so_shark_new.restype = p; L.so_shark_new.argtypes = [C.c_uint32, C.c_double, u64, C.c_int, C.c_int]
         L.so_shark_free.restype = None; L.so_shark_free.argtypes = [p]
         L.so_shark_build.restype = C.c_int; L.so_shark_build.argtypes = [p, p, p, C.c_size_t]
+        L.so_shark_build_mt.restype = C.c_int; L.so_shark_build_mt.argtypes = [p, p, p, C.c_size_t, C.c_int]
         L.so_shark_bf.restype = p; L.so_shark_bf.argtypes = [p]
         L.so_analyze_read.restype = C.c_int
         L.so_analyze_read.argtypes = [p, C.c_char_p, C.c_size_t, p, C.c_int, p, p, p]
@@ -131,13 +132,16 @@ class Shark:
         except Exception:
             pass
 
-    def build(self, seqs):
-        """seqs: list of bytes, FASTA records in file order."""
+    def build(self, seqs, nthreads=1):
+        """seqs: list of bytes, FASTA records in file order.  nthreads > 1: so_shark_build_mt (same index; the scale tests)."""
         n = len(seqs)
         bufs = [C.create_string_buffer(bytes(s), len(s) + 1) for s in seqs]
         arr = (C.c_char_p * max(n, 1))(*[C.cast(b, C.c_char_p) for b in bufs])
         lens = (C.c_uint64 * max(n, 1))(*[len(s) for s in seqs])
-        self.nidx = self.L.so_shark_build(self.h, arr, lens, n)
+        if nthreads > 1:
+            self.nidx = self.L.so_shark_build_mt(self.h, arr, lens, n, int(nthreads))
+        else:
+            self.nidx = self.L.so_shark_build(self.h, arr, lens, n)
         return self.nidx
 
     # -- index introspection -------------------------------------------------

@@ -487,6 +487,162 @@ int so_shark_build(so_shark *s, const char *const *seqs, const uint64_t *lens, s
   return nidx;
 }
 
+/* ---- the same build on several threads (test infrastructure's own convenience: the 60 000-gene indices of the scale
+ * tests take the serial build 80 s each).  Nothing about the RESULT changes, and the argument is the reference's own:
+ *   pass 1  BloomfilterFiller.hpp:38-46 sets bits under a mutex in whatever order the worker threads deliver their
+ *           batches; setting a bit is idempotent, so the filter does not depend on the order.  Here: records are dealt to
+ *           threads, bits are set with an atomic OR.
+ *   pass 2  main.cpp:154-189 walks the records in file order on one thread.  What a record does to the index is: number
+ *           itself (nidx, with the skipped increment of :165), hash and sort its k-mers (bloomfilter.h:65-68), and append
+ *           its number to the list of every set bit it hits unless that list already ends with it (:69-74).  The lists
+ *           are independent of each other, and a list sees the records in file order.  Here: (A) threads compute every
+ *           record's sorted positions and their ranks -- pure functions of the frozen filter --; (B) the record numbers
+ *           are the running count of :162-185; (C) every thread owns a range of ranks and walks ALL records in file order,
+ *           applying the literal append rule of :72 to the lists in its range only.
+ * tests/test_oracle.py checks so_shark_build_mt == so_shark_build (filter words, lists) incl. the numbering quirk and
+ * more than 65 536 genes. */
+typedef struct {
+  so_shark *s;
+  const char *const *seqs;
+  const uint64_t *lens;
+  size_t n_records;
+  int tid, nthreads;
+  /* per record */
+  uint32_t **ranks;      /* sorted by position: rank of every k-mer occurrence */
+  uint32_t *cnt;         /* k-mers of the record (0: none valid, or shorter than k) */
+  uint8_t *advances;     /* the record takes a gene number (everything but `continue` at main.cpp:165) */
+  int *nidx_of;
+} mt_job;
+
+static size_t record_kmers(const char *seq, int seq_len, uint32_t k, uint64_t *kmers, int *skipped)
+{
+  /* main.cpp:163-182, as in so_shark_build */
+  size_t cnt = 0;
+  int _p = 0;
+  *skipped = 0;
+  uint64_t kmer = (uint64_t)so_build_kmer(seq, seq_len, &_p, (uint8_t)k);
+  if (kmer == (uint64_t)-1) { *skipped = 1; return 0; }
+  uint64_t rckmer = so_revcompl(kmer, (uint8_t)k);
+  kmers[cnt++] = kmer < rckmer ? kmer : rckmer;
+  for (int p = _p; p < seq_len; ++p) {
+    uint8_t new_char = so_to_int(seq[p]);
+    if (new_char == 0) {
+      ++p;
+      kmer = (uint64_t)so_build_kmer(seq, seq_len, &p, (uint8_t)k);
+      if (kmer == (uint64_t)-1) break;
+      rckmer = so_revcompl(kmer, (uint8_t)k);
+      --p;
+    } else {
+      --new_char;
+      kmer = so_lsappend(kmer, new_char, k);
+      rckmer = so_rsprepend(rckmer, so_reverse_char(new_char), k);
+    }
+    kmers[cnt++] = kmer < rckmer ? kmer : rckmer;
+  }
+  return cnt;
+}
+
+static void *mt_pass1(void *arg)
+{
+  mt_job *j = (mt_job *)arg;
+  so_bf *b = j->s->bf;
+  const uint32_t k = j->s->k;
+  for (size_t r = (size_t)j->tid; r < j->n_records; r += (size_t)j->nthreads) {
+    size_t n = (size_t)j->lens[r];
+    if (n < k) continue;
+    uint64_t *hashes = (uint64_t *)malloc((n - k + 1) * sizeof(uint64_t));
+    size_t cnt = so_kmer_builder(j->seqs[r], n, k, hashes);
+    for (size_t i = 0; i < cnt; ++i) {
+      uint64_t p = hashes[i] % b->size;                       /* so_bf_add_at, atomically */
+      __atomic_fetch_or(&b->bf[p >> 6], (uint64_t)1 << (p & 63), __ATOMIC_RELAXED);
+    }
+    free(hashes);
+  }
+  return NULL;
+}
+
+static void *mt_pass2a(void *arg)
+{
+  mt_job *j = (mt_job *)arg;
+  so_bf *b = j->s->bf;
+  const uint32_t k = j->s->k;
+  for (size_t r = (size_t)j->tid; r < j->n_records; r += (size_t)j->nthreads) {
+    int seq_len = (int)j->lens[r];
+    j->cnt[r] = 0;
+    j->ranks[r] = NULL;
+    j->advances[r] = 1;
+    if ((unsigned)seq_len < k) continue;
+    uint64_t *kmers = (uint64_t *)malloc(((size_t)seq_len - k + 1) * sizeof(uint64_t));
+    int skipped = 0;
+    size_t cnt = record_kmers(j->seqs[r], seq_len, k, kmers, &skipped);
+    if (skipped) { j->advances[r] = 0; free(kmers); continue; }
+    for (size_t i = 0; i < cnt; ++i) kmers[i] = so_get_hash(kmers[i]) % b->size;   /* bloomfilter.h:65-67 */
+    qsort(kmers, cnt, sizeof(uint64_t), cmp_u64);                                   /* :68 */
+    uint32_t *rk = (uint32_t *)malloc((cnt ? cnt : 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < cnt; ++i) rk[i] = (uint32_t)so_bf_rank(b, kmers[i]);     /* :70 */
+    free(kmers);
+    j->ranks[r] = rk;
+    j->cnt[r] = (uint32_t)cnt;
+  }
+  return NULL;
+}
+
+static void *mt_pass2c(void *arg)
+{
+  mt_job *j = (mt_job *)arg;
+  so_bf *b = j->s->bf;
+  const uint64_t per = (b->num_kmer + (uint64_t)j->nthreads - 1) / (uint64_t)j->nthreads;
+  const uint64_t lo = per * (uint64_t)j->tid, hi = lo + per;
+  for (size_t r = 0; r < j->n_records; ++r) {
+    const uint32_t *rk = j->ranks[r];
+    const uint32_t n = j->cnt[r];
+    const int input_idx = j->nidx_of[r];
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t kr = rk[i];
+      if (kr < lo || kr >= hi) continue;
+      smallvec *sv = &b->set_index[kr];
+      if (sv->n == 0 || (int)sv->d[sv->n - 1] != input_idx) sv_push(sv, (uint16_t)input_idx);   /* :72, literally */
+    }
+  }
+  return NULL;
+}
+
+static void mt_run(void *(*fn)(void *), mt_job *jobs, int nthreads)
+{
+  pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
+  for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, fn, &jobs[t]);
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  free(th);
+}
+
+int so_shark_build_mt(so_shark *s, const char *const *seqs, const uint64_t *lens, size_t n_records, int nthreads)
+{
+  if (nthreads <= 1) return so_shark_build(s, seqs, lens, n_records);
+  mt_job *jobs = (mt_job *)calloc((size_t)nthreads, sizeof(mt_job));
+  uint32_t **ranks = (uint32_t **)calloc(n_records ? n_records : 1, sizeof(uint32_t *));
+  uint32_t *cnt = (uint32_t *)calloc(n_records ? n_records : 1, sizeof(uint32_t));
+  uint8_t *advances = (uint8_t *)calloc(n_records ? n_records : 1, 1);
+  int *nidx_of = (int *)calloc(n_records ? n_records : 1, sizeof(int));
+  for (int t = 0; t < nthreads; ++t) {
+    jobs[t].s = s; jobs[t].seqs = seqs; jobs[t].lens = lens; jobs[t].n_records = n_records; jobs[t].tid = t; jobs[t].nthreads = nthreads;
+    jobs[t].ranks = ranks; jobs[t].cnt = cnt; jobs[t].advances = advances; jobs[t].nidx_of = nidx_of;
+  }
+  mt_run(mt_pass1, jobs, nthreads);
+  so_bf_switch_mode(s->bf, 1);                              /* main.cpp:148 */
+  mt_run(mt_pass2a, jobs, nthreads);
+  int nidx = 0;                                             /* main.cpp:156, :165, :185 */
+  for (size_t r = 0; r < n_records; ++r) {
+    nidx_of[r] = nidx;
+    if (advances[r]) ++nidx;
+  }
+  if (s->bf->num_kmer) mt_run(mt_pass2c, jobs, nthreads);
+  for (size_t r = 0; r < n_records; ++r) free(ranks[r]);
+  free(ranks); free(cnt); free(advances); free(nidx_of); free(jobs);
+  so_bf_switch_mode(s->bf, 2);                              /* :193 */
+  s->nidx = nidx;
+  return nidx;
+}
+
 /* ---- ordered map<int, ((cov, nk), last)>  (ReadAnalyzer.hpp:41-42) ------ */
 typedef struct {
   int *key;

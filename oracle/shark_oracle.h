@@ -78,6 +78,9 @@ void      so_shark_free(so_shark *s);
 /* main.cpp:128-193: pass 1, switch_mode(1), pass 2, switch_mode(2) over the
  * FASTA records given in file order.  Returns final nidx (main.cpp:191). */
 int       so_shark_build(so_shark *s, const char *const *seqs, const uint64_t *lens, size_t n_records);
+/* the same index built on `nthreads` threads (the scale tests' 60 000-gene indices); see the comment at its definition for why
+ * the result cannot differ */
+int       so_shark_build_mt(so_shark *s, const char *const *seqs, const uint64_t *lens, size_t n_records, int nthreads);
 const so_bf *so_shark_bf(const so_shark *s);
 
 /* ReadAnalyzer.hpp:39-110 for ONE already joined/masked read string.  Writes

@@ -1210,8 +1210,16 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     f = f < 0.1 ? 0.1 : (f > 0.9 ? 0.9 : f);
     many_assigned = (double)ctx->last.last_n_assoc > f * (double)ctx->last.last_n_reads;
   }
-  // tables far beyond the caches (k = 15 ... 17): the k-mer keyed, minimiser-bucketed table
-  if (mode == PM_TAB && ctx->idx.ktab_lg) mode = PM_KTAB;
+  // tables far beyond the caches (k = 15 ... 17): the k-mer keyed, minimiser-bucketed table -- while the batch just finished left
+  // a fifth of its pairs unassigned or more.  Pairs from a gene hardly probe either table (the anchored extension settles them from
+  // the reference itself), and what they do probe are isolated slots that share no line with a neighbour: the same results at 18.8
+  // against 17.9 ms per 10 M pairs on the 60 000-gene index at 100 % on-target -- and at 17.8 against 28.8 ms at 0 %, 17.8 / 19.2 at 50 %.
+  // (SHK_KTAB=1, the tests' switch, keeps it on whatever the stream looks like)
+  if (mode == PM_TAB && ctx->idx.ktab_lg) {
+    const bool mostly_assigned = ctx->last.last_n_reads != 0 && !ctx->env_ktab_always &&
+                                 (double)ctx->last.last_n_assoc > 0.8 * (double)ctx->last.last_n_reads;
+    if (!mostly_assigned) mode = PM_KTAB;
+  }
   const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10) && !many_assigned;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
@@ -1228,7 +1236,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lx_gene = ctx->idx.ltab_gene;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
-  const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));   // (= UniGeom::MIN_WAVES)
+  const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : (mode == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));   // (= UniGeom::MIN_WAVES)
   const uint64_t wpb = lx ? SHK_LX_WAVES : (wg16 ? 16 : 8);
   const uint64_t cap = wg16 ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;

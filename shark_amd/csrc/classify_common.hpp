@@ -19,6 +19,10 @@
 #ifndef SHK_TAB_WAVES
 #define SHK_TAB_WAVES 6
 #endif
+// (the instantiations that probe the minimiser-bucketed table, up to U = 5)
+#ifndef SHK_KT_WAVES
+#define SHK_KT_WAVES 6
+#endif
 
 // (-DSHK_NO_ACCEPT=1: a build without the early decision, for A/B timing)
 #ifndef SHK_NO_ACCEPT

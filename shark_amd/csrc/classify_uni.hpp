@@ -159,7 +159,7 @@ struct UniGeom {
   // LDS summary: 3 x 512 threads per CU at <= 80 VGPRs (SHK_UNI_WAVES); table modes likewise (SHK_TAB_WAVES, classify_common.hpp)
   // (U = 10, and the table modes beyond U = 5 -- they carry the anchored extension --: 4 waves per SIMD, 128 VGPRs; at 80 the U = 8 table
   //  kernels spilled 50-130 VGPRs)
-  static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : ((U > 8 || (U > 5 && !pm_lds(MODE))) ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : SHK_TAB_WAVES)));
+  static constexpr int MIN_WAVES = (WAVES == 16 || LX) ? WAVES / 4 : ((U > 8 || (U > 5 && !pm_lds(MODE))) ? 4 : (U > 5 ? 6 : (pm_lds(MODE) ? SHK_UNI_WAVES : (MODE == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));
   static constexpr uint32_t SUM_BITS = pm_lds(MODE) ? (LX ? LTAB_BYTES * 8u : (1u << LSL)) : 0u;   // what the workgroup keeps in LDS
   static constexpr uint32_t SUM_WORDS64 = SUM_BITS / 64;
 };

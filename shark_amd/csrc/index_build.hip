@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void ktab_build_kernel(const uint32_t k, const
     for (uint32_t d = 0; d < 64 && !done; ++d) {
       for (int sidx = 0; sidx < 2 && !done; ++sidx)
         done = atomicCAS(&ktab[2ull * bkt + sidx], 0ull, e) == 0ull;
-      if (done && d) atomicOr(&ktab[2ull * home], (unsigned long long)TAB_OVERFLOW);
+      if (done && d) { atomicOr(&ktab[2ull * home], (unsigned long long)TAB_OVERFLOW); atomicAdd(fail + 2, 1u); atomicMax(fail + 3, d); }
       bkt = (bkt + 8u) & kmask;                              // the same bucket of the next line
     }
     if (!done) atomicAdd(fail, 1u);
@@ -742,22 +743,32 @@ int build_index(Ctx *ctx)
         ix.ktab_lg = 0;
         const bool ktab_forced = getenv("SHK_KTAB") != nullptr;
         if (ix.pow2 && !wrap && k >= 15 && k <= 17 && !getenv("SHK_NO_KTAB") && (ktab_forced || table_bytes > (256ull << 20))) {
-          const uint32_t w = 14;
+          // (SHK_KTAB_W / SHK_KTAB_LOAD: the minimiser's length and the table's load in per cent, for A/B timing)
+          // Measured on the 60 000-gene index (2^36-bit filter, 1.9 x 10^8 keys), per 10 M pairs at 0 / 50 / 100 % on-target, against
+          // 28.8 / 19.2 / 17.9 ms through the position table: w = 14, load 0.18: 19.9 / 19.6 / 19.1 ms (11 % of the keys behind their
+          // home bucket -- a minimiser that many k-mers share overfills its line); w = 15, load 0.18: 18.2 / 18.3 / 18.8 (4 %);
+          // w = 15, load 0.09 (2^27 lines, 16 GiB): 17.8 / 17.8 / 18.8 (2 %)
+          uint32_t w = 15;
+          double load = 0.09;
+          if (const char *e = getenv("SHK_KTAB_W")) { const int v = atoi(e); if (v >= 8 && v <= 15) w = (uint32_t)v; }
+          if (const char *e = getenv("SHK_KTAB_LOAD")) { const int v = atoi(e); if (v >= 2 && v <= 50) load = v / 100.0; }
+          if (w > k) w = k;
+          if (k - w > 3) w = k - 3;
           // keys: the set bits' own k-mers (about n_set) + the filter's false positives among the other canonical k-mers
           const double canon = 0.5 * std::pow(4.0, (double)k);
           const double est = (double)n_set + canon * ((double)n_set / (double)ix.bf_bits);
           uint32_t line_lg = 6;
-          while (line_lg < 28 && (double)(16ull << line_lg) * 0.18 < est) ++line_lg;
+          while (line_lg < 28 && (double)(16ull << line_lg) * load < est) ++line_lg;
           const uint64_t kslots = 16ull << line_lg;
           if ((double)kslots * 0.5 >= est && kslots * sizeof(uint64_t) <= (64ull << 30)) {
             unsigned long long *d_nk = nullptr;
             uint32_t *d_kf = nullptr;
             bool have = hipMalloc((void **)&ix.ktab, (kslots + 16) * sizeof(uint64_t)) == hipSuccess &&   // (+8 buckets that stay empty: probes that need no answer)
-                        hipMalloc((void **)&d_nk, sizeof(unsigned long long)) == hipSuccess && hipMalloc((void **)&d_kf, 2 * sizeof(uint32_t)) == hipSuccess;
+                        hipMalloc((void **)&d_nk, sizeof(unsigned long long)) == hipSuccess && hipMalloc((void **)&d_kf, 4 * sizeof(uint32_t)) == hipSuccess;
             unsigned long long h_nk = 0;
-            uint32_t h_kf[2] = {0, 0};
+            uint32_t h_kf[4] = {0, 0, 0, 0};   // keys without a place, set bits the position table does not hold, keys behind their home bucket, longest path
             have = have && hipMemsetAsync(ix.ktab, 0, (kslots + 16) * sizeof(uint64_t), st) == hipSuccess && hipMemsetAsync(d_nk, 0, sizeof(unsigned long long), st) == hipSuccess &&
-                   hipMemsetAsync(d_kf, 0, 2 * sizeof(uint32_t), st) == hipSuccess;
+                   hipMemsetAsync(d_kf, 0, 4 * sizeof(uint32_t), st) == hipSuccess;
             if (have) {
               hipLaunchKernelGGL(ktab_build_kernel, dim3(256 * 16), dim3(256), 0, st, k, w, (const uint64_t *)ix.bf64, ix.bf_bits - 1, (const uint64_t *)ix.tab, lg,
                                  reinterpret_cast<unsigned long long *>(ix.ktab), line_lg + 3u, d_nk, d_kf, d_kf + 1);
@@ -766,6 +777,9 @@ int build_index(Ctx *ctx)
             }
             (void)hipGetLastError();
             (void)hipFree(d_nk); (void)hipFree(d_kf);
+            if (getenv("SHK_KTAB_STATS"))
+              fprintf(stderr, "[shk/ktab] k=%u w=%u lines=2^%u keys=%llu (estimated %.0f) load=%.3f displaced=%u (%.2f %%) longest path=%u no place=%u lost=%u\n", k, w, line_lg,
+                      h_nk, est, (double)h_nk / (double)kslots, h_kf[2], h_nk ? 100.0 * h_kf[2] / (double)h_nk : 0.0, h_kf[3], h_kf[0], h_kf[1]);
             if (have && h_kf[0] == 0 && h_kf[1] == 0) {
               ix.ktab_lg = line_lg + 3u;
               ix.ktab_w = w;

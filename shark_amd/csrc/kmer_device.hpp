@@ -68,7 +68,7 @@ constexpr uint32_t TAB_OVERFLOW = 1u << 30, TAB_PAYLOAD = 0x3FFFFFFFu;
 // canonical w-mers -- and with it the minimiser -- is the same whichever strand a read shows); the hash is a multiplication by
 // an odd constant modulo 2^32, injective on w-mers of up to 16 bases, so the smallest hash names the w-mer.  Consecutive k-mers
 // of a sequence share k - 1 bases and, more often than not, their minimiser: they are looked up in the same 128-byte line.
-// w <= 14, k - w <= 3.
+// w <= 15, k - w <= 3.
 // ---------------------------------------------------------------------------
 constexpr uint32_t KTAB_C1 = 0x9E3779B1u, KTAB_C2 = 0x85EBCA6Bu;
 __host__ __device__ __forceinline__ void ktab_home(const uint64_t fwd, const uint64_t rc, const uint32_t k, const uint32_t w, const uint32_t line_lg,
@@ -84,10 +84,18 @@ __host__ __device__ __forceinline__ void ktab_home(const uint64_t fwd, const uin
     const uint32_t h = (a < b ? a : b) * KTAB_C1;
     mh = (i <= nw && h < mh) ? h : mh;
   }
+  // Which of a line's eight buckets: three bits that depend on the bases AROUND the minimiser.  The keys that share a minimiser
+  // differ only in where it sits in them and in the k - w bases beside it -- bases at the two ENDS of the k-mer -- so the low bits of
+  // the key alone would be the minimiser's own for every key that ends with it (one bucket of the line taking them all: paths of
+  // 30 lines on the 60 000-gene index).  The key is therefore passed through a bijection first -- its top three bases xored into its
+  // last three, the upper of those six bits into the lower --: equal images, equal keys, and the image's low three bits mix all six
+  // bases.  The bucket names those three bits, the slot holds the other 31 (k <= 17) and "taken".
   const uint64_t key = fwd < rc ? fwd : rc;
+  uint32_t lo = (uint32_t)key ^ ((uint32_t)(key >> (2u * k - 6u)) & 63u);
+  lo ^= (lo >> 3) & 7u;
   const uint32_t line = (mh * KTAB_C2) >> (32u - line_lg);
-  bucket = (line << 3) | ((uint32_t)key & 7u);
-  want = ((uint32_t)(key >> 3) << 1) | 1u;      // (k <= 17: 31 bits of key, and "this slot is taken")
+  bucket = (line << 3) | (lo & 7u);
+  want = ((((uint32_t)(key >> 32) << 29) | (lo >> 3)) << 1) | 1u;
 }
 
 // ---------------------------------------------------------------------------

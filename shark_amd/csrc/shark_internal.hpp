@@ -322,7 +322,8 @@ struct Ctx {
   // test / A-B switches of the environment, read ONCE when the context is created (never per launch):
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
-  bool env_ktab_nt = false;         // SHK_KTAB_NT=1: the minimiser table probed with non-temporal loads (A/B timing)
+  bool env_ktab_always = false;     // SHK_KTAB=1: the minimiser table for every batch of an index that has it (tests)
+  bool env_ktab_nt = false, env_ktab_plain = false;   // SHK_KTAB_NT=1 / 0: the minimiser table probed with / without non-temporal loads whatever its size (A/B timing, tests)
   bool env_force_generic = false, env_big_lds_always = false, env_cls_always = false;   // SHK_CLS_MIN_FILL given: no adapting to the stream
   uint32_t last_verdict = 0;        // CTR_VERDICT of the last batch finished
   uint32_t env_cls_min_fill = CLS_MIN_FILL;   // SHK_CLS_MIN_FILL: pairs per non-empty class a batch needs to go class by class (0: never; tests: 1)

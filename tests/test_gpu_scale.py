@@ -8,7 +8,7 @@ name; the per-GPU shard of the 8-GPU configs).  Checked per config:
   * the index built on the device equals the oracle's: set bits, list total, every gene list
     (and, for the 8 GiB filter, every filter word)
   * both probe chains (position table vs filter words + rank directory) give identical results
-  * a 200 000-pair sample of the batch is bit-equal to the oracle's associations
+  * a 2 M-pair sample of the batch is bit-equal to the oracle's associations
   * per-gene counters equal the histogram of the per-read results
   * configs[2] AND configs[4] at their full length: 100 M pairs / 200 M pairs with qualities streamed through
     shk_classify_submit / _wait in 4 M-pair batches (three in flight), every batch equal to the resident classification of
@@ -16,8 +16,11 @@ name; the per-GPU shard of the 8-GPU configs).  Checked per config:
   * membership at scale: 50 M reference k-mers, each classified as a read of its own, all come back assigned (a key
     the position table had lost, or a search that ends too early, would show here and nowhere in whole-read parity),
     and both probe chains return the same associations for them
-The oracle builds each index in ~80 s single-threaded (pass 2 of the reference is single-threaded,
-main.cpp:154-189), which is what sizes this file's run time (~4 min)."""
+  * configs[2]'s index is probed through the minimiser-bucketed table (k = 17): 10^9 uniform-random 17-mers, each a read of its
+    own, must come back as the plain filter words answer them -- the only witness of the table's enumeration of the filter's
+    false positives (2.5 x 10^6 of them among 10^9 random k-mers)
+The oracle's serial build takes ~80 s per index (pass 2 of the reference is single-threaded, main.cpp:154-189); the tests use
+so_shark_build_mt (same index, tests/test_oracle.py), a few seconds."""
 import os
 
 import numpy as np
@@ -31,7 +34,7 @@ except Exception:  # pragma: no cover
 pytestmark = pytest.mark.gpu
 
 PAIRS = 10_000_000
-SAMPLE = 200_000
+SAMPLE = 2_000_000
 L = 150
 KMER_READS = 50_000_000
 
@@ -119,7 +122,7 @@ def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words, strea
     ptr = {kk: (v.data_ptr() if v is not None else 0) for kk, v in batch.items()}
 
     o = oracle.Shark(k=k, c=0.6, bf_bits=1 << bf_log2, min_quality=q, single=single)
-    nidx = o.build(gbytes)
+    nidx = o.build(gbytes, nthreads=min(os.cpu_count() or 1, 32))
 
     res, kres = {}, {}
     for mode in ("auto", "bitvector"):
@@ -153,6 +156,10 @@ def _scale_case(oracle, monkeypatch, k, bf_log2, q, single, compare_words, strea
         counts = h.gene_counts(65536)
         assert np.array_equal(counts, np.bincount(gids, minlength=65536).astype(np.uint64))
         res[mode] = (goff, gids)
+        if mode == "auto":
+            # which chain ran: the minimiser-bucketed table for k = 17 (PM_KTAB = 8), the position table for k = 31 (PM_TAB = 3)
+            assert h.probe_mode() == ("minimiser-table" if k <= 17 else "table"), h.probe_mode()
+            assert (", 8, " if k <= 17 else ", 3, ") in h.last_kernel(), h.last_kernel()
         # every reference k-mer as a read of its own
         nk, kseq, koff, kqual = _reference_kmers_as_reads(genes, k, dev, q > 0)
         torch.cuda.synchronize()
@@ -204,3 +211,57 @@ def test_config4_gencode_scale_k31_q20_single_16gb(oracle, monkeypatch):
     # qualities low at the read ends only (shark_amd/synth.py "ends"): most on-target pairs keep enough valid 31-mers, so the
     # quality-mask HIT path is exercised at scale (the rounds 1-2 model assigned 1.3 % of the pairs)
     assert cnt.sum() > 0.30 * PAIRS
+
+
+def test_config2_index_random_kmers_agree_with_the_filter_words(monkeypatch):
+    """10^9 uniform-random 17-mers against the configs[2] index, each a read of its own (c = 0: whatever list the k-mer's filter
+    bit has is the answer, bloomfilter.h:78-102), through the minimiser-bucketed table and through the plain filter words + rank
+    directory.  A random 17-mer is a reference k-mer with probability 2 %, and one of the filter's FALSE positives -- a key the
+    table holds only because the build enumerated all 4^17 / 2 canonical k-mers -- with probability 0.25 %: 2.5 x 10^6 of those
+    in this test, every one of which must come back with the list of the bit it collides with."""
+    from shark_amd import SharkHip, synth
+    from shark_amd.capi import hip_memcpy_dtoh
+    k, n, chunks = 17, 100_000_000, 10
+    genes = synth.make_gencode_like_reference(60000)
+    gbytes = [g.tobytes() for g in genes]
+    monkeypatch.delenv("SHK_PROBE", raising=False)
+    monkeypatch.setenv("SHK_KTAB", "1")              # (no switching by what the last batch looked like)
+    h = SharkHip(k=k, c=0.0, bf_bits=1 << 36)
+    info = h.build(gbytes)
+    assert h.probe_mode() == "minimiser-table"
+    monkeypatch.setenv("SHK_PROBE", "bitvector")
+    hb = SharkHip(k=k, c=0.0, bf_bits=1 << 36)
+    hb.build(gbytes)
+    assert hb.probe_mode().startswith("bitvector") or "bitvector" in hb.probe_mode()
+    del gbytes
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20261005)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    off = torch.arange(0, n + 1, device=dev, dtype=torch.int64) * k
+    hits = assoc = 0
+    for c in range(chunks):
+        seq = acgt[torch.randint(0, 4, (n * k,), generator=gen, device=dev)]
+        torch.cuda.synchronize()
+        got = []
+        for ctx in (h, hb):
+            r = ctx.classify_device(n, seq.data_ptr(), off.data_ptr(), max_read_len=k)
+            g = np.empty(n + 1, np.uint32)
+            hip_memcpy_dtoh(g, r.gene_off, g.nbytes)
+            ids = np.empty(int(r.n_assoc), np.uint16)
+            if len(ids):
+                hip_memcpy_dtoh(ids, r.gene_ids, ids.nbytes)
+            got.append((g, ids))
+        assert ", 8, " in h.last_kernel(), h.last_kernel()
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), "chunk %d" % c
+        hits += int((np.diff(got[0][0].astype(np.int64)) > 0).sum())
+        assoc += len(got[0][1])
+        del seq, got
+    # a random 17-mer hits a set bit with probability (set bits) / 2^36 on top of being one of the reference's own k-mers
+    total = n * chunks
+    p_ref = info["n_set_bits"] / (4.0 ** k / 2)
+    p_fp = info["n_set_bits"] / float(1 << 36)
+    assert 0.95 * total * (p_ref + p_fp) < hits < 1.05 * total * (p_ref + p_fp), (hits, total * (p_ref + p_fp))
+    assert assoc >= hits
+    h.close()
+    hb.close()

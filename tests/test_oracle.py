@@ -271,3 +271,33 @@ def test_handworked_cases(oracle, case, tmp_path):
         args.append("-s")
     oracle.run_cli(args, str(tmp_path / "out.ssv"))
     assert (tmp_path / "out.ssv").read_text() == case["ssv"]
+
+
+@pytest.mark.parametrize("k,bf_bits,n_genes,gene_len,threads", [(17, 1 << 26, 300, 2500, 4), (5, 4099, 40, 300, 3), (31, 1 << 30, 120, 1500, 8),
+                                                                (9, 1 << 18, 66_000, 40, 5)])
+def test_multithreaded_build_equals_the_serial_one(oracle, k, bf_bits, n_genes, gene_len, threads):
+    """so_shark_build_mt (the scale tests' 60 000-gene indices in seconds instead of minutes) must leave exactly the index
+    so_shark_build leaves: filter words, number of set bits, every gene list in order -- with the numbering quirk (a record
+    without a valid k-mer, main.cpp:165), records shorter than k, genes sharing halves, a filter dense with collisions
+    (4 099 bits), and more than 65 536 genes (the uint16_t comparison of bloomfilter.h:72 then appends per occurrence)"""
+    rng = np.random.default_rng(k * 7 + n_genes)
+    genes = [bytes(g) for g in synth.make_genes(rng, n_genes, max(k + 3, gene_len // 3), gene_len, share_every=3)]
+    genes.insert(len(genes) // 3, b"N" * (k + 20))          # at least k long, no valid k-mer: takes no gene number
+    genes.insert(len(genes) // 2, b"ACGT"[:max(1, min(4, k - 1))])   # shorter than k: takes one
+    g = bytearray(genes[5])
+    g[len(g) // 2] = ord("N")
+    genes[5] = bytes(g)
+    a = oracle.Shark(k=k, c=0.6, bf_bits=bf_bits)
+    na = a.build(genes)
+    b = oracle.Shark(k=k, c=0.6, bf_bits=bf_bits)
+    nb = b.build(genes, nthreads=threads)
+    assert na == nb == len(genes) - 1
+    assert a.num_kmer() == b.num_kmer() > 0
+    assert np.array_equal(a.bf_words(), b.bf_words())
+    assert np.array_equal(a.index_kmer(), b.index_kmer())
+    reads = synth.make_reads(rng, [np.frombuffer(x, dtype=np.uint8) for x in genes[:20]], 500, read_len=max(2 * k, 40), on_target=0.7)
+    ra = a.classify(reads["seq1"], reads["off1"], reads["seq2"], reads["off2"], nthreads=2)
+    rb = b.classify(reads["seq1"], reads["off1"], reads["seq2"], reads["off2"], nthreads=2)
+    assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+    a.close()
+    b.close()

@@ -49,6 +49,12 @@ __global__ __launch_bounds__(256) void k(const uint32_t *__restrict__ a, uint64_
         if (lane < 11) v0[f] = a[base + lane];
       } else if (SHAPE == 8) {   // 64 lanes x 16 bytes contiguous (1 KiB), 16-byte aligned
         const u32x4 v = *reinterpret_cast<const u32x4 *>(a + (base & ~3ull) + 4 * lane); v0[f] = v.x; v1[f] = v.w;
+      } else if (SHAPE >= 10 && SHAPE <= 14) {   // runs of R adjacent lanes share a random 128-byte line, each lane one of its eight 16-byte buckets (the minimiser table's probes)
+        constexpr int R = SHAPE == 10 ? 2 : (SHAPE == 11 ? 3 : (SHAPE == 12 ? 4 : (SHAPE == 13 ? 5 : 8)));
+        const uint64_t line = mix(r + lane / R) & (n_dw / 32 - 1);
+        const uint64_t i = line * 8 + (mix(r ^ (lane * 77u)) & 7);
+        const u32x4 v = reinterpret_cast<const u32x4 *>(a)[i];
+        v0[f] = v.x; v1[f] = v.w;
       } else if (SHAPE == 9) {   // 16 independent random 16-byte buckets (the sample)
         if (lane < 16) { const uint64_t i = mix(r + lane) & (n_dw / 8 - 1); const u32x4 v = reinterpret_cast<const u32x4 *>(a)[i]; v0[f] = v.x; v1[f] = v.w; }
       }
@@ -63,7 +69,7 @@ template <int SHAPE>
 static int run(const uint32_t *a, uint64_t n_dw, uint32_t *out, const char *what, double *t_rand)
 {
   const unsigned grid = 256u * 8u;
-  const uint32_t iters = SHAPE == 0 ? 320 : 4000;
+  const uint32_t iters = (SHAPE == 0 || SHAPE >= 10) ? 320 : 4000;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   hipLaunchKernelGGL(k<SHAPE>, dim3(grid), dim3(256), 0, 0, a, n_dw, 20u, out);
@@ -100,5 +106,10 @@ int main()
   run<5>(a, n_dw, out, "16 lanes x 16 B contiguous, 16-B aligned", &t);
   run<7>(a, n_dw, out, "11 lanes x dword contiguous", &t);
   run<8>(a, n_dw, out, "64 lanes x 16 B contiguous (1 KiB)", &t);
+  run<10>(a, n_dw, out, "64 lanes x 16 B, runs of 2 adjacent lanes in one random line (32 lines)", &t);
+  run<11>(a, n_dw, out, "64 lanes x 16 B, runs of 3 adjacent lanes in one random line (22 lines)", &t);
+  run<12>(a, n_dw, out, "64 lanes x 16 B, runs of 4 adjacent lanes in one random line (16 lines)", &t);
+  run<13>(a, n_dw, out, "64 lanes x 16 B, runs of 5 adjacent lanes in one random line (13 lines)", &t);
+  run<14>(a, n_dw, out, "64 lanes x 16 B, runs of 8 adjacent lanes in one random line (8 lines)", &t);
   return 0;
 }
