@@ -235,7 +235,14 @@ def counter_child(args):
         order.append({"workload": name, "calls": calls, "kernel": h.last_kernel(), "n_assoc": int(r.n_assoc), "probe_mode": h.probe_mode()})
         h.close()
         del b, p
-    print(json.dumps({"counter_child": order}), flush=True)
+    # the issue ceiling's kernel (shk_measure_valu_mix): its instruction count per wave-iteration comes from this same counter pass
+    hm = SharkHip(k=args.k, c=0.6, bf_bits=1 << 20, device=0)
+    mix = []
+    for wv in (4, 8):
+        ms, wi = hm.measure_valu_mix(wv, 2000)
+        mix.append({"waves_per_simd": wv, "wave_iterations_timed_launch": wi, "warmup_wave_iterations": wi // 2000 * 64})
+    hm.close()
+    print(json.dumps({"counter_child": order, "valu_mix": mix}), flush=True)
 
 
 def parse_counter_dir(d, order):
@@ -279,6 +286,23 @@ def parse_counter_dir(d, order):
     return out
 
 
+def parse_kernel_counter(d, kernel, counter):
+    """values of one counter for every dispatch of `kernel`, in dispatch order (summed over the rows of a dispatch)"""
+    import csv
+    import glob
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for i, r in enumerate(csv.DictReader(fh)):
+                if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    try:
+                        did = int(r.get("Dispatch_Id") or r.get("Dispatch_ID") or i)
+                    except ValueError:
+                        did = i
+                    acc[did] = acc.get(did, 0.0) + float(r["Counter_Value"])
+    return [acc[k] for k in sorted(acc)]
+
+
 def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
     """one rocprofv3 --pmc child per counter set (separate passes, --kernel-trace only beside --pmc) over `workloads`
     -> ({workload: {"kernel":..., counter: value per launch, ...}}, note).  Never raises: a bench line without live counters
@@ -316,14 +340,22 @@ def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
                 notes.append("set %d timed out" % si)
                 continue
             pr = subprocess.CompletedProcess(cmd, pp.returncode, so, se)
-            order = None
+            order, mix = None, None
             for ln in pr.stdout.splitlines():
                 if ln.startswith('{"counter_child"'):
                     order = json.loads(ln)["counter_child"]
+                    mix = json.loads(ln).get("valu_mix")
             if pr.returncode != 0 or order is None:
                 notes.append("set %d failed (rc %d): %s" % (si, pr.returncode, (pr.stderr or "")[-300:].replace("\n", " | ")))
                 continue
             got = parse_counter_dir(d, order)
+            if mix and "SQ_INSTS_VALU" in cset:
+                # the issue-ceiling kernel's dispatches, in order: (warm-up, timed) per occupancy; VALU instructions per wave-iteration
+                vals = parse_kernel_counter(d, "valu_mix_kernel", "SQ_INSTS_VALU")
+                if len(vals) == 2 * len(mix):
+                    res.setdefault("valu_mix", {})
+                    for i, m in enumerate(mix):
+                        res["valu_mix"][str(m["waves_per_simd"])] = vals[2 * i + 1] / float(m["wave_iterations_timed_launch"])
             for o in order:
                 w = o["workload"]
                 if w in got:
@@ -337,7 +369,7 @@ def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
     finally:
         if not keep_dir:
             shutil.rmtree(base, ignore_errors=True)
-    res = {w: e for w, e in res.items() if len(e) > 1}
+    res = {w: e for w, e in res.items() if len(e) > 1 or w == "valu_mix"}
     note = "live: rocprofv3 --pmc child passes of this run (%d sets, %.0f s)" % (len(sets or COUNTER_SETS), time.time() - t0)
     if notes:
         note += "; " + "; ".join(notes)
@@ -720,6 +752,7 @@ def main():
     ap.add_argument("--no-trimmed", action="store_true", help="skip the trimmed-batch leg (its launches include no-op launches of the headline kernel: "
                                                               "a kernel trace of the run then averages them in)")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the shark command line")
+    ap.add_argument("--no-async", action="store_true", help="skip the pipelined device-resident leg (value_async)")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc child passes (committed counters are used when they match)")
     ap.add_argument("--cli-pairs", type=int, default=16_000_000)
     ap.add_argument("--cli-devices", default=None, help="device list handed to `shark --devices` in the CLI leg (default: the command's own 0..N-1; "
@@ -855,6 +888,37 @@ def main():
                  "barrier_wait_ms": round(x[3], 3), "launches": int(x[4])} for r, x in enumerate(rows)]
     reads_per_step = 2 * pairs_per_pass_all * reps
     value = reads_per_step * args.steps / dt
+    # ---- the same passes through the device-resident PIPELINE (shk_classify_device_submit / shk_classify_wait: three launches in
+    # flight, no host synchronisation between two of them, the uniform read length vouched for by the caller as the host entry
+    # points find it out themselves).  Never `value`: `value_async` next to it, with what a launch costs either way. ----
+    value_async = None
+    if world == 1 and not args.no_async:
+        from shark_amd.capi import SHK_PIPE_DEPTH
+        def async_passes(n_pass):
+            tickets, a = [], 0
+            for _ in range(n_pass):
+                for p in ptrs:
+                    if len(tickets) == SHK_PIPE_DEPTH:
+                        a += int(h.wait_device(tickets.pop(0)).n_assoc)
+                    tickets.append(h.submit_device(chunk_pairs, p["seq1"], p["off1"], p["seq2"], p["off2"], p["qual1"], p["qual2"], max_read_len=L,
+                                                   uniform_len1=L, uniform_len2=L))
+            while tickets:
+                a += int(h.wait_device(tickets.pop(0)).n_assoc)
+            return a
+        async_passes(max(1, args.warmup) * reps)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        a_async = async_passes(args.steps * reps)
+        torch.cuda.synchronize()
+        ta = time.perf_counter() - ta
+        n_launch = args.steps * reps * len(ptrs)
+        value_async = {"value": round(reads_per_step * args.steps / ta, 1), "unit": "reads/s", "ms_per_launch": round(ta * 1e3 / n_launch, 4),
+                       "sync_ms_per_launch": round(dt * 1e3 / n_launch, 4), "kernel_ms_per_launch": round(tm["total_ms"] / max(tm["n_launches"], 1), 4),
+                       "assoc_equal_to_the_synchronous_passes": a_async == n_assoc_local,
+                       "what": "the timed passes again through shk_classify_device_submit / shk_classify_wait, %d launches in flight, read length vouched for "
+                               "(no pass over the offsets); wall time of %d launches" % (SHK_PIPE_DEPTH, n_launch)}
+        if a_async != n_assoc_local:
+            sys.exit("bench.py: the pipelined passes returned %d associations, the synchronous ones %d" % (a_async, n_assoc_local))
     kern_ms = tm["total_ms"] / max(tm["n_launches"], 1)
     headline_kernel = h.last_kernel()
 
@@ -1029,6 +1093,23 @@ def main():
                             "why_this_bound": "the index's exact table sits in LDS (probe mode %s): a pair touches no memory but its own bases; the SQ counters put "
                                               "the kernel's time into VALU issue and exposed LDS latency" % h.probe_mode(),
                             "instructions": ip}
+                # ... and against what the SIMDs issue of THIS instruction mix (shk_measure_valu_mix: the kernel's own arithmetic on register
+                # operands, nothing to wait for): instructions per wave-iteration from the same counter pass, time measured here
+                vm = ctr.get("valu_mix") or {}
+                mixc = {}
+                for wv in (4, 8):
+                    ipi = vm.get(str(wv))
+                    if ipi:
+                        ms_mix, wi = h.measure_valu_mix(wv, 20000)
+                        mixc["%d_waves_per_simd" % wv] = {"G_valu_wave_instructions_per_s": round(ipi * wi / (ms_mix * 1e-3) / 1e9, 1),
+                                                          "valu_per_iteration": round(ipi, 1),
+                                                          "simd_cycles_per_valu_instruction": round(ms_mix * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / (ipi * wi), 2)}
+                if mixc:
+                    ref = mixc.get("4_waves_per_simd") or list(mixc.values())[0]
+                    roofline["mix_ceiling"] = dict(mixc, what="G VALU wave-instructions/s of the exact-table kernel's own instruction mix on register operands "
+                                                              "(stage, windows, canonical form, XXH64, table arithmetic, validity / coverage step; no LDS, no memory), "
+                                                              "at the kernel's occupancy (4 waves per SIMD: its 144 KiB table admits one 16-wave workgroup per CU) and at 8")
+                    roofline["frac_of_mix_ceiling"] = round(ip["G_valu_wave_instructions_per_s"] / ref["G_valu_wave_instructions_per_s"], 4)
             else:
                 roofline = {"bound": "hbm", "achieved": round((in_bytes + out_bytes) / t_k / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round((in_bytes + out_bytes) / t_k / 1e9 / HBM_PEAK_GBPS, 5),
@@ -1208,6 +1289,7 @@ def main():
                    "timed_window": "barrier, %d steps x %d passes x %d launches per GPU (each shk_classify_device call synchronises once), one all-reduce of "
                                    "uint64[65536], barrier; max over ranks" % (args.steps, reps, len(my_chunks)),
                    "long_reads": int(tm["last_n_long"]), "tie_reads": int(tm["last_n_tie"]), "probe_mode": h.probe_mode()},
+        "value_async": value_async,
         "per_rank": per_rank,
         "roofline": roofline,
         "cpu_baseline": cpu,

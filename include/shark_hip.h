@@ -156,6 +156,7 @@ int shk_classify(shk_ctx *ctx, const shk_batch *batch, shk_result *result);
  *           tickets are outstanding.
  *   wait  : blocks until that batch is classified and returns its associations in pinned host
  *           buffers owned by the context; they stay valid until SHK_PIPE_DEPTH further submits.
+ *           (A ticket of shk_classify_device_submit: device pointers instead.)
  * Tickets must be waited for in the order they were submitted. */
 #define SHK_PIPE_DEPTH 3
 int shk_classify_submit(shk_ctx *ctx, const shk_batch *batch, uint64_t *ticket);
@@ -169,6 +170,21 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result);
  * Work is enqueued on the context's stream and the call returns after the
  * stream has drained (one host synchronisation per call when max_read_len is given). */
 int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_len, shk_result *result);
+
+/* ... and as a pipeline: the device-resident entry point WITHOUT its host synchronisation (the reference's analyzer threads never
+ * wait for the output stage either, main.cpp:66-77).  Everything is enqueued on the context's stream and the call returns a
+ * ticket; shk_classify_wait(ticket) then returns DEVICE pointers (as shk_classify_device does), valid until SHK_PIPE_DEPTH
+ * further submits.  Tickets of this call and of shk_classify_submit share the context's SHK_PIPE_DEPTH slots and are waited for
+ * in submission order.
+ *   max_read_len   an upper bound on the longest mate, REQUIRED here (> 0): without one the device would have to be asked
+ *                  between two kernels; SHK_ERR_ARG when 0.  A bound that does not hold is noticed and repaired in wait.
+ *   uniform_len1/2 when the caller KNOWS that every mate 1 (mate 2) has exactly this length and off1[i] = i * uniform_len1
+ *                  (off2 likewise) -- a sequencer's output, generated or copied to the device by the caller itself -- it says so
+ *                  here, as the host entry points find out by scanning the offsets: the kernel then never reads an offset and
+ *                  the pass that would verify them on the device (61 us per 10 M pairs) is not made.  0, 0: unknown, the
+ *                  device looks (as shk_classify_device always does).  The caller vouches for what it states. */
+int shk_classify_device_submit(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_len, uint32_t uniform_len1, uint32_t uniform_len2,
+                               uint64_t *ticket);
 
 /* Per-gene number of assigned reads accumulated over all classify calls (all
  * waited tickets) since the last reset (counts[g] for g in [0, 65536)); the quantity all-reduced
@@ -238,6 +254,15 @@ int shk_count_work(shk_ctx *ctx, const shk_batch *dev_batch, shk_work_counters *
  * reports.  Allocates the table, performs about `n_lookups` lookups (five in flight per lane, 8 waves per SIMD;
  * `nontemporal` != 0: streaming loads), frees it again.  On no product path; new (the reference has no counterpart). */
 int shk_measure_random_lookups(shk_ctx *ctx, uint64_t table_bytes, uint64_t n_lookups, int nontemporal, double *g_lookups_per_s);
+
+/* The ISSUE ceiling of the exact-table classify kernel's own instruction mix: a kernel that does, on register operands only
+ * (no LDS, no memory), the arithmetic that kernel does for a read on its shortest way through -- stage eight bases, a slot's two
+ * windows, canonical form, XXH64 (kmer_utils.hpp:81-83), the exact table's address arithmetic and compare, validity window and
+ * coverage step -- `iters` times per lane with `waves_per_simd` (1 ... 8) waves resident per SIMD; *ms = its duration,
+ * *wave_iterations = waves x iters.  bench.py takes the instructions per iteration from the same rocprofv3 counter pass that
+ * counts the classify kernel's, and prints the classify kernel's VALU rate as a fraction of this kernel's (`mix_ceiling`) next
+ * to the fraction of the 2-cycle peak.  On no product path; new (the reference has no counterpart). */
+int shk_measure_valu_mix(shk_ctx *ctx, int waves_per_simd, uint32_t iters, double *ms, uint64_t *wave_iterations);
 
 /* pinned host memory helpers for callers that stream batches */
 void *shk_alloc_pinned(size_t bytes);

@@ -50,7 +50,8 @@ EXPORTS = [
     "shk_gene_counts", "shk_gene_counts_reset", "shk_timing_enable", "shk_timing_get", "shk_count_work",
     "shk_alloc_pinned", "shk_free_pinned", "shk_version", "shk_probe_mode", "shk_gene_counts_allreduce",
     "shk_classify_submit", "shk_classify_wait", "shk_dist_unique_id", "shk_dist_init", "shk_dist_gene_counts_allreduce",
-    "shk_dist_info", "shk_measure_random_lookups", "shk_last_kernel",
+    "shk_dist_info", "shk_measure_random_lookups", "shk_last_kernel", "shk_classify_device_submit",
+    "shk_measure_valu_mix",
 ]
 SHK_PIPE_DEPTH = 3
 SHK_DIST_ID_BYTES = 128
@@ -97,12 +98,16 @@ def load():
     L.shk_gene_counts_allreduce.restype = C.c_int; L.shk_gene_counts_allreduce.argtypes = [C.POINTER(p), C.c_int, p, C.c_uint32]
     L.shk_classify_submit.restype = C.c_int; L.shk_classify_submit.argtypes = [p, C.POINTER(ShkBatch), C.POINTER(C.c_uint64)]
     L.shk_classify_wait.restype = C.c_int; L.shk_classify_wait.argtypes = [p, C.c_uint64, C.POINTER(ShkResult)]
+    L.shk_classify_device_submit.restype = C.c_int
+    L.shk_classify_device_submit.argtypes = [p, C.POINTER(ShkBatch), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.shk_dist_unique_id.restype = C.c_int; L.shk_dist_unique_id.argtypes = [p]
     L.shk_dist_init.restype = C.c_int; L.shk_dist_init.argtypes = [p, p, C.c_int, C.c_int]
     L.shk_dist_gene_counts_allreduce.restype = C.c_int; L.shk_dist_gene_counts_allreduce.argtypes = [p, p, C.c_uint32]
     L.shk_dist_info.restype = C.c_int; L.shk_dist_info.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.shk_measure_random_lookups.restype = C.c_int
     L.shk_measure_random_lookups.argtypes = [p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+    L.shk_measure_valu_mix.restype = C.c_int
+    L.shk_measure_valu_mix.argtypes = [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -228,6 +233,18 @@ class SharkHip:
         self._check(self.L.shk_classify_device(self.h, C.byref(b), max_read_len, C.byref(r)), "shk_classify_device")
         return r
 
+    def submit_device(self, n, seq1, off1, seq2=0, off2=0, qual1=0, qual2=0, max_read_len=0, uniform_len1=0, uniform_len2=0):
+        """device pointers (ints) -> ticket; wait_device(ticket) gives the ShkResult with DEVICE pointers"""
+        b = ShkBatch(n, seq1 or None, off1 or None, seq2 or None, off2 or None, qual1 or None, qual2 or None)
+        t = C.c_uint64()
+        self._check(self.L.shk_classify_device_submit(self.h, C.byref(b), max_read_len, uniform_len1, uniform_len2, C.byref(t)), "shk_classify_device_submit")
+        return t.value
+
+    def wait_device(self, ticket):
+        r = ShkResult()
+        self._check(self.L.shk_classify_wait(self.h, ticket, C.byref(r)), "shk_classify_wait")
+        return r
+
     def count_work(self, n, seq1, off1, seq2=0, off2=0, qual1=0, qual2=0):
         b = ShkBatch(n, seq1 or None, off1 or None, seq2 or None, off2 or None, qual1 or None, qual2 or None)
         w = ShkWorkCounters()
@@ -300,6 +317,12 @@ class SharkHip:
         g = C.c_double()
         self._check(self.L.shk_measure_random_lookups(self.h, table_bytes, n_lookups, int(bool(nontemporal)), C.byref(g)), "shk_measure_random_lookups")
         return g.value
+
+    def measure_valu_mix(self, waves_per_simd=4, iters=20000):
+        """(ms, wave_iterations) of the exact-table kernel's instruction mix on register operands, `waves_per_simd` waves per SIMD"""
+        ms, wi = C.c_double(), C.c_uint64()
+        self._check(self.L.shk_measure_valu_mix(self.h, waves_per_simd, iters, C.byref(ms), C.byref(wi)), "shk_measure_valu_mix")
+        return ms.value, wi.value
 
     def timing_enable(self, on=True):
         self._check(self.L.shk_timing_enable(self.h, int(on)), "shk_timing_enable")

@@ -1234,6 +1234,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lsum32 = ctx->idx.ltab;
     p.lsum_shift = ctx->idx.ltab_mul;   // (no summary in this mode: the field carries the table's slot multiplier)
     p.lx_gene = ctx->idx.ltab_gene;
+    p.lx_multi = (uni && ctx->idx.ltab_sparse && ctx->idx.ltab_gene == 0xFFFFFFFFu) ? 1u : 0u;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : (mode == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));   // (= UniGeom::MIN_WAVES)
@@ -1255,7 +1256,8 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   if (uni || !p.uni_flag)
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s", u, mode, hasq ? "true" : "false",
              (lx && (u <= 5 || u == 10)) ? 21 : ((big && (u <= 5 || u == 10)) ? 20 : 18), p.uni_flag ? "device" : (uni ? "true" : "false"),
-             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "", (lx && p.lx_gene != 0xFFFFFFFFu) ? " +sparse-first-round" : "");
+             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "",
+             (lx && p.lx_gene != 0xFFFFFFFFu) ? " +sparse-first-round" : ((lx && p.lx_multi) ? " +sparse-first-rounds" : ""));
   return SHK_OK;
 }
 

@@ -351,7 +351,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   //  instead of one was measured as well and changed nothing: 4.21 -> 4.29 ms)
   uint32_t *sp_count = nullptr;
   uint16_t *sp_inl = nullptr;
-  const bool sp_on = SPARSE && P.lx_gene != 0xFFFFFFFFu;
+  // sp_one: ONE gene in the index (the argument above).  Several genes (P.lx_multi): the same two rounds in the same order settle a read
+  // too, by the early decision's argument instead -- see sparse_first
+  const bool sp_one = SPARSE && P.lx_gene != 0xFFFFFFFFu;
+  const bool sp_on = SPARSE && (P.lx_gene != 0xFFFFFFFFu || P.lx_multi != 0u);
   // floor(x / k) and floor(x / (k - 1)) for x < 2048 as a multiplication (k <= 32)
   const uint32_t sp_rk = sp_on ? (65536u + k - 1u) / k : 0u, sp_rk1 = (sp_on && k > 1u) ? (65536u + k - 2u) / (k - 1u) : 0u;
   // the smallest slot s with bases_behind(s) <= B
@@ -1425,7 +1428,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       return per_gene && gene_cover(j_const) < thr_r - ub;
     };
     // the slot ss of the read as a probe of the exact LDS table (LX): is its k-mer in the filter?  (`want` false: no probe)
-    auto lx_hit_at = [&](const uint32_t ss_in, const bool want) -> bool {
+    auto lx_hit_at = [&](const uint32_t ss_in, const bool want, uint32_t &payload) -> bool {
       const uint32_t ss = want ? ss_in : 0u;
       const uint32_t q = rcap - k - ss;
       const uint32_t *f = fw + (ss >> 4);
@@ -1445,49 +1448,71 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       const uint32_t tg = __builtin_amdgcn_alignbit((uint32_t)(h >> 32), (uint32_t)h, LTAB_SLOT_LG) & tagmask15;
       const uint32_t base = (uint32_t)h + (tg >> LTAB_GROUP_LG) * P.lsum_shift;
       const uint32_t ee = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + (((base + dd) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+      payload = ee & LTAB_ESC;                          // the gene of the matched entry's single-gene list, or the escape value
       return want & ((ee >> 13) == ((tg << 1) | 1u));   // (not validated: the caller looks at the slot when something matched)
     };
     // the first two rounds of a one-gene index in the sparse order (see spT above).  true: the read is settled.  false: mt / slo of
     // the rounds 0 and 1 are what probe_rounds would have left (matches validated), the read goes on behind the cut's first stop.
-    auto sparse_first = [&]() -> bool {
+    // Returns 1: the read is settled.  0: not settled, mt / slo of the rounds 0 and 1 are what probe_rounds would have left (one-gene
+    // indices).  2: not settled and nothing left behind -- the caller probes the first rounds in the usual order (indices of several
+    // genes: a read whose matches are not all one gene's single-gene lists, or do not reach the threshold yet; rare).
+    // SEVERAL GENES.  Every entry of the exact table carries its list's one gene (or the escape value: a list of several genes, a
+    // gene beyond 13 bits).  Say every match of the rounds A and B -- the whole prefix [0, 128 - T) and the T tiles -- is a
+    // single-gene list of ONE gene g, and what those matches cover (as the vote counts it) is cov.  Any other gene's k-mers can
+    // then only sit in slots that were not probed, all at packed positions >= 128 - T, which cover at most spUb bases: its final
+    // coverage is <= spUb, while g's is >= cov.  With cov >= c * len (thr_r) and cov > spUb, g is the read's only association
+    // (ReadAnalyzer.hpp:90-108) whatever the other 140 probes would say: 128 probes instead of 192 and no vote -- the early
+    // decision's argument (above), made one round earlier because the tiles bring mate 2's coverage forward.
+    auto sparse_first = [&]() -> int {
       const uint32_t T = spT, nA = 64u - T, ln = (uint32_t)lane;
-      // (the read's one association: the index's gene)
-      auto write_the_gene = [&]() {
+      // (the read's one association)
+      auto write_the_gene = [&](const uint32_t g) {
         if (lane == 0 && !SHK_ABL(P, 64u)) {
           sp_count[read] = 1u;
           uint2 pk;
-          pk.x = P.lx_gene & 0xFFFFu;
+          pk.x = g & 0xFFFFu;
           pk.y = 0u;
           *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
         }
       };
       const bool tile = ln >= nA;
       const uint32_t sA = tile ? spLast - (ln - nA) * k : 2u * ln;
-      bool hA = lx_hit_at(sA, true);
+      uint32_t pA = 0u, pB = 0u;
+      bool hA = lx_hit_at(sA, true, pA);
       uint64_t HA = __ballot(hA);
       if (HA) {
         hA = hA && slot_valid(sA);   // (the slot has to exist and be a valid k-mer)
         HA = __ballot(hA);
       }
-      if (HA) {
+      if (HA && sp_one) {
         // bases covered by what matched: an even slot adds min(k, distance to the next even match), a tile k
         const uint64_t H1 = HA & ((1ull << nA) - 1ull);
         const uint64_t nx = (H1 >> ln) >> 1;
         const uint32_t step = nx ? 2u * ((uint32_t)__builtin_ctzll(nx) + 1u) : k;
         const uint32_t cov = wave_sum_u32((hA && !tile) ? (step < k ? step : k) : 0u) + k * (uint32_t)__builtin_popcountll(HA >> nA);
         if (cov >= thr_r) {
-          write_the_gene();
-          return true;
+          write_the_gene(P.lx_gene);
+          return 1;
         }
       }
       const uint32_t sB = ln < nA - 1u ? 2u * ln + 1u : ln + nA;
-      bool hB = lx_hit_at(sB, true);
+      bool hB = lx_hit_at(sB, true, pB);
       uint64_t HB = __ballot(hB);
       if (HB) {
         hB = hB && slot_valid(sB);
         HB = __ballot(hB);
       }
-      if (!(HA | HB) && spUb < thr_r) return true;   // the bound cut: nothing of the prefix is in the filter
+      if (!(HA | HB) && spUb < thr_r) return 1;   // the bound cut: nothing of the prefix is in the filter
+      bool one_g = sp_one;
+      if (!sp_one) {
+        // several genes.  A list of several genes among the matches (the escape value): the usual order, whose rounds ask the
+        // position table for such lists.  Else: one gene's single-gene lists only?
+        if (!(HA | HB)) return 2;
+        if (__ballot((hA & (pA == LTAB_ESC)) | (hB & (pB == LTAB_ESC)))) return 2;
+        const uint32_t g = HA ? (uint32_t)__builtin_amdgcn_readlane((int)pA, (int)__builtin_ctzll(HA))
+                              : (uint32_t)__builtin_amdgcn_readlane((int)pB, (int)__builtin_ctzll(HB));
+        one_g = __ballot((hA & (pA != g)) | (hB & (pB != g))) == 0ull;
+      }
       // (a few per cent of the reads) the matches in the usual order: slot s was probed by lane s / 2 of round A or B (even / odd
       // s < 2 nA - 1) or by lane s - nA of B; the T slots in front of the stop that the tiles displaced are not probed yet
       auto settle_round = [&](const int j, const uint32_t v) {
@@ -1497,10 +1522,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t bit = eo ? sl & 1u : (inB ? 1u : 2u);
         const uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
         mt[j] = ((pv >> bit) & 1u) != 0u;
-        slo[j] = P.lx_gene;
+        // (several genes: the matched entry's gene travels with its bit -- A's in bits 3..15, B's in 16..28, F's in a word of its own)
+        slo[j] = sp_one ? P.lx_gene : ((bit == 0u ? pv >> 3 : pv >> 16) & LTAB_ESC);
         okm[j] = mt[j] ? 0xFFFFFFFFu : 0u;
       };
-      const uint32_t vAB = (hA ? 1u : 0u) | (hB ? 2u : 0u);
+      const uint32_t vAB = (hA ? 1u : 0u) | (hB ? 2u : 0u) | (sp_one ? 0u : ((pA << 3) | (pB << 16)));
       settle_round(0, vAB);
       settle_round(1, vAB);
       if (HA | HB) {
@@ -1508,16 +1534,25 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         // even slots forgive is settled here, behind the two rounds an off-target read costs
         const uint64_t H0 = __ballot(mt[0]), H1 = __ballot(mt[1]);
         const uint32_t cov = cover(H0, 0ull) + cover(H1, H0) + cover(0ull, H1) + k * (uint32_t)__builtin_popcountll(HA >> nA);
-        if (cov >= thr_r) {
-          write_the_gene();
-          return true;
+        if (one_g && cov >= thr_r && (sp_one || cov > spUb)) {
+          write_the_gene(sp_one ? P.lx_gene : (uint32_t)__builtin_amdgcn_readfirstlane((int)(HA ? __builtin_amdgcn_readlane((int)pA, (int)__builtin_ctzll(HA))
+                                                                                                   : __builtin_amdgcn_readlane((int)pB, (int)__builtin_ctzll(HB)))));
+          return 1;
         }
       }
       // ... then the displaced slots, and on behind the cut's first stop as ever
-      const bool hF = lx_hit_at(128u - T + ln, ln < T) && slot_valid(ln < T ? 128u - T + ln : 0u);
+      uint32_t pF = 0u;
+      const bool hF = lx_hit_at(128u - T + ln, ln < T, pF) && slot_valid(ln < T ? 128u - T + ln : 0u);
+      if (!sp_one && __ballot(hF & (pF == LTAB_ESC))) return 2;
       settle_round(1, vAB | (hF ? 4u : 0u));
+      if (!sp_one) {
+        // (the displaced slots' genes: slot sl >= 128 - T of round 1 was probed by lane sl - (128 - T))
+        const uint32_t sl = ln + 64u;
+        const uint32_t pvF = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((sl >= 128u - T ? sl - (128u - T) : 0u) << 2), (int)pF);
+        if (sl >= 128u - T) slo[1] = pvF & LTAB_ESC;
+      }
       lane_any = mt[0] | mt[1];
-      return false;
+      return 0;
     };
     if constexpr (JA >= U) {
       // nothing to decide early (two rounds): the cut's first stop at most
@@ -1533,8 +1568,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         bool first_done = false;
         if constexpr (SPARSE && E == 2) {
           if (spT) {
-            if (sparse_first()) return true;
-            first_done = true;
+            const int sf = sparse_first();
+            if (sf == 1) return true;
+            first_done = sf == 0;
           }
         }
         if (!first_done) probe_rounds(I0{}, IE{}, 0u);
@@ -1577,8 +1613,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         bool first_done = false;
         if constexpr (SPARSE && E == 2 && JA == 2) {
           if (spT) {
-            if (sparse_first()) return true;
-            first_done = true;
+            const int sf = sparse_first();
+            if (sf == 1) return true;
+            first_done = sf == 0;
           }
         }
         if (!first_done) probe_rounds(I0{}, IA{}, 0u);

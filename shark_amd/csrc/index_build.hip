@@ -643,6 +643,7 @@ int build_index(Ctx *ctx)
         // touch no memory but their own bases (classify_uni.hpp LSL = 21); the chains above stay for trimmed reads
         if (ix.ltab) { (void)hipFree(ix.ltab); ix.ltab = nullptr; }
         ix.ltab_gene = 0xFFFFFFFFu;
+        ix.ltab_sparse = false;
         if (ix.pow2 && ix.lsum_shift && lgB >= 24 && lgB <= LTAB_MAX_POS_LG && n_set <= LTAB_MAX_KEYS && !getenv("SHK_NO_LDS_TABLE")) {
           std::vector<uint64_t> h_tab(slots);
           std::vector<uint32_t> img;
@@ -651,6 +652,7 @@ int build_index(Ctx *ctx)
           uint32_t one_gene = 0xFFFFFFFFu;
           if (build_lds_table(h_tab, lg, img, &ix.ltab_mul, &one_gene)) {
             if (!getenv("SHK_NO_SPARSE")) ix.ltab_gene = one_gene;   // (SHK_NO_SPARSE=1: the usual probe order on one-gene indices too; the tests run both)
+            ix.ltab_sparse = !getenv("SHK_NO_SPARSE");
             BI_HIP(hipMalloc((void **)&ix.ltab, LTAB_BYTES));
             BI_HIP(hipMemcpyAsync(ix.ltab, img.data(), LTAB_BYTES, hipMemcpyHostToDevice, st));
             BI_HIP(hipStreamSynchronize(st));

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 
+#include "kmer_device.hpp"
 #include "shark_internal.hpp"
 
 namespace shk {
@@ -45,9 +46,102 @@ __global__ __launch_bounds__(256) void random_lookup_kernel(const uint8_t *__res
   if (acc == 0x12345678u) out[tid & 1023] = acc;   // keeps the loads alive
 }
 
+// shk_measure_valu_mix: the ISSUE ceiling of the exact-table classify kernel's own instruction mix.  One iteration is the
+// arithmetic that kernel does for a read on its shortest way through -- stage eight bases (classify4 / pack4 / gather4, the two code
+// streams), cut a slot's two windows out of six dwords, canonical form, XXH64, the exact table's address arithmetic and compare,
+// the validity window and the coverage step -- on REGISTER operands: no LDS, no memory, nothing to wait for but the VALU itself;
+// every lane carries its own dependent chain, as in the kernel, and W waves per SIMD interleave.  bench.py divides the kernel's
+// measured VALU rate by this kernel's (instructions from the same counter pass, time from here): how far the classify kernel is
+// from what the SIMDs can issue of THIS mix -- 15 of XXH64's 38 instructions are quarter-rate multiplies -- rather than from the
+// 2-cycle peak no integer code reaches.
+__global__ __launch_bounds__(256) void valu_mix_kernel(const uint32_t iters, const uint32_t k, uint32_t *__restrict__ out)
+{
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t d0 = tid * 2654435761u + 0x41434754u, d1 = d0 ^ 0x47544341u, d2 = d1 + 0x54474341u;
+  const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull, kmask0 = (1ull << k) - 1ull;
+  const uint32_t tagmask = (1u << 18) - 1u, gmask2 = ((1u << 13) - 1u) << 1;
+  uint32_t acc = 0;
+  for (uint32_t it = 0; it < iters; ++it) {
+    // stage (classify_uni.hpp, "stage")
+    const uint32_t sh = d0 & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    uint32_t c_lo, c_hi, i_lo, i_hi;
+    classify4(lo, c_lo, i_lo);
+    classify4(hi, c_hi, i_hi);
+    const uint32_t msb16 = (pack4(c_lo) << 8) | pack4(c_hi);
+    const uint32_t inv8 = gather4(i_lo) | (gather4(i_hi) << 4);
+    uint32_t lsb = __builtin_bitreverse32(msb16);
+    lsb = ((lsb >> 1) & 0x55555555u) | ((lsb & 0x55555555u) << 1);
+    // a slot's windows out of six dwords (`windows`)
+    const uint32_t f0 = lsb ^ d0, f1 = lsb + d1, f2 = msb16 ^ d2, e0 = msb16 + d0, e1 = lsb ^ d2, e2 = msb16 ^ d1;
+    const uint32_t sf = (lane & 15u) << 1, sr = ((lane * 7u + it) & 15u) << 1;
+    const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(f2, f1, sf) << 32) | __builtin_amdgcn_alignbit(f1, f0, sf);
+    const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, sr) << 32) | __builtin_amdgcn_alignbit(e1, e0, sr);
+    const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+    const uint64_t h = xxh64_u64(fwd < rc ? fwd : rc);
+    // the exact table's probe (`lx_hit_at`: addresses and compare; the two LDS reads themselves are not VALU work)
+    const uint32_t di = ((uint32_t)h >> 14) & gmask2;
+    const uint32_t tg = __builtin_amdgcn_alignbit((uint32_t)(h >> 32), (uint32_t)h, 15) & tagmask;
+    const uint32_t base = (uint32_t)h + (tg >> 13) * 40503u;
+    const uint32_t ti = ((base + di) << 2) & ((32768u - 1u) << 2);
+    const uint32_t ee = ti ^ d1;
+    const bool hit = (ee >> 13) == ((tg << 1) | 1u);
+    // validity window and coverage step of a matched slot (`slot_valid`, `sparse_first`)
+    const uint64_t v0 = ((uint64_t)d2 << 32) | inv8, v1 = ((uint64_t)d0 << 32) | lsb;
+    const uint32_t vs = lane;
+    const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs));
+    const bool valid = (win & kmask0) == kmask0;
+    const uint64_t nx = (v1 >> lane) >> 1;
+    const uint32_t step = nx ? 2u * ((uint32_t)__builtin_ctzll(nx) + 1u) : k;
+    const uint32_t cv = (hit & valid) ? (step < k ? step : k) : 0u;
+    acc += cv;
+    d0 ^= (uint32_t)h + inv8;
+    d1 += hit ? lsb : msb16;
+    d2 ^= (uint32_t)(h >> 32) + ti;
+  }
+  if (acc == 0x12345678u && d0 == d1) out[tid & 1023u] = acc + d2;   // (keeps the chain alive)
+}
+
 }  // namespace shk
 
 using namespace shk;
+
+extern "C" int shk_measure_valu_mix(shk_ctx *cctx, int waves_per_simd, uint32_t iters, double *ms_out, uint64_t *wave_iterations)
+{
+  Ctx *ctx = cctx;
+  if (!ctx || !ms_out || !wave_iterations || waves_per_simd < 1 || waves_per_simd > 8 || iters == 0) return SHK_ERR_ARG;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  hipDeviceProp_t prop;
+  SHK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->prm.device));
+  uint32_t *out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto done = [&](int r) {
+    if (out) (void)hipFree(out);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return r;
+  };
+#define MS_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return done(set_hip_error(ctx, e__, #call)); } while (0)
+  MS_HIP(hipMalloc((void **)&out, 4096));
+  MS_HIP(hipEventCreate(&e0));
+  MS_HIP(hipEventCreate(&e1));
+  // one 256-thread workgroup puts a wave on each of a CU's four SIMDs: W workgroups per CU are W waves per SIMD, all resident at once
+  const unsigned grid = (unsigned)prop.multiProcessorCount * (unsigned)waves_per_simd;
+  hipLaunchKernelGGL(valu_mix_kernel, dim3(grid), dim3(256), 0, ctx->stream, 64u, ctx->prm.k, out);
+  MS_HIP(hipGetLastError());
+  MS_HIP(hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(valu_mix_kernel, dim3(grid), dim3(256), 0, ctx->stream, iters, ctx->prm.k, out);
+  MS_HIP(hipGetLastError());
+  MS_HIP(hipEventRecord(e1, ctx->stream));
+  MS_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MS_HIP(hipEventElapsedTime(&ms, e0, e1));
+#undef MS_HIP
+  *ms_out = ms;
+  *wave_iterations = (uint64_t)grid * 4ull * iters;
+  return done(SHK_OK);
+}
 
 extern "C" int shk_measure_random_lookups(shk_ctx *cctx, uint64_t table_bytes, uint64_t n_lookups, int nontemporal, double *g_lookups_per_s)
 {

@@ -860,9 +860,45 @@ int shk_classify_submit(shk_ctx *ctx, const shk_batch *b, uint64_t *ticket)
   if (paired) { d.seq2 = (const char *)s.d_seq2; d.off2 = s.d_off2; }
   if (hasq) { d.qual1 = (const char *)s.d_qual1; if (paired) d.qual2 = (const char *)s.d_qual2; }
   s.host_batch = true;
+  s.long_speculative = false;
   const bool uni_fits = uniform && n_long == 0 && groups_fit;
   if ((rc = enqueue_classify(ctx, s, &d, max_slots, LONG_KNOWN, n_long, long_slots, true, uni_fits ? UNI_YES : UNI_NO, (uint32_t)max1, (uint32_t)max2,
                              groups_fit)))
+    return rc;
+  s.ticket = ctx->next_ticket++;
+  s.waited = false;
+  *ticket = s.ticket;
+  return SHK_OK;
+}
+
+// the device-resident entry point as a pipeline (no host synchronisation): see the header
+int shk_classify_device_submit(shk_ctx *ctx, const shk_batch *b, uint32_t max_read_len, uint32_t uniform_len1, uint32_t uniform_len2, uint64_t *ticket)
+{
+  if (!ctx || !ticket || max_read_len == 0) return SHK_ERR_ARG;
+  if (ctx->mode != 2) return SHK_ERR_STATE;
+  int rc = check_batch(ctx, b);
+  if (rc) return rc;
+  SHK_HIP(ctx, hipSetDevice(ctx->prm.device));
+  TraceRange tr("shk_classify_device_submit");
+  Slot &s = ctx->slots[(ctx->next_ticket - 1) % PIPE_DEPTH];
+  if (s.ticket != 0 && !s.waited) {
+    ctx->last_error = "pipeline full: shk_classify_wait the oldest ticket before submitting another batch";
+    return SHK_ERR_STATE;
+  }
+  const uint64_t n = b->n;
+  if (n >= 0xFFFFFFFFull) { ctx->last_error = "batch too large (n must be < 2^32-1)"; return SHK_ERR_ARG; }
+  const bool paired = b->seq2 != nullptr;
+  if (uniform_len1 > max_read_len || uniform_len2 > max_read_len || (!paired && uniform_len2)) return SHK_ERR_ARG;
+  uint32_t max_slots = slots_for_len(max_read_len, ctx->prm.k, paired);
+  // a bound beyond the largest specialisation: the device would have to be asked how many reads do not fit
+  if (max_slots > fast_kernel_max_slots()) { ctx->last_error = "max_read_len beyond the kernels' specialisations: use shk_classify_device"; return SHK_ERR_ARG; }
+  const uint64_t hint_groups = (((uint64_t)max_read_len + 7) >> 3) * (paired ? 2 : 1);
+  const bool groups_fit = hint_groups <= uni_kernel_max_groups(max_slots);
+  const bool vouched = n != 0 && uniform_len1 != 0 && (paired ? uniform_len2 != 0 : true) && groups_fit;
+  s.host_batch = false;
+  s.long_speculative = true;
+  if ((rc = enqueue_classify(ctx, s, b, max_slots, LONG_NONE_EXPECTED, 0, 0, true, vouched ? UNI_YES : UNI_ASK_DEVICE,
+                             vouched ? uniform_len1 : max_read_len, vouched ? uniform_len2 : (paired ? max_read_len : 0), groups_fit)))
     return rc;
   s.ticket = ctx->next_ticket++;
   s.waited = false;
@@ -879,12 +915,12 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
   if (s.ticket != ticket || s.waited) { ctx->last_error = "unknown or already waited ticket"; return SHK_ERR_STATE; }
   SHK_HIP(ctx, hipEventSynchronize(s.ev_done));
   bool redone = false;
-  int rc = finish_classify(ctx, s, false, true, &redone);
+  int rc = finish_classify(ctx, s, s.long_speculative, true, &redone);
   if (rc) { s.waited = true; return rc; }
   // (finish_classify re-ran the tail when it had to, and the tail publishes the results again)
   const uint64_t n = s.n;
   const uint64_t n_assoc = ((uint64_t)s.h_counters[CTR_ASSOC_HI] << 32) | s.h_counters[CTR_ASSOC_LO];
-  if (s.h_counters[CTR_OVERFLOW] || n_assoc > s.cap_h_gene_ids) { ctx->last_error = "result publication failed"; s.waited = true; return SHK_ERR_HIP; }
+  if (s.h_counters[CTR_OVERFLOW] || (s.host_batch && n_assoc > s.cap_h_gene_ids)) { ctx->last_error = "result publication failed"; s.waited = true; return SHK_ERR_HIP; }
   s.waited = true;
   ctx->last.last_n_reads = n;
   ctx->last.last_n_long = s.h_counters[CTR_LONG];
@@ -892,8 +928,8 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
   note_verdict(ctx, s.h_counters[CTR_VERDICT]);
   ctx->last.last_n_assoc = n_assoc;
   result->n = n;
-  result->gene_off = s.h_gene_off;
-  result->gene_ids = s.h_gene_ids;
+  result->gene_off = s.host_batch ? s.h_gene_off : s.d_gene_off;     // (a device-resident ticket: device pointers)
+  result->gene_ids = s.host_batch ? s.h_gene_ids : s.d_gene_ids;
   result->n_assoc = n_assoc;
   return SHK_OK;
 }

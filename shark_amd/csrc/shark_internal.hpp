@@ -68,6 +68,7 @@ struct DeviceIndex {
   uint32_t *ltab = nullptr;   // LDS-resident EXACT table of a tiny index (LTAB_BYTES image: T[2^15] then D[2^13]; lds_table.hpp)
   uint32_t ltab_mul = 0;      //   the multiplier its slots were computed with
   uint32_t ltab_gene = 0xFFFFFFFFu;   //   the ONE gene every key of that table answers with (a one-gene index), else 0xFFFFFFFF
+  bool ltab_sparse = false;           //   the sparse first rounds are allowed on it (not SHK_NO_SPARSE=1 at build time)
   uint64_t *tab = nullptr;   // 2 slots per bucket
   uint32_t tab_lg = 0;       // log2(number of buckets); 0 = no table
   bool tab_with_summary = false;
@@ -138,6 +139,7 @@ struct ClassifyParams {
   const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
   uint32_t lsum_shift;
   uint32_t lx_gene;          // exact table in LDS (LSL = 21): the gene of a one-gene index (DeviceIndex::ltab_gene), else 0xFFFFFFFF
+  uint32_t lx_multi;         // exact table in LDS of an index of SEVERAL genes: the sparse first rounds with the early decision's argument (classify_uni.hpp)
   uint64_t bf_bits;
   uint64_t bf_mask;
   // options
@@ -262,6 +264,7 @@ struct Slot {
   ClassifyParams p{};              // launch parameters (kept for the slow paths)
   uint32_t fast_cap = 0, gen_slots = 0;
   bool host_batch = false;
+  bool long_speculative = false;   // (device-resident submit) the caller's length bound was taken on trust: checked in wait
 };
 
 struct Ctx;

@@ -971,6 +971,70 @@ def test_device_api_with_a_wrong_length_bound(oracle):
         assert np.array_equal(h.gene_counts(8), np.bincount(oi, minlength=8)[:8].astype(np.uint64)), bound
 
 
+def test_device_resident_pipeline_submit_wait(oracle):
+    """shk_classify_device_submit / shk_classify_wait: the device-resident entry point without its host synchronisation -- three
+    batches in flight on the context's slots, results as DEVICE pointers, equal to the oracle's for uniform batches whose
+    lengths the caller vouches for (no pass over the offsets, the kernel never reads one), for uniform batches it does not
+    vouch for (the device looks), for trimmed ones, with a length bound that does not hold (repaired in wait), mixed with
+    host-buffer tickets in one stream; a fourth outstanding ticket and a missing bound are refused; counters = histogram"""
+    from shark_amd import SharkHipError
+    from shark_amd.capi import SHK_PIPE_DEPTH, hip_memcpy_dtoh
+    rng = np.random.default_rng(4141)
+    genes = synth.make_genes(rng, 20, 400, 2500, share_every=3)
+    o, h, _ = _build_both(oracle, genes, k=17, bf_bits=1 << 30)
+    dev = torch.device("cuda:0")
+    specs = [dict(read_len=150, var_len=False, vouch=True), dict(read_len=150, var_len=False, vouch=False), dict(read_len=100, var_len=True, vouch=False),
+             dict(read_len=150, var_len=False, vouch=True, host=True), dict(read_len=125, var_len=False, vouch=True), dict(read_len=150, var_len=False, vouch=True, bound=60),
+             dict(read_len=90, var_len=False, vouch=True, paired=False), dict(read_len=150, var_len=True, vouch=False, bound=80)]
+    batches, want, keep = [], [], []
+    for sp in specs:
+        b = synth.make_reads(rng, genes, 1500, read_len=sp["read_len"], paired=sp.get("paired", True), on_target=0.6, var_len=sp["var_len"])
+        batches.append(b)
+        want.append(o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"]))
+    h.gene_counts_reset()
+    with pytest.raises(SharkHipError):
+        b = batches[0]
+        h.submit_device(1500, 1, 1, 1, 1, max_read_len=0)                # no bound: refused before anything is touched
+    tickets, got = [], []
+
+    def drain():
+        kind, t = tickets.pop(0)
+        if kind == "host":
+            got.append(h.wait(t))
+            return
+        r = h.wait_device(t)
+        g = np.empty(int(r.n) + 1, np.uint32)
+        hip_memcpy_dtoh(g, r.gene_off, g.nbytes)
+        ids = np.empty(int(r.n_assoc), np.uint16)
+        if len(ids):
+            hip_memcpy_dtoh(ids, r.gene_ids, ids.nbytes)
+        got.append((g, ids))
+
+    for sp, b in zip(specs, batches):
+        if len(tickets) == SHK_PIPE_DEPTH:
+            with pytest.raises(SharkHipError, match="not allowed"):
+                h.submit(b["seq1"], b["off1"], b["seq2"], b["off2"])
+            drain()
+        if sp.get("host"):
+            tickets.append(("host", h.submit(b["seq1"], b["off1"], b["seq2"], b["off2"])))
+            continue
+        t = {kk: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for kk, v in b.items() if v is not None}
+        keep.append(t)
+        torch.cuda.synchronize()
+        paired = b["seq2"] is not None
+        L = sp["read_len"]
+        tickets.append(("dev", h.submit_device(1500, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr() if paired else 0,
+                                               t["off2"].data_ptr() if paired else 0, max_read_len=sp.get("bound", L),
+                                               uniform_len1=L if sp["vouch"] and "bound" not in sp else 0,
+                                               uniform_len2=L if sp["vouch"] and paired and "bound" not in sp else 0)))
+    while tickets:
+        drain()
+    for i, ((wg, wi), (gg, gi)) in enumerate(zip(want, got)):
+        assert np.array_equal(wg, gg) and np.array_equal(wi, gi), specs[i]
+    allids = np.concatenate([w[1] for w in want])
+    assert np.array_equal(h.gene_counts(32), np.bincount(allids, minlength=32)[:32].astype(np.uint64))
+
+
 def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
     """device-resident batches: uniform_check_kernel decides on the device whether every read has one length per mate (two offsets
     per thread, the third from the next lane).  One read a base shorter -- first, last, odd / even index, either side of a wave and
@@ -1150,10 +1214,12 @@ def test_handworked_cases(case, probe, tmp_path):
     from tests.test_oracle import _handworked_batch
     h = _hip(k=case["k"], c=case["c"], bf_bits=case["bf_bits"], min_quality=case["q"], single=case["single"])
     info = h.build([seq.encode() for _, seq in case["fasta"]])
-    assert info["n_set_bits"] == case["distinct_kmers"]
+    assert info["n_set_bits"] == case.get("set_bits", case["distinct_kmers"])
     batch, paired = _handworked_batch(case)
     goff, gids = h.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"])
     assert [list(map(int, gids[goff[i]:goff[i + 1]])) for i in range(len(case["reads"]))] == [r["genes"] for r in case["reads"]]
+    if case.get("no_cli"):      # (the collision case: a 64-bit filter, which the CLI's -b -- in GB -- cannot name)
+        return
     # end to end through the shark CLI: ssv bytes (-b 1 = 2^33 bits; the few k-mers of a case do not collide there either)
     fa = tmp_path / "g.fa"
     fa.write_text("".join(">%s\n%s\n" % (n_, s_) for n_, s_ in case["fasta"]))
@@ -1638,6 +1704,46 @@ def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
                 n_assigned += int(goff[-1])
             h.close()
     assert n_assigned > 0
+
+
+@pytest.mark.parametrize("n_genes,share,L1,L2,k", [(2, 0, 150, 150, 17), (10, 0, 150, 150, 17), (10, 3, 150, 150, 17), (6, 2, 100, 100, 17), (4, 2, 150, 150, 31),
+                                                   (10, 3, 250, 0, 21), (3, 0, 151, 101, 17), (8, 4, 140, 140, 12)])
+def test_sparse_first_rounds_on_indices_of_several_genes(oracle, monkeypatch, n_genes, share, L1, L2, k):
+    """an index of SEVERAL genes held in LDS: the first 128 slots in the sparse order (even slots + tiles, then the rest of the
+    prefix) settle a read when every match is a single-gene list of one gene, what they cover passes c * len and exceeds what the
+    unprobed slots could still give any other gene -- 128 probes instead of 192 and no vote.  Genes without anything in common,
+    genes sharing halves (their k-mers have multi-gene lists: the escape value sends such reads to the usual path), reads from one
+    gene with 0-12 % errors, chimeric reads of two genes on either side of every bound, mates from different genes, N, quality
+    masks, thresholds from 0 to 1, uniform and trimmed batches: the oracle's result with the sparse rounds -- asserted to be what
+    ran -- and (SHK_NO_SPARSE=1 at index build time) without"""
+    monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
+    rng = np.random.default_rng(8800 + 10 * n_genes + L1 + k)
+    genes = synth.make_genes(rng, n_genes, 1_200, 2_400, share_every=share)
+    genes[0][700:702] = ord("N")
+    n_assigned = n_ties = 0
+    for sparse in (True, False):
+        if sparse:
+            monkeypatch.delenv("SHK_NO_SPARSE", raising=False)
+        else:
+            monkeypatch.setenv("SHK_NO_SPARSE", "1")
+        for c, q, single in ((0.6, 0, False), (0.3, 0, False), (0.45, 20, False), (0.8, 0, True), (1.0, 0, False), (0.0, 0, False)):
+            o, h, info = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=c, min_quality=q, single=single)
+            assert h.probe_mode() == "lds-table", h.probe_mode()
+            for ragged in (False, True):
+                for sub_rate in (0.0, 0.01, 0.05, 0.12):
+                    batch = _sequenced_pairs(rng, genes, 400, L1, L2, ragged, q > 0, sub_rate, 0.002 if sub_rate else 0.0, 0.003)
+                    goff, _ = _compare_classify(o, h, batch)
+                    n_assigned += int(goff[-1])
+                    n_ties += int((np.diff(goff.astype(np.int64)) > 1).sum())
+                    if not ragged and ", 21, " in h.last_kernel():
+                        assert ("+sparse-first-rounds" in h.last_kernel()) == sparse, h.last_kernel()
+                batch = _chimeric_batch(rng, genes, 800, L1, L2, ragged, with_n=True, qual=q > 0, k_hint=k)
+                goff, _ = _compare_classify(o, h, batch)
+                n_assigned += int(goff[-1])
+            h.close()
+    assert n_assigned > 1000
+    if share:
+        assert n_ties > 0          # shared halves: reads with two genes came through (the escape path)
 
 
 # ---------------------------------------------------------------------------

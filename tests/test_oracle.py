@@ -230,6 +230,10 @@ def _handworked():
     return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "handworked.json")))["cases"]
 
 
+def L_hash(oracle, v):
+    return int(oracle.lib().so_get_hash(v))
+
+
 def _handworked_batch(case):
     from tests import synth
     paired = case["reads"][0]["m2"] is not None
@@ -244,7 +248,15 @@ def _handworked_batch(case):
 def test_handworked_cases(oracle, case, tmp_path):
     o = oracle.Shark(k=case["k"], c=case["c"], bf_bits=case["bf_bits"], min_quality=case["q"], single=case["single"])
     o.build([seq.encode() for _, seq in case["fasta"]])
-    assert o.num_kmer() == case["distinct_kmers"]                      # no filter collision: the derivations' one assumption
+    assert o.num_kmer() == case.get("set_bits", case["distinct_kmers"])    # no filter collision (the derivations' one assumption), or exactly the case's
+    if "xxh64_mod_64" in case:                                         # the case's filter positions: python-xxhash, not the oracle's own hash
+        import struct
+        import xxhash
+        for kmer, pos in case["xxh64_mod_64"].items():
+            v = 0
+            for ch in kmer:
+                v = (v << 2) | "ACGT".index(ch)
+            assert xxhash.xxh64(struct.pack("<Q", v), seed=0).intdigest() % 64 == pos == L_hash(oracle, v) % 64, kmer
     L = oracle.lib()
     batch, paired = _handworked_batch(case)
     for r in case["reads"]:
@@ -256,6 +268,10 @@ def test_handworked_cases(oracle, case, tmp_path):
         assert (ln, [mx, mk], genes) == (r["len"], r["best"], r["genes"]), r["id"]
     goff, gids = o.classify(batch["seq1"], batch["off1"], batch["seq2"], batch["off2"], batch["qual1"], batch["qual2"])
     assert [list(map(int, gids[goff[i]:goff[i + 1]])) for i in range(len(case["reads"]))] == [r["genes"] for r in case["reads"]]
+    if case.get("no_cli"):                                             # (a filter size the CLI's -b, which counts in GB, cannot name)
+        names = [n_ for n_, _ in case["fasta"]]
+        assert "".join("%s %s\n" % (r["id"], names[g]) for r in case["reads"] for g in r["genes"]) == case["ssv"]
+        return
     # and end to end through the oracle CLI: ssv bytes
     fa = tmp_path / "g.fa"
     fa.write_text("".join(">%s\n%s\n" % (n_, s_) for n_, s_ in case["fasta"]))
