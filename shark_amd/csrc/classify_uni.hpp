@@ -175,10 +175,13 @@ struct UniGeom {
 // and the sparse round's plan, and whatever the compiler derives from them -- is a wave constant exactly as for a uniform batch;
 // a pair brings its two offsets.  (The ragged instantiation re-derives all that per read: 317 VALU + 168 scalar instructions per
 // trimmed pair against 199 + 78; 10 M pairs trimmed to 100-150 bases: 7.1 -> 4.6 ms.)
-template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false>
+// LXM (exact-table instantiations, uniform batches): an index of SEVERAL genes -- the sparse first rounds with the early decision's
+// argument (sparse_first).  A compile-time form: as a run-time one it cost the one-gene index 3 % (4.18 -> 4.30 ms per 10 M pairs).
+template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false>
 __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
   static_assert(!CLS || UNI, "CLS is a form of the uniform instantiation");
+  static_assert(!LXM || (UNI && !CLS && pm_lds(MODE) && LSL == 21), "LXM is a form of the uniform exact-table instantiation");
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
@@ -351,10 +354,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   //  instead of one was measured as well and changed nothing: 4.21 -> 4.29 ms)
   uint32_t *sp_count = nullptr;
   uint16_t *sp_inl = nullptr;
-  // sp_one: ONE gene in the index (the argument above).  Several genes (P.lx_multi): the same two rounds in the same order settle a read
-  // too, by the early decision's argument instead -- see sparse_first
-  const bool sp_one = SPARSE && P.lx_gene != 0xFFFFFFFFu;
-  const bool sp_on = SPARSE && (P.lx_gene != 0xFFFFFFFFu || P.lx_multi != 0u);
+  // sp_one: ONE gene in the index (the argument above).  Several genes (the LXM instantiation): the same two rounds in the same order
+  // settle a read too, by the early decision's argument instead -- see sparse_first
+  constexpr bool sp_one = !LXM;
+  const bool sp_on = SPARSE && (LXM ? P.lx_multi != 0u : P.lx_gene != 0xFFFFFFFFu);
   // floor(x / k) and floor(x / (k - 1)) for x < 2048 as a multiplication (k <= 32)
   const uint32_t sp_rk = sp_on ? (65536u + k - 1u) / k : 0u, sp_rk1 = (sp_on && k > 1u) ? (65536u + k - 2u) / (k - 1u) : 0u;
   // the smallest slot s with bases_behind(s) <= B
@@ -1678,6 +1681,13 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
     return;
   }
   const bool uni = rmode == 1;
+  if (uni && lx && mode == PM_LDS_TAB && p.lx_multi) {
+    if constexpr (U <= 5 || U == 10) {
+      if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, true, 21, true, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+      else hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+    }
+    return;
+  }
 #define LU4(M_, L_, HQ_, UN_) hipLaunchKernelGGL((classify_uni_kernel<U, M_, HQ_, L_, UN_>), dim3(grid), dim3(UniGeom<U, M_, L_>::THREADS), 0, s, p)
 #define LU(M_, L_) do { if (uni) { if (hasq) LU4(M_, L_, true, true); else LU4(M_, L_, false, true); } \
                         else if (L_ != 20) { if (hasq) LU4(M_, L_, true, false); else LU4(M_, L_, false, false); } } while (0)

@@ -38,7 +38,7 @@ for step in "$@"; do
     ab:*)        IFS=: read -r _ ot libs <<< "$step"
                  for rep in 1 2; do for v in $(echo $libs | tr ':' ' '); do
                    if [ $v = base ]; then unset SHK_LIB_PATH; else export SHK_LIB_PATH=$PWD/tools/variants/$v.so; fi
-                   timeout -k 10 300 python3 bench.py --no-configs --no-cpu-baseline --no-boundary --no-cli --no-live-counters --steps 2 --reps-per-step 2 --total-pairs 20000000 --on-target $ot 2>> $log \
+                   timeout -k 10 300 python3 bench.py --no-configs --no-cpu-baseline --no-boundary --no-cli --no-live-counters --no-async --no-trimmed --steps 2 --reps-per-step 2 --total-pairs 20000000 --on-target $ot 2>> $log \
                      | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['config']['on_target'], d['roofline']['kernel_ms'], d['config']['assoc_per_step'], d['roofline']['kernel_reported_by_library'])" | tee -a $log.txt
                  done; done; unset SHK_LIB_PATH ;;
     abpy:*)      # abpy:<lib>+<lib>..:<script@args>  the script on library variants (base = in-tree), interleaved, twice; one output line each
