@@ -24,7 +24,7 @@ for step in "$@"; do
   echo "== $step $(date +%T)"
   log=$out/$(printf %02d $i)_$(echo "$step" | tr ':/ ,' '____').log
   case $step in
-    suite)       timeout -k 10 1150 python3 -m pytest tests -m gpu -x -q --durations=15 > $log 2>&1 ;;
+    suite)       timeout -k 10 1150 python3 -m pytest tests -m gpu -x -q --durations=60 > $log 2>&1 ;;
     scale)       timeout -k 10 1150 python3 -m pytest tests/test_gpu_scale.py -x -q --durations=5 > $log 2>&1 ;;
     fuzz)        timeout -k 10 900 python3 -m pytest tests/test_gpu_fuzz.py -x -q -s > $log 2>&1 ;;
     t:*)         timeout -k 10 1150 python3 -m pytest tests/test_gpu_parity.py -k "${step#t:}" -x -q --durations=8 > $log 2>&1 ;;
