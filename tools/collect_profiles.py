@@ -70,6 +70,9 @@ for name, c in raw.items():
     # bench.py --profile-passes: {workload: {"kernel": ..., counter: value per launch, ...}}
     if not c:
         continue
+    if name == "valu_mix":      # shk_measure_valu_mix's kernel: VALU instructions per wave-iteration by waves per SIMD
+        out["valu_mix_instructions_per_wave_iteration"] = c
+        continue
     e = {"kernel": c.get("kernel"), "kernel_reported_by_library": c.get("kernel_reported_by_library"), "pairs": 10_000_000, "n_assoc": c.get("n_assoc")}
     for key in ("FETCH_SIZE", "WRITE_SIZE"):
         if key in c:
