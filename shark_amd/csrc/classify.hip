@@ -35,6 +35,7 @@
 // nothing hit -- the common case for off-target reads.  DESIGN.md 3 has the full description and
 // what bounds the kernel.
 #include <cstdio>
+#include <cstring>
 
 #include "classify_common.hpp"
 
@@ -1176,6 +1177,14 @@ bool uni_kernel_available(const Ctx *ctx)
   return pm_tab(probe_mode(ctx->idx)) && !ctx->idx.wrap && !ctx->env_force_generic;
 }
 
+// (classify_uni.hpp's tri_applies, restated for the launcher's report: the lengths for which three pairs share a staging pass)
+static bool tri_applies_host(uint32_t L1, uint32_t L2, uint32_t k, uint32_t S)
+{
+  const uint32_t c1 = (L1 + 15u) >> 4, c2 = (L2 + 15u) >> 4;
+  const uint32_t nk2 = L2 >= k ? L2 - k + 1u : 0u, nk1 = L1 >= k ? L1 - k + 1u : 0u;
+  return L1 != 0u && c1 + c2 <= 21u && (nk2 ? (c1 << 4) + nk2 : nk1) <= S;
+}
+
 // classify_uni_kernel lives in classify_uni.hpp, instantiated per unroll in classify_uni_u<U>.hip
 void launch_uni_u2(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
 void launch_uni_u3(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s);
@@ -1235,6 +1244,8 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lsum_shift = ctx->idx.ltab_mul;   // (no summary in this mode: the field carries the table's slot multiplier)
     p.lx_gene = ctx->idx.ltab_gene;
     p.lx_multi = (uni && ctx->idx.ltab_sparse && ctx->idx.ltab_gene == 0xFFFFFFFFu) ? 1u : 0u;
+    // three pairs per staging pass (classify_uni.hpp, TRI): uniform batches without qualities, U = 3 ... 5 (SHK_NO_TRI=1: not)
+    p.tri = (rmode == 1 && !hasq && u >= 3 && u <= 5 && !ctx->env_no_tri) ? 1u : 0u;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : (mode == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));   // (= UniGeom::MIN_WAVES)
@@ -1258,6 +1269,10 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
              (lx && (u <= 5 || u == 10)) ? 21 : ((big && (u <= 5 || u == 10)) ? 20 : 18), p.uni_flag ? "device" : (uni ? "true" : "false"),
              (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "",
              (lx && p.lx_gene != 0xFFFFFFFFu) ? " +sparse-first-round" : ((lx && p.lx_multi) ? " +sparse-first-rounds" : ""));
+  if (lx && p.tri && (uni || !p.uni_flag) && (p.uni_flag || tri_applies_host(p.uni_L1, p.uni_L2, p.k, 64u * u))) {
+    const size_t l = strlen(ctx->last_kernel);
+    snprintf(ctx->last_kernel + l, sizeof(ctx->last_kernel) - l, p.uni_flag ? " +three-pairs-if-they-fit" : " +three-pairs");
+  }
   return SHK_OK;
 }
 

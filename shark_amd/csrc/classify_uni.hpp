@@ -177,11 +177,25 @@ struct UniGeom {
 // trimmed pair against 199 + 78; 10 M pairs trimmed to 100-150 bases: 7.1 -> 4.6 ms.)
 // LXM (exact-table instantiations, uniform batches): an index of SEVERAL genes -- the sparse first rounds with the early decision's
 // argument (sparse_first).  A compile-time form: as a run-time one it cost the one-gene index 3 % (4.18 -> 4.30 ms per 10 M pairs).
-template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false>
+// TRI (exact-table instantiations, uniform batches without qualities): THREE pairs per staging pass.  Staging is what a pair
+// costs before its first probe -- 65 VALU wave-instructions, a third of an off-target pair's -- and with 8 bases per lane only 38 of a
+// wave's 64 lanes have a 2 x 150 bp pair's bases to stage.  Here a lane stages 16 bases: ten lanes a mate, twenty a pair, and the
+// wave stages three consecutive pairs at once into three staging areas (60 lanes busy; the twice longer per-lane work is paid once
+// for three pairs), then classifies them one after the other exactly as before.  Mate 2 is packed at 16 x ceil(L1 / 16) instead of
+// 8 x ceil(L1 / 8); results do not depend on where mate 2 is packed (see FIXLAY).  tri_applies() says for which lengths.
+__host__ __device__ inline bool tri_applies(const uint32_t L1, const uint32_t L2, const uint32_t k, const uint32_t S)
+{
+  const uint32_t c1 = (L1 + 15u) >> 4, c2 = (L2 + 15u) >> 4;
+  const uint32_t nk2 = L2 >= k ? L2 - k + 1u : 0u, nk1 = L1 >= k ? L1 - k + 1u : 0u;
+  const uint32_t ns = nk2 ? (c1 << 4) + nk2 : nk1;
+  return L1 != 0u && c1 + c2 <= 21u && ns <= S;
+}
+template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false, bool TRI = false>
 __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
   static_assert(!CLS || UNI, "CLS is a form of the uniform instantiation");
   static_assert(!LXM || (UNI && !CLS && pm_lds(MODE) && LSL == 21), "LXM is a form of the uniform exact-table instantiation");
+  static_assert(!TRI || (UNI && !CLS && !HASQ && pm_lds(MODE) && LSL == 21 && U <= 8), "TRI is a form of the uniform exact-table instantiation without qualities");
   constexpr bool POW2 = pm_pow2(MODE);
   constexpr bool LSUM = pm_lds(MODE);
   constexpr bool SUM = MODE == PM_TAB_SUM;
@@ -203,7 +217,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   constexpr uint32_t S = 64 * U;
   // per wave: fw + rv + validity, and -- table modes, for the base-by-base form of the anchored extension -- one more bit stream: agreement with the reference
   constexpr uint32_t WORDS = stage_words_for(S) + ((ANCH && SHK_ANCH_BASEWISE) ? vbit_words_for(S) : 0u);
-  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS];
+  constexpr uint32_t AREAS = TRI ? 3u : 1u;      // staging areas per wave
+  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS * AREAS];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
@@ -219,6 +234,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   }
   L1 = __builtin_amdgcn_readfirstlane(L1);
   L2 = __builtin_amdgcn_readfirstlane(L2);
+  // the three-pairs-per-pass instantiation and the ordinary one are launched side by side when only the device knows the lengths
+  // (P.tri): exactly one of them works
+  if (TRI && !tri_applies(L1, L2, P.k, 64u * U)) return;
+  if (!TRI && UNI && !CLS && P.tri && tri_applies(L1, L2, P.k, 64u * U)) return;
   // G: staging groups (8 bases) per lane -- one up to 512 bases per pair, two beyond (U = 10: 2 x 300 bp)
   constexpr int G = U > 8 ? 2 : 1;
   // FIXLAY: the ragged instantiation that keeps the exact table in LDS (one-gene indices: instruction-bound, 128 VGPRs to its name).
@@ -254,10 +273,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     __syncthreads();
   }
   const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
-  uint64_t *wbase = lds + UG::SUM_WORDS64 + wave * WORDS;
-  uint32_t *const fw = reinterpret_cast<uint32_t *>(wbase);
-  uint32_t *const rv = fw + code_dwords_for(S);
-  uint64_t *const vbits = wbase + code_dwords_for(S);
+  uint64_t *wbase = lds + UG::SUM_WORDS64 + wave * WORDS * AREAS;
+  // (TRI: re-pointed to the area of the pair at hand)
+  uint32_t *fw = reinterpret_cast<uint32_t *>(wbase);
+  uint32_t *rv = fw + code_dwords_for(S);
+  uint64_t *vbits = wbase + code_dwords_for(S);
   [[maybe_unused]] uint64_t *const mbits = vbits + vbit_words_for(S);   // (base-by-base form of the anchored extension only) bit p: the read's base at packed position p equals the reference's under the mate's anchor
   constexpr uint32_t rcap = stage_cap_bases(S);
 
@@ -306,6 +326,29 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
   };
   set_geometry(L1, L2);
+  // TRI: 16 bases per lane.  Lane -> (pair of the triple, chunk of the pair); a pair has c1 + c2 chunks, mate 2's first one at packed
+  // position P2 = 16 c1.  The 8-base arrays above stay unused but for act[0], which lane_valid_bases() reads: a pair's validity
+  // bytes are 2 (c1 + c2).
+  uint32_t tri_lp = 0, tri_pr = 0, tri_cl = 0, tri_bofs = 0, tri_tail = 0, tri_Lm = 0;
+  bool tri_act = false;
+  const uint8_t *tri_base = nullptr;
+  if (TRI) {
+    const uint32_t c1 = (L1 + 15u) >> 4, c2 = (L2 + 15u) >> 4;
+    tri_lp = c1 + c2;
+    P2 = c1 << 4;
+    g2 = P2 >> 3;
+    n_groups = 2u * tri_lp;
+    act[0] = (uint32_t)lane < n_groups;
+    tri_pr = ((uint32_t)lane >= tri_lp ? 1u : 0u) + ((uint32_t)lane >= 2u * tri_lp ? 1u : 0u);
+    tri_cl = (uint32_t)lane - tri_pr * tri_lp;
+    tri_act = (uint32_t)lane < 3u * tri_lp;
+    const bool in2 = tri_cl >= c1;
+    tri_bofs = (in2 ? tri_cl - c1 : tri_cl) << 4;
+    tri_Lm = in2 ? L2 : L1;
+    const uint32_t rem = tri_act ? tri_Lm - tri_bofs : 16u;       // (>= 1: a chunk holds a base of its mate)
+    tri_tail = rem < 16u ? (0xFFFFu << rem) & 0xFFFFu : 0u;
+    tri_base = (in2 ? P.seq2 : P.seq1) + tri_bofs;
+  }
   // (ragged batches) what a read of the batch brings of its own: slots per mate, and which of a lane's bases lie behind its mate's end
   auto set_read = [&](const uint32_t l1, const uint32_t l2) {
     nk1 = l1 >= k ? l1 - k + 1 : 0;
@@ -411,7 +454,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     qbase[g] = HASQ ? (m2[g] ? P.qual2 : P.qual1) + bofs[g] : nullptr;
   }
   // the unguarded loads read up to 11 bytes behind a group's first byte: fine while that stays inside the mate's buffer
-  const uint32_t n32 = CLS ? ent_end : (uint32_t)P.n, stride = CLS ? 1u : gridDim.x * WAVES;
+  // (TRI: the loop below walks TRIPLES of consecutive reads)
+  const uint32_t n_reads = (uint32_t)P.n;
+  const uint32_t n32 = CLS ? ent_end : (TRI ? (n_reads + 2u) / 3u : n_reads), stride = CLS ? 1u : gridDim.x * WAVES;
   const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
   const uint32_t guard_reads = Lmin >= 12u ? 1u : (Lmin ? (12u + Lmin - 1u) / Lmin : n32);   // trailing reads with guarded loads
 
@@ -497,7 +542,37 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     return c;
   };
 
-  uint32_t it = CLS ? ent_first : blockIdx.x * WAVES + wave;   // position in the batch (CLS: in the list of entries)
+  // (TRI) the 16 bases lane (pair tri_pr, chunk tri_cl) stages of triple t: five aligned dwords.  An unguarded fetch reads up to 19
+  // bytes from the chunk's first -- into the reads behind it --, so the last reads of the batch take the guarded form (only dwords
+  // that hold a byte of the mate)
+  struct Raw16 { uint32_t d0, d1, d2, d3, d4, sh; };
+  const uint32_t tri_guard = Lmin ? (19u + Lmin - 1u) / Lmin : 0u;
+  auto tri_issue = [&](const uint32_t t) -> Raw16 {
+    Raw16 r{0u, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t rd = 3u * t + tri_pr;
+    if (tri_act && rd < n_reads) {
+      const uint8_t *sp = tri_base + (uint64_t)rd * tri_Lm;
+      const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(sp) & 3u;
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(sp - sh);
+      r.sh = sh;
+      if (n_reads - rd > tri_guard) {
+        r.d0 = q[0]; r.d1 = q[1]; r.d2 = q[2]; r.d3 = q[3]; r.d4 = q[4];
+      } else {
+        const uint32_t nb = tri_Lm - tri_bofs < 16u ? tri_Lm - tri_bofs : 16u;
+        const uint32_t last = sh + nb - 1u;              // index of the last wanted byte relative to q
+        r.d0 = q[0];
+        r.d1 = last >= 4u ? q[1] : 0u;
+        r.d2 = last >= 8u ? q[2] : 0u;
+        r.d3 = last >= 12u ? q[3] : 0u;
+        r.d4 = last >= 16u ? q[4] : 0u;
+      }
+    }
+    return r;
+  };
+  auto tri_retire = [&](Raw16 &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.d0), "+v"(r.d1), "+v"(r.d2), "+v"(r.d3), "+v"(r.d4)); };
+  Raw16 t_cur{0u, 0u, 0u, 0u, 0u, 0u};
+
+  uint32_t it = CLS ? ent_first : blockIdx.x * WAVES + wave;   // position in the batch (CLS: in the list of entries; TRI: the triple)
   if (!CLS && it >= n32) return;
   uint32_t read = it;                                          // the read's index in the batch: where its result goes
   Raw8 w_cur[G], q_cur[G];
@@ -539,6 +614,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   if (CLS) {
     entry_fetch(it, w_cur, q_cur);
     read = read_nxt;
+  } else if (TRI) {
+    t_cur = tri_issue(it);
+    tri_retire(t_cur);
   } else if (UNI) {
     issue(read, w_cur, q_cur);
   } else {
@@ -559,8 +637,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     ReadMetaRaw r_nn{};
     uint32_t nn = n32;
     uint4 pl_nxt = make_uint4(0u, 0u, 0u, 0u);
+    Raw16 t_nxt{0u, 0u, 0u, 0u, 0u, 0u};
     if (CLS) {
       if (have_nxt) entry_fetch(nxt, w_nxt, q_nxt);
+    } else if (TRI) {
+      if (have_nxt) t_nxt = tri_issue(nxt);
     } else if (UNI) {
       if (have_nxt) issue(nxt, w_nxt, q_nxt);
     } else {
@@ -587,8 +668,31 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
 
     // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
     uint32_t inv_real = 0u;   // invalid characters among the lane's bases that belong to the read
+    if (TRI) {
+      // sixteen bases of pair tri_pr of the triple into that pair's area: the same three streams, a dword / a dword / 16 bits per chunk
+      if (tri_act && 3u * it + tri_pr < n_reads) {
+        const uint32_t sh = t_cur.sh;
+        const uint32_t b0 = __builtin_amdgcn_alignbyte(t_cur.d1, t_cur.d0, sh), b1 = __builtin_amdgcn_alignbyte(t_cur.d2, t_cur.d1, sh);
+        const uint32_t b2 = __builtin_amdgcn_alignbyte(t_cur.d3, t_cur.d2, sh), b3 = __builtin_amdgcn_alignbyte(t_cur.d4, t_cur.d3, sh);
+        uint32_t c0, c1, c2, c3, i0, i1, i2, i3;
+        classify4(b0, c0, i0);
+        classify4(b1, c1, i1);
+        classify4(b2, c2, i2);
+        classify4(b3, c3, i3);
+        const uint32_t msb32 = (pack4(c0) << 24) | (pack4(c1) << 16) | (pack4(c2) << 8) | pack4(c3);      // first base in bits 31:30
+        const uint32_t inv16 = gather4(i0) | (gather4(i1) << 4) | (gather4(i2) << 8) | (gather4(i3) << 12) | tri_tail;
+        uint32_t lsb32 = __builtin_bitreverse32(msb32);
+        lsb32 = ((lsb32 >> 1) & 0x55555555u) | ((lsb32 & 0x55555555u) << 1);
+        uint64_t *area = wbase + tri_pr * WORDS;
+        uint32_t *fwa = reinterpret_cast<uint32_t *>(area);
+        fwa[tri_cl] = lsb32;
+        (fwa + code_dwords_for(S))[(rcap >> 4) - 1u - tri_cl] = msb32;
+        reinterpret_cast<uint16_t *>(area + code_dwords_for(S))[tri_cl] = (uint16_t)(~inv16 & 0xFFFFu);
+        inv_real = inv16 & ~tri_tail;
+      }
+    }
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < (TRI ? 0 : G); ++g) {
       if (act[g]) {
         const uint32_t gi = (uint32_t)lane + 64u * g;
         const uint32_t sh = w_cur[g].shn & 3u;
@@ -619,6 +723,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // (TRI: the three pairs of the triple one after the other, each in its own staging area)
+    for (uint32_t tp = 0; tp < AREAS; ++tp) {
+    if (TRI) {
+      read = 3u * it + tp;
+      if (read >= n_reads) break;
+      uint64_t *area = wbase + tp * WORDS;
+      fw = reinterpret_cast<uint32_t *>(area);
+      rv = fw + code_dwords_for(S);
+      vbits = area + code_dwords_for(S);
+    }
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
     if (!UNI) {
       const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.w);
@@ -639,7 +753,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
     // a read without any invalid character (N, masked quality) -- most reads -- needs no validity window per slot: every existing
     // slot is a valid k-mer (table modes test validity before a probe; uniform branch around eight instructions per slot and round)
-    const bool any_inv = __ballot(inv_real != 0u) != 0ull;
+    const bool any_inv = __ballot((inv_real != 0u) & (!TRI || tri_pr == tp)) != 0ull;
     if (cutE < (uint32_t)U || JA_ROUNDS < U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
       if (any_inv) {
@@ -1653,8 +1767,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       else if (CUT && CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E1 : U)>{});
       else classify_staged(std::integral_constant<int, U>{});
     }
+    }   // the pairs of a triple
     }   // !skip
     if (!have_nxt) break;
+    if (TRI) { tri_retire(t_nxt); t_cur = t_nxt; }
     retire(w_nxt, q_nxt);
     if (!UNI) {
       retire_meta(r_nn);
@@ -1695,6 +1811,19 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
     return;
   }
   const bool uni = rmode == 1;
+  // the exact table in LDS, uniform batches without qualities: three pairs per staging pass where the lengths allow (TRI) -- decided
+  // here when the host knows the lengths, else both instantiations are launched and the device's verdict picks (p.tri)
+  if constexpr (U >= 3 && U <= 5) {
+    if (uni && lx && mode == PM_LDS_TAB && !hasq && p.tri) {
+      const bool host_knows = p.uni_flag == nullptr;
+      const bool applies = host_knows && tri_applies(p.uni_L1, p.uni_L2, p.k, 64u * U);
+      if (!host_knows || applies) {
+        if (p.lx_multi) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+        else hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+        if (applies) return;
+      }
+    }
+  }
   if (uni && lx && mode == PM_LDS_TAB && p.lx_multi) {
     if constexpr (U <= 5 || U == 10) {
       if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, true, 21, true, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);

@@ -139,6 +139,7 @@ struct ClassifyParams {
   const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
   uint32_t lsum_shift;
   uint32_t lx_gene;          // exact table in LDS (LSL = 21): the gene of a one-gene index (DeviceIndex::ltab_gene), else 0xFFFFFFFF
+  uint32_t tri;              // 1 = the three-pairs-per-pass instantiation (classify_uni.hpp, TRI) is launched beside the ordinary uniform one: the one whose lengths qualify works
   uint32_t lx_multi;         // exact table in LDS of an index of SEVERAL genes: the sparse first rounds with the early decision's argument (classify_uni.hpp)
   uint64_t bf_bits;
   uint64_t bf_mask;
@@ -325,13 +326,14 @@ struct Ctx {
   // test / A-B switches of the environment, read ONCE when the context is created (never per launch):
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
+  bool env_no_tri = false;          // SHK_NO_TRI=1: no three-pairs-per-pass instantiation (A/B timing, tests)
   bool env_ktab_always = false;     // SHK_KTAB=1: the minimiser table for every batch of an index that has it (tests)
   bool env_ktab_nt = false, env_ktab_plain = false;   // SHK_KTAB_NT=1 / 0: the minimiser table probed with / without non-temporal loads whatever its size (A/B timing, tests)
   bool env_force_generic = false, env_big_lds_always = false, env_cls_always = false;   // SHK_CLS_MIN_FILL given: no adapting to the stream
   uint32_t last_verdict = 0;        // CTR_VERDICT of the last batch finished
   uint32_t env_cls_min_fill = CLS_MIN_FILL;   // SHK_CLS_MIN_FILL: pairs per non-empty class a batch needs to go class by class (0: never; tests: 1)
   // which classify kernel the last batch's main launch was (shk_last_kernel): the choice can depend on the batch before it
-  char last_kernel[96] = "";
+  char last_kernel[160] = "";
 
   // timing
   bool timing = false;
