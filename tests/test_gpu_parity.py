@@ -1746,6 +1746,63 @@ def test_sparse_first_rounds_on_indices_of_several_genes(oracle, monkeypatch, n_
         assert n_ties > 0          # shared halves: reads with two genes came through (the escape path)
 
 
+@pytest.mark.parametrize("L1,L2,k,n_genes", [(150, 150, 17, 1), (150, 150, 17, 5), (100, 100, 17, 1), (151, 101, 17, 1), (76, 76, 21, 1), (160, 160, 17, 1),
+                                              (144, 145, 17, 1), (33, 17, 17, 1), (150, 0, 17, 1), (125, 125, 12, 3), (161, 160, 17, 1), (170, 170, 17, 1)])
+def test_three_pairs_per_staging_pass(oracle, monkeypatch, L1, L2, k, n_genes):
+    """the TRI instantiation of the exact-table kernel (uniform batches without qualities: a lane stages 16 bases, a wave three
+    consecutive pairs per pass, mate 2 packed at 16 x ceil(L1 / 16)): batches of 1 ... 8 pairs and of 3 m - 1, 3 m, 3 m + 1 pairs (the
+    last triple is short; the last reads of the batch take guarded loads), host and device-resident (the device's verdict picks
+    between the two launched instantiations), mates of unequal length, a mate exactly one k-mer long, single-end, N and lower
+    case anywhere incl. the bases beside a chunk boundary, lengths for which three pairs do not fit a pass or the specialisation is not compiled
+    for them (2 x 170, 2 x 100, 33 + 17: the ordinary instantiation -- asserted): the oracle's result, and what ran"""
+    from shark_amd.capi import hip_memcpy_dtoh
+    monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
+    rng = np.random.default_rng(9900 + L1 + 7 * L2 + k)
+    genes = synth.make_genes(rng, n_genes, 2_000, 3_000, share_every=0)
+    # what the library does: the specialisation for the pair's slots (8-base packing), three pairs per pass at U = 3 ... 5 when a
+    # pair is at most 21 chunks of 16 bases and its slots still fit with mate 2 packed at a multiple of 16
+    nk1, nk2 = max(0, L1 - k + 1), max(0, L2 - k + 1)
+    u = max(2, -(-((((L1 + 7) // 8) * 8 + nk2) if nk2 else nk1) // 64))
+    c1, c2 = (L1 + 15) // 16, (L2 + 15) // 16
+    fits = u in (3, 4, 5) and c1 + c2 <= 21 and ((c1 * 16 + nk2) if nk2 else nk1) <= 64 * u
+    assert fits == ((L1, L2) not in ((33, 17), (170, 170), (100, 100)))      # (2 x 100 bp: 112 + 84 slots do not fit U = 3's 192)
+    dev = torch.device("cuda:0")
+    for no_tri in (False, True):
+        if no_tri:
+            monkeypatch.setenv("SHK_NO_TRI", "1")
+        else:
+            monkeypatch.delenv("SHK_NO_TRI", raising=False)
+        o, h, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=0.5)
+        assert h.probe_mode() == "lds-table"
+        total = 0
+        for n in (1, 2, 3, 4, 5, 7, 8, 191, 192, 193, 3000):
+            b = synth.make_reads(rng, genes, n, read_len=max(L1, L2), paired=L2 > 0, on_target=0.6, n_rate=0.01, lower_rate=0.02)
+            # cut the mates to (L1, L2)
+            m1 = [bytes(b["seq1"][int(b["off1"][i]):int(b["off1"][i]) + L1]) for i in range(n)]
+            m2 = [bytes(b["seq2"][int(b["off2"][i]):int(b["off2"][i]) + L2]) for i in range(n)] if L2 else None
+            if n >= 191:                              # an N right at a chunk boundary of some reads
+                m1 = [x[:15] + b"N" + x[16:] if i % 5 == 0 and len(x) > 16 else x for i, x in enumerate(m1)]
+            bb = synth.batch_from_lists(m1, m2)
+            goff, _ = _compare_classify(o, h, bb)
+            total += int(goff[-1])
+            lk = h.last_kernel()
+            if ", 21, " in lk:
+                assert ("+three-pairs" in lk) == (fits and not no_tri), (lk, n)
+            # the same batch resident in HBM, in buffers that end with the last read
+            t = {kk: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for kk, v in bb.items() if v is not None}
+            torch.cuda.synchronize()
+            r = h.classify_device(n, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr() if L2 else 0, t["off2"].data_ptr() if L2 else 0,
+                                  max_read_len=max(L1, L2))
+            dg = np.empty(n + 1, np.uint32)
+            hip_memcpy_dtoh(dg, r.gene_off, dg.nbytes)
+            og, _ = o.classify(bb["seq1"], bb["off1"], bb["seq2"], bb["off2"])
+            assert np.array_equal(og, dg), (n, no_tri)
+            if ", 21, " in h.last_kernel() and not no_tri and u in (3, 4, 5):     # (the caller's bound picks the specialisation; the device the instantiation)
+                assert "+three-pairs-if-they-fit" in h.last_kernel()
+        assert total > 500
+        h.close()
+
+
 # ---------------------------------------------------------------------------
 # tiny indices: the exact table held in LDS (classify_uni_kernel LSL = 21, shark_internal.hpp LTAB_*)
 # ---------------------------------------------------------------------------
