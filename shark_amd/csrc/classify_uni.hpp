@@ -724,10 +724,14 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // (TRI: the three pairs of the triple one after the other, each in its own staging area)
-    for (uint32_t tp = 0; tp < AREAS; ++tp) {
+    // (a generic lambda called once per pair, not a loop: with the pair's area a compile-time offset from the wave's, the LDS
+    //  addresses of a pair's windows stay what they are for one area -- the lane's offset from a loop-invariant base, the area as the
+    //  instruction's immediate -- instead of an addition per address and pair)
+    auto per_pair = [&](auto tp_const) -> void {
+    constexpr uint32_t tp = decltype(tp_const)::value;
     if (TRI) {
       read = 3u * it + tp;
-      if (read >= n_reads) break;
+      if (read >= n_reads) return;
       uint64_t *area = wbase + tp * WORDS;
       fw = reinterpret_cast<uint32_t *>(area);
       rv = fw + code_dwords_for(S);
@@ -1767,7 +1771,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       else if (CUT && CutPlan<U>::E1 != CutPlan<U>::E0 && cutE == (uint32_t)CutPlan<U>::E1) classify_staged(std::integral_constant<int, (CUT ? CutPlan<U>::E1 : U)>{});
       else classify_staged(std::integral_constant<int, U>{});
     }
-    }   // the pairs of a triple
+    };   // per_pair
+    per_pair(std::integral_constant<uint32_t, 0u>{});
+    if constexpr (TRI) {
+      per_pair(std::integral_constant<uint32_t, 1u>{});
+      per_pair(std::integral_constant<uint32_t, 2u>{});
+    }
     }   // !skip
     if (!have_nxt) break;
     if (TRI) { tri_retire(t_nxt); t_cur = t_nxt; }
