@@ -81,6 +81,9 @@ COUNTER_SETS = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+    # the clock the chip held during the kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the dispatch's duration in the same pass
+    # (MI355X_MICROARCH.md, "DVFS give-back"); a set of its own, so that a box without the counter loses nothing else
+    ["GRBM_GUI_ACTIVE"],
 ]
 COUNTER_SETS_FULL = COUNTER_SETS + [["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM", "SQ_INSTS_VALU"]]
 WORKLOADS = ("configs1", "configs2", "configs4_uniform", "configs4_ends")
@@ -259,10 +262,14 @@ def parse_counter_dir(d, order):
                     did = int(r.get("Dispatch_Id") or r.get("Dispatch_ID") or i)
                 except ValueError:
                     did = i
-                rows.append((did, r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])))
+                try:
+                    dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                except (KeyError, ValueError, TypeError):
+                    dur = None
+                rows.append((did, r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"]), dur))
     rows.sort(key=lambda x: x[0])
     calls, cur, last_did = [], None, None
-    for did, kn, cn, v in rows:
+    for did, kn, cn, v, dur in rows:
         if "uniform_check_kernel" in kn:
             if did != last_did:
                 cur = {}
@@ -274,6 +281,8 @@ def parse_counter_dir(d, order):
         name = kn.split("(")[0].replace("void shk::", "")
         cur.setdefault(name, {})
         cur[name][cn] = cur[name].get(cn, 0.0) + v      # (a counter may be reported per XCD / per dimension: summed)
+        if cn == "GRBM_GUI_ACTIVE" and dur:
+            cur[name]["GRBM_PASS_NS"] = dur            # (the dispatch's duration in the pass that counted it)
     out, at = {}, 0
     for o in order:
         mine = calls[at:at + o["calls"]]
@@ -415,6 +424,13 @@ def instruction_part(e, n_pairs, kern_ms):
          "lds_per_pair": round(e.get("SQ_INSTS_LDS", 0) / n_pairs, 1),
          "G_valu_wave_instructions_per_s": round(iv / t / 1e9, 1), "frac_of_valu_issue_peak": round(iv / t / 1e9 / VALU_PEAK_GINST, 4),
          "simd_cycles_per_valu_instruction": round(t * CLK_GHZ * 1e9 * N_SIMD / iv, 2)}
+    ga, gns = e.get("GRBM_GUI_ACTIVE"), e.get("GRBM_PASS_NS")
+    if ga and gns:
+        # the clock the chip held during this kernel (it lowers it under load): busy cycles of the 8 XCDs / 8 / duration, same pass
+        clk = ga / 8.0 / gns
+        d["shader_clock_GHz"] = round(clk, 3)
+        d["simd_cycles_per_valu_instruction_at_that_clock"] = round(t * clk * 1e9 * N_SIMD / iv, 2)
+        d["frac_of_valu_issue_peak_at_that_clock"] = round(iv / t / 1e9 / (N_SIMD * clk / 2.0), 4)
     wc = e.get("SQ_WAVE_CYCLES")
     if wc:
         for key, nm in (("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_WAIT_ANY", "wait_any")):
@@ -1100,16 +1116,28 @@ def main():
                 for wv in (4, 8):
                     ipi = vm.get(str(wv))
                     if ipi:
-                        ms_mix, wi = h.measure_valu_mix(wv, 20000)
+                        ms_mix, wi, ghz_mix = h.measure_valu_mix_clock(wv, 20000)
                         mixc["%d_waves_per_simd" % wv] = {"G_valu_wave_instructions_per_s": round(ipi * wi / (ms_mix * 1e-3) / 1e9, 1),
                                                           "valu_per_iteration": round(ipi, 1),
-                                                          "simd_cycles_per_valu_instruction": round(ms_mix * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / (ipi * wi), 2)}
+                                                          "simd_cycles_per_valu_instruction": round(ms_mix * 1e-3 * CLK_GHZ * 1e9 * N_SIMD / (ipi * wi), 2),
+                                                          "shader_clock_GHz": round(ghz_mix, 3),
+                                                          "simd_cycles_per_valu_instruction_at_that_clock": round(ms_mix * 1e-3 * ghz_mix * 1e9 * N_SIMD / (ipi * wi), 2) if ghz_mix else None}
                 if mixc:
                     ref = mixc.get("4_waves_per_simd") or list(mixc.values())[0]
                     roofline["mix_ceiling"] = dict(mixc, what="G VALU wave-instructions/s of the exact-table kernel's own instruction mix on register operands "
                                                               "(stage, windows, canonical form, XXH64, table arithmetic, validity / coverage step; no LDS, no memory), "
                                                               "at the kernel's occupancy (4 waves per SIMD: its 144 KiB table admits one 16-wave workgroup per CU) and at 8")
                     roofline["frac_of_mix_ceiling"] = round(ip["G_valu_wave_instructions_per_s"] / ref["G_valu_wave_instructions_per_s"], 4)
+                    # the same two readings in CYCLES: the kernel and the mix each at the clock they were measured to hold (the kernel's from
+                    # GRBM_GUI_ACTIVE of its counter pass, the mix's from s_memtime / s_memrealtime inside it) -- `frac` prices the kernel at
+                    # 2.4 GHz whatever the chip ran at
+                    ck, cm = ip.get("simd_cycles_per_valu_instruction_at_that_clock"), ref.get("simd_cycles_per_valu_instruction_at_that_clock")
+                    if ck:
+                        roofline["clock"] = {"kernel_GHz": ip["shader_clock_GHz"], "mix_GHz": ref.get("shader_clock_GHz"), "nominal_GHz": CLK_GHZ,
+                                             "frac_at_measured_clock": ip["frac_of_valu_issue_peak_at_that_clock"],
+                                             "frac_of_mix_ceiling_in_cycles": round(cm / ck, 4) if cm else None,
+                                             "how": "kernel: GRBM_GUI_ACTIVE / 8 / dispatch duration in one rocprofv3 --pmc pass of this run; mix: sum of "
+                                                    "s_memtime deltas / sum of s_memrealtime deltas (100 MHz) around every wave's loop"}
             else:
                 roofline = {"bound": "hbm", "achieved": round((in_bytes + out_bytes) / t_k / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round((in_bytes + out_bytes) / t_k / 1e9 / HBM_PEAK_GBPS, 5),

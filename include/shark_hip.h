@@ -264,6 +264,12 @@ int shk_measure_random_lookups(shk_ctx *ctx, uint64_t table_bytes, uint64_t n_lo
  * to the fraction of the 2-cycle peak.  On no product path; new (the reference has no counterpart). */
 int shk_measure_valu_mix(shk_ctx *ctx, int waves_per_simd, uint32_t iters, double *ms, uint64_t *wave_iterations);
 
+/* The same, and *shader_ghz = the clock the SIMDs held while that kernel ran: shader cycles (s_memtime) over the constant 100 MHz
+ * counter (s_memrealtime) around each wave's loop, summed over the waves.  The chip lowers its clock under load, so a rate in
+ * instructions per second prices a kernel against 2.4 GHz it may not have had; bench.py reports cycles per instruction beside it
+ * (`roofline.clock`).  On no product path; new (the reference has no counterpart). */
+int shk_measure_valu_mix_clock(shk_ctx *ctx, int waves_per_simd, uint32_t iters, double *ms, uint64_t *wave_iterations, double *shader_ghz);
+
 /* pinned host memory helpers for callers that stream batches */
 void *shk_alloc_pinned(size_t bytes);
 void  shk_free_pinned(void *p);

@@ -52,6 +52,7 @@ EXPORTS = [
     "shk_classify_submit", "shk_classify_wait", "shk_dist_unique_id", "shk_dist_init", "shk_dist_gene_counts_allreduce",
     "shk_dist_info", "shk_measure_random_lookups", "shk_last_kernel", "shk_classify_device_submit",
     "shk_measure_valu_mix",
+    "shk_measure_valu_mix_clock",
 ]
 SHK_PIPE_DEPTH = 3
 SHK_DIST_ID_BYTES = 128
@@ -117,6 +118,9 @@ def load():
     L.shk_measure_random_lookups.argtypes = [p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.shk_measure_valu_mix.restype = C.c_int
     L.shk_measure_valu_mix.argtypes = [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    if hasattr(L, "shk_measure_valu_mix_clock"):      # (absent from older variant libraries, see above)
+        L.shk_measure_valu_mix_clock.restype = C.c_int
+        L.shk_measure_valu_mix_clock.argtypes = [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -332,6 +336,12 @@ class SharkHip:
         ms, wi = C.c_double(), C.c_uint64()
         self._check(self.L.shk_measure_valu_mix(self.h, waves_per_simd, iters, C.byref(ms), C.byref(wi)), "shk_measure_valu_mix")
         return ms.value, wi.value
+
+    def measure_valu_mix_clock(self, waves_per_simd=4, iters=20000):
+        """(ms, wave_iterations, shader_ghz): measure_valu_mix and the clock the SIMDs held meanwhile (s_memtime over s_memrealtime)"""
+        ms, wi, ghz = C.c_double(), C.c_uint64(), C.c_double()
+        self._check(self.L.shk_measure_valu_mix_clock(self.h, waves_per_simd, iters, C.byref(ms), C.byref(wi), C.byref(ghz)), "shk_measure_valu_mix_clock")
+        return ms.value, wi.value, ghz.value
 
     def timing_enable(self, on=True):
         self._check(self.L.shk_timing_enable(self.h, int(on)), "shk_timing_enable")

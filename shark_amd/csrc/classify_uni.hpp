@@ -127,6 +127,23 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #error "-DSHK_ABLATION builds a library that can return wrong results (SHK_ABLATE bits): say so with -DSHK_TIMING_ONLY as well"
 #endif
 // (-DSHK_NO_SPARSE=1: a build without the sparse first round of one-gene indices, for A/B timing; at run time SHK_NO_SPARSE=1 when the index is built)
+// -DSHK_STAMPS=1 (a diagnostic build of one translation unit, tools/stamps.sh): the three-pairs instantiation reads the shader
+// clock (s_memtime) at its phase boundaries and every wave adds its per-phase sums to shk_stamp_acc -- the cycle budget of
+// profiles/r05_headline_stamps.json.  A stamp waits for the scalar unit's outstanding loads (lgkmcnt covers the LDS as well), so a
+// phase that ends behind a probe is charged the probe's LDS latency; the product build contains none of this.
+#ifndef SHK_STAMPS
+#define SHK_STAMPS 0
+#endif
+#if SHK_STAMPS
+__device__ unsigned long long shk_stamp_acc[16];
+__device__ unsigned long long shk_stamp_waves[2 * 4096];   // per wave of the last launch: the 100 MHz counter at its loop's start and end
+#define SHK_STAMP(i) do { if constexpr (TRI) { const uint64_t t__ = __builtin_readcyclecounter(); st_acc[i] += t__ - st_last; st_last = t__; } } while (0)
+#else
+#define SHK_STAMP(i) do {} while (0)
+#endif
+#ifndef SHK_NO_DYN
+#define SHK_NO_DYN 0   // (-DSHK_NO_DYN=1: every wave walks its own fixed sequence of reads, for A/B timing)
+#endif
 #ifndef SHK_NO_SPARSE
 #define SHK_NO_SPARSE 0
 #endif
@@ -218,7 +235,13 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // per wave: fw + rv + validity, and -- table modes, for the base-by-base form of the anchored extension -- one more bit stream: agreement with the reference
   constexpr uint32_t WORDS = stage_words_for(S) + ((ANCH && SHK_ANCH_BASEWISE) ? vbit_words_for(S) : 0u);
   constexpr uint32_t AREAS = TRI ? 3u : 1u;      // staging areas per wave
-  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS * AREAS];
+  // DYN (exact table in LDS, uniform batches): the workgroup's waves take their reads (TRI: triples) from a counter in LDS instead of
+  // every wave walking its own fixed sequence.  The SIMD issues oldest wave first: with fixed sequences of equal length the four
+  // waves of a SIMD finished at 2.8 / 3.5 / 4.4 / 5.3 ms of a 5.3 ms launch (s_memrealtime at every wave's start and end, the stamped
+  // build of tools/stamps.sh) -- the SIMD spent the last third of the launch with two waves, then one, to hide its latencies
+  constexpr bool DYN = LX && UNI && !CLS && !SHK_NO_DYN;
+  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS * AREAS + (DYN ? 2 : 0)];
+  uint32_t *const dyn_ctr = reinterpret_cast<uint32_t *>(lds + UG::SUM_WORDS64 + WAVES * WORDS * AREAS);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
@@ -270,6 +293,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
+    if (DYN && threadIdx.x == 0) *dyn_ctr = 2u * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave)
     __syncthreads();
   }
   const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
@@ -437,8 +461,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (back < nkl && spLast >= back && spLast - back >= (128u - T) + k - 1u && ub < thr_full) { spT = T; spUb = ub; }
   };
   if (sp_on) {
-    sp_count = P.out->count;
-    sp_inl = P.out->inl;
+    // (through readfirstlane: values of their own from here on.  As plain loads the compiler is free to re-do them at every use when
+    //  scalar registers run short -- kernarg -> *P.out -> store, a dependent memory round trip and a vmcnt(0) per settled read; some
+    //  builds of the three-pairs kernel did)
+    const uint64_t pc = reinterpret_cast<uint64_t>(P.out->count), pi = reinterpret_cast<uint64_t>(P.out->inl);
+    sp_count = reinterpret_cast<uint32_t *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pc >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pc));
+    sp_inl = reinterpret_cast<uint16_t *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pi >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pi));
     if (UNI) plan_sparse(L1, L2);
   }
   // (ragged, fixed layout) where the mates' buffers end: off[n]
@@ -628,8 +656,26 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   }
   retire(w_cur, q_cur);
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;
+#if SHK_STAMPS
+  // phases: 0 loop head (next triple's loads issued) | 1 staging | 2 a pair's set-up | 3 round A's probe | 4 A's validation, coverage,
+  // verdict | 5 round B's probe | 6 everything else of a pair | 7 loop tail | 8 (count) triples | 9 (count) pairs
+  uint64_t st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t st_last = __builtin_readcyclecounter();
+  // 13 / 14: the wave's whole loop in shader cycles and in ticks of the constant 100 MHz counter -- their quotient is the clock the
+  // chip held during the launch
+  const uint64_t st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // DYN: turn q of the workgroup is position blockIdx.x * WAVES + q % WAVES + (q / WAVES) * stride of the batch -- the positions the
+  // workgroup's waves walk together in the fixed order, whoever takes them
+  uint32_t dyn_q = (uint32_t)WAVES + wave;
   for (;;) {
-    const uint32_t nxt = n32 - it > stride ? it + stride : n32;   // saturates at n32
+    uint32_t nxt;
+    if (DYN) {
+      const uint64_t v = (uint64_t)(dyn_q / (uint32_t)WAVES) * stride + (blockIdx.x * WAVES + dyn_q % (uint32_t)WAVES);
+      nxt = v < n32 ? (uint32_t)v : n32;
+    } else {
+      nxt = n32 - it > stride ? it + stride : n32;   // saturates at n32
+    }
     const bool have_nxt = nxt < n32;
     Raw8 w_nxt[G], q_nxt[G];
 #pragma unroll
@@ -650,6 +696,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
       if (FIXLAY) set_read(m_cur.L1, m_cur.L2); else set_geometry(m_cur.L1, m_cur.L2);
     }
+    // (DYN) the turn after the next: asked for here, behind the next one's loads, wanted at the end of this pass
+    uint32_t dyn_take = 0u;
+    if (DYN) {
+      if (lane == 0) dyn_take = atomicAdd(dyn_ctr, 1u);
+    }
+    SHK_STAMP(0);
     bool skip = false;
     if (!UNI) {
       const uint32_t ns = nk2 ? ((m_cur.L1 + 7u) & ~7u) + nk2 : nk1;
@@ -722,6 +774,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    SHK_STAMP(1);
+#if SHK_STAMPS
+    if constexpr (TRI) st_acc[8] += 1;
+#endif
 
     // (TRI: the three pairs of the triple one after the other, each in its own staging area)
     // (a generic lambda called once per pair, not a loop: with the pair's area a compile-time offset from the wave's, the LDS
@@ -732,11 +788,15 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (TRI) {
       read = 3u * it + tp;
       if (read >= n_reads) return;
+#if SHK_STAMPS
+      st_acc[9] += 1;
+#endif
       uint64_t *area = wbase + tp * WORDS;
       fw = reinterpret_cast<uint32_t *>(area);
       rv = fw + code_dwords_for(S);
       vbits = area + code_dwords_for(S);
     }
+    SHK_STAMP(10);
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
     if (!UNI) {
       const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.w);
@@ -766,6 +826,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       }
     }
 
+    SHK_STAMP(11);
     // ---- everything behind the staging, for a compile-time E: rounds [0, E) first; E == U: all at once, no cut; E < 0: the anchored
     // extension (table modes), which returns false when the read has to take one of the other sequences after all.
     // (State and steps are declared INSIDE the lambda: shared between its instantiations from outside, hipcc 7.2 stops with
@@ -1613,8 +1674,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       const bool tile = ln >= nA;
       const uint32_t sA = tile ? spLast - (ln - nA) * k : 2u * ln;
       uint32_t pA = 0u, pB = 0u;
+      SHK_STAMP(2);
       bool hA = lx_hit_at(sA, true, pA);
       uint64_t HA = __ballot(hA);
+      SHK_STAMP(3);
       if (HA) {
         hA = hA && slot_valid(sA);   // (the slot has to exist and be a valid k-mer)
         HA = __ballot(hA);
@@ -1627,12 +1690,15 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t cov = wave_sum_u32((hA && !tile) ? (step < k ? step : k) : 0u) + k * (uint32_t)__builtin_popcountll(HA >> nA);
         if (cov >= thr_r) {
           write_the_gene(P.lx_gene);
+          SHK_STAMP(4);
           return 1;
         }
       }
+      SHK_STAMP(4);
       const uint32_t sB = ln < nA - 1u ? 2u * ln + 1u : ln + nA;
       bool hB = lx_hit_at(sB, true, pB);
       uint64_t HB = __ballot(hB);
+      SHK_STAMP(5);
       if (HB) {
         hB = hB && slot_valid(sB);
         HB = __ballot(hB);
@@ -1689,6 +1755,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       lane_any = mt[0] | mt[1];
       return 0;
     };
+    SHK_STAMP(12);
     if constexpr (JA >= U) {
       // nothing to decide early (two rounds): the cut's first stop at most
       if constexpr (E < U) {
@@ -1773,11 +1840,30 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     };   // per_pair
     per_pair(std::integral_constant<uint32_t, 0u>{});
+    SHK_STAMP(6);
     if constexpr (TRI) {
       per_pair(std::integral_constant<uint32_t, 1u>{});
+      SHK_STAMP(6);
       per_pair(std::integral_constant<uint32_t, 2u>{});
+      SHK_STAMP(6);
     }
     }   // !skip
+#if SHK_STAMPS
+    if constexpr (TRI) {
+      if (!have_nxt) {
+        SHK_STAMP(7);
+        st_acc[13] = st_last - st_t0;
+        const uint64_t st_r1 = __builtin_amdgcn_s_memrealtime();
+        st_acc[14] = st_r1 - st_r0;
+        if (lane == 0 && blockIdx.x * WAVES + wave < 4096u) {
+          shk_stamp_waves[2u * (blockIdx.x * WAVES + wave)] = st_r0;
+          shk_stamp_waves[2u * (blockIdx.x * WAVES + wave) + 1u] = st_r1;
+        }
+        if (lane == 0)
+          for (int i = 0; i < 16; ++i) atomicAdd(&shk_stamp_acc[i], (unsigned long long)st_acc[i]);
+      }
+    }
+#endif
     if (!have_nxt) break;
     if (TRI) { tri_retire(t_nxt); t_cur = t_nxt; }
     retire(w_nxt, q_nxt);
@@ -1788,9 +1874,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       pl_cur = pl_nxt;
     }
     it = nxt;
+    if (DYN) dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
     read = CLS ? read_nxt : it;
 #pragma unroll
     for (int g = 0; g < G; ++g) { w_cur[g] = w_nxt[g]; q_cur[g] = q_nxt[g]; }
+    SHK_STAMP(7);
   }
   if (!CLS) break;
   // the next class of the share, or the wave's next share

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void valu_mix_kernel(const uint32_t iters, con
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull, kmask0 = (1ull << k) - 1ull;
   const uint32_t tagmask = (1u << 18) - 1u, gmask2 = ((1u << 13) - 1u) << 1;
   uint32_t acc = 0;
+  // the clock the SIMDs hold while this mix runs (the chip lowers it under load): shader cycles (s_memtime) over the constant 100 MHz
+  // counter (s_memrealtime) around the loop, summed over the waves -- out[1024..1027] as two 64-bit sums nothing else reads
+  const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (uint32_t it = 0; it < iters; ++it) {
     // stage (classify_uni.hpp, "stage")
     const uint32_t sh = d0 & 3u;
@@ -101,6 +104,12 @@ __global__ __launch_bounds__(256) void valu_mix_kernel(const uint32_t iters, con
     d2 ^= (uint32_t)(h >> 32) + ti;
   }
   if (acc == 0x12345678u && d0 == d1) out[tid & 1023u] = acc + d2;   // (keeps the chain alive)
+  const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(out + 1024);
+    atomicAdd(&clk[0], (unsigned long long)(t1 - t0));
+    atomicAdd(&clk[1], (unsigned long long)(r1 - r0));
+  }
 }
 
 }  // namespace shk
@@ -108,6 +117,11 @@ __global__ __launch_bounds__(256) void valu_mix_kernel(const uint32_t iters, con
 using namespace shk;
 
 extern "C" int shk_measure_valu_mix(shk_ctx *cctx, int waves_per_simd, uint32_t iters, double *ms_out, uint64_t *wave_iterations)
+{
+  return shk_measure_valu_mix_clock(cctx, waves_per_simd, iters, ms_out, wave_iterations, nullptr);
+}
+
+extern "C" int shk_measure_valu_mix_clock(shk_ctx *cctx, int waves_per_simd, uint32_t iters, double *ms_out, uint64_t *wave_iterations, double *shader_ghz)
 {
   Ctx *ctx = cctx;
   if (!ctx || !ms_out || !wave_iterations || waves_per_simd < 1 || waves_per_simd > 8 || iters == 0) return SHK_ERR_ARG;
@@ -123,13 +137,14 @@ extern "C" int shk_measure_valu_mix(shk_ctx *cctx, int waves_per_simd, uint32_t 
     return r;
   };
 #define MS_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return done(set_hip_error(ctx, e__, #call)); } while (0)
-  MS_HIP(hipMalloc((void **)&out, 4096));
+  MS_HIP(hipMalloc((void **)&out, 4096 + 64));
   MS_HIP(hipEventCreate(&e0));
   MS_HIP(hipEventCreate(&e1));
   // one 256-thread workgroup puts a wave on each of a CU's four SIMDs: W workgroups per CU are W waves per SIMD, all resident at once
   const unsigned grid = (unsigned)prop.multiProcessorCount * (unsigned)waves_per_simd;
   hipLaunchKernelGGL(valu_mix_kernel, dim3(grid), dim3(256), 0, ctx->stream, 64u, ctx->prm.k, out);
   MS_HIP(hipGetLastError());
+  MS_HIP(hipMemsetAsync(out + 1024, 0, 64, ctx->stream));
   MS_HIP(hipEventRecord(e0, ctx->stream));
   hipLaunchKernelGGL(valu_mix_kernel, dim3(grid), dim3(256), 0, ctx->stream, iters, ctx->prm.k, out);
   MS_HIP(hipGetLastError());
@@ -137,6 +152,11 @@ extern "C" int shk_measure_valu_mix(shk_ctx *cctx, int waves_per_simd, uint32_t 
   MS_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
   MS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (shader_ghz) {
+    unsigned long long clk[2] = {0, 0};
+    MS_HIP(hipMemcpy(clk, out + 1024, sizeof(clk), hipMemcpyDeviceToHost));
+    *shader_ghz = clk[1] ? 0.1 * (double)clk[0] / (double)clk[1] : 0.0;   // (s_memrealtime: 100 MHz)
+  }
 #undef MS_HIP
   *ms_out = ms;
   *wave_iterations = (uint64_t)grid * 4ull * iters;
