@@ -135,11 +135,16 @@ template <> struct CutPlan<5> { static constexpr int E0 = 2, E1 = 3; };
 #define SHK_STAMPS 0
 #endif
 #if SHK_STAMPS
-__device__ unsigned long long shk_stamp_acc[16];
+// per wave (4096 = 256 workgroups of 16 waves): its sums, added up over the launches since the last reset -- a row of its own per wave:
+// 4 096 waves adding to sixteen shared words as they finish kept the memory side busy for 0.6 ms, which the waves still running paid
+__device__ unsigned long long shk_stamp_acc[4096 * 16];
 __device__ unsigned long long shk_stamp_waves[2 * 4096];   // per wave of the last launch: the 100 MHz counter at its loop's start and end
 #define SHK_STAMP(i) do { if constexpr (TRI) { const uint64_t t__ = __builtin_readcyclecounter(); st_acc[i] += t__ - st_last; st_last = t__; } } while (0)
 #else
 #define SHK_STAMP(i) do {} while (0)
+#endif
+#ifndef SHK_DYN_ALL
+#define SHK_DYN_ALL 1   // (0: turn-taking only where the exact table sits in LDS)
 #endif
 #ifndef SHK_NO_DYN
 #define SHK_NO_DYN 0   // (-DSHK_NO_DYN=1: every wave walks its own fixed sequence of reads, for A/B timing)
@@ -239,7 +244,13 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // every wave walking its own fixed sequence.  The SIMD issues oldest wave first: with fixed sequences of equal length the four
   // waves of a SIMD finished at 2.8 / 3.5 / 4.4 / 5.3 ms of a 5.3 ms launch (s_memrealtime at every wave's start and end, the stamped
   // build of tools/stamps.sh) -- the SIMD spent the last third of the launch with two waves, then one, to hide its latencies
-  constexpr bool DYN = LX && UNI && !CLS && !SHK_NO_DYN;
+  // (likewise behind an LDS or L2 summary -- 100 / 1 000 genes at 0 / 50 / 100 % on-target 5.0 / 10.7 / 14.2 -> 4.7 / 10.4 / 13.9 and 9.7 / 11.7 /
+  //  14.7 -> 9.4 / 11.5 / 14.5 ms per 10 M pairs; not on the position / minimiser tables of large indices, whose waves wait on memory at even
+  //  rates: 17.6-18.1 / 17.9-18.4 -> 18.0-18.2 / 18.7-18.8 ms at 0 / 50 %, the turn's registers spilled there)
+  constexpr bool DYN = (LX || (SHK_DYN_ALL && (pm_lds(MODE) || MODE == PM_TAB_SUM))) && UNI && !CLS && !SHK_NO_DYN;
+  // (Workgroups taking CHUNKS of the batch from one counter of the launch, on top of this, was built and measured: 3.15 -> 3.21 ms.  The
+  //  spread of the workgroups' ends that suggested it -- 4.2 ... 4.85 ms in the stamped build -- was that build's own doing: 4 096 waves
+  //  adding their sums to sixteen words of one cache line as they finish.)
   __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS * AREAS + (DYN ? 2 : 0)];
   uint32_t *const dyn_ctr = reinterpret_cast<uint32_t *>(lds + UG::SUM_WORDS64 + WAVES * WORDS * AREAS);
   const int lane = threadIdx.x & 63;
@@ -294,6 +305,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
     if (DYN && threadIdx.x == 0) *dyn_ctr = 2u * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave)
+    __syncthreads();
+  } else if (DYN) {
+    if (threadIdx.x == 0) *dyn_ctr = 2u * WAVES;
     __syncthreads();
   }
   const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
@@ -492,7 +506,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // the next one is a running pointer (one 64-bit add per fetch instead of two quarter-rate 64-bit multiply-adds: 1 000 genes at
   // 0 / 50 / 100 % on-target 9.8 / 12.1 / 15.4 -> 9.4 / 11.7 / 15.2 ms per 10 M pairs); the exact-table kernel keeps the product
   // (with the pointer it measured 4.25 -> 4.40 ms)
-  constexpr bool RUNPTR = !LX;
+  constexpr bool RUNPTR = !LX && !DYN;   // (a wave that takes turns has no fixed step)
   const uint8_t *snext[G], *qnext[G];
   uint32_t sstep[G];
   {
@@ -600,6 +614,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   auto tri_retire = [&](Raw16 &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.d0), "+v"(r.d1), "+v"(r.d2), "+v"(r.d3), "+v"(r.d4)); };
   Raw16 t_cur{0u, 0u, 0u, 0u, 0u, 0u};
 
+  // DYN: the position of the workgroup's turn t (n32: behind the batch's end; the turns behind such a turn are too)
+  auto dyn_pos = [&](const uint32_t t) -> uint32_t {
+    const uint64_t v = (uint64_t)(t / (uint32_t)WAVES) * stride + (blockIdx.x * WAVES + t % (uint32_t)WAVES);
+    return v < n32 ? (uint32_t)v : n32;
+  };
   uint32_t it = CLS ? ent_first : blockIdx.x * WAVES + wave;   // position in the batch (CLS: in the list of entries; TRI: the triple)
   if (!CLS && it >= n32) return;
   uint32_t read = it;                                          // the read's index in the batch: where its result goes
@@ -670,12 +689,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   uint32_t dyn_q = (uint32_t)WAVES + wave;
   for (;;) {
     uint32_t nxt;
-    if (DYN) {
-      const uint64_t v = (uint64_t)(dyn_q / (uint32_t)WAVES) * stride + (blockIdx.x * WAVES + dyn_q % (uint32_t)WAVES);
-      nxt = v < n32 ? (uint32_t)v : n32;
-    } else {
-      nxt = n32 - it > stride ? it + stride : n32;   // saturates at n32
-    }
+    if (DYN) nxt = dyn_pos(dyn_q);
+    else nxt = n32 - it > stride ? it + stride : n32;   // saturates at n32
     const bool have_nxt = nxt < n32;
     Raw8 w_nxt[G], q_nxt[G];
 #pragma unroll
@@ -1859,8 +1874,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           shk_stamp_waves[2u * (blockIdx.x * WAVES + wave)] = st_r0;
           shk_stamp_waves[2u * (blockIdx.x * WAVES + wave) + 1u] = st_r1;
         }
-        if (lane == 0)
-          for (int i = 0; i < 16; ++i) atomicAdd(&shk_stamp_acc[i], (unsigned long long)st_acc[i]);
+        if (lane == 0 && blockIdx.x * WAVES + wave < 4096u)
+          for (int i = 0; i < 16; ++i) shk_stamp_acc[16u * (blockIdx.x * WAVES + wave) + i] += (unsigned long long)st_acc[i];
       }
     }
 #endif

@@ -9,13 +9,17 @@ void launch_uni_u5(const ClassifyParams &p, int mode, bool hasq, bool big, bool 
 }  // namespace shk
 
 #if SHK_STAMPS
-// (diagnostic build only) the per-phase clock sums of the three-pairs kernel since the last reset: out[16]
+// (diagnostic build only) the per-phase clock sums of the three-pairs kernel since the last reset, summed over the waves: out[16]
 extern "C" int shk_debug_read_stamps(unsigned long long *out, int reset)
 {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(shk::shk_stamp_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  static unsigned long long rows[4096 * 16];
+  if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(shk::shk_stamp_acc), sizeof(rows)) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  for (int w = 0; w < 4096; ++w)
+    for (int i = 0; i < 16; ++i) out[i] += rows[16 * w + i];
   if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(shk::shk_stamp_acc), z, sizeof(z)) != hipSuccess) return -1;
+    for (auto &x : rows) x = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(shk::shk_stamp_acc), rows, sizeof(rows)) != hipSuccess) return -1;
   }
   return 0;
 }

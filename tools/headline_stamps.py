@@ -66,6 +66,7 @@ for ot in [float(x) for x in a.ot.split(",")]:
     wt = wt[wt[:, 1] > 0]
     t_first = int(wt[:, 0].min())
     starts, ends = (wt[:, 0] - t_first) * 0.01, (wt[:, 1] - t_first) * 0.01      # microseconds behind the first wave's start
+    wg_end = [round(float(x), 1) for x in ends.reshape(-1, 16).max(axis=1)] if len(ends) % 16 == 0 else []
     pct = lambda v: [round(float(np.percentile(v, q)), 1) for q in (0, 10, 50, 90, 100)]
     kernel_ms = tm["total_ms"] / tm["n_launches"]
     ticks = [x / a.reps for x in st[:8]]
@@ -82,6 +83,7 @@ for ot in [float(x) for x in a.ot.split(",")]:
            "share": {PHASES[i]: round(ticks[i] / total, 4) for i in range(8)},
            "wave_loop_start_us_behind_the_first_p0_10_50_90_100": pct(starts), "wave_loop_end_us_p0_10_50_90_100": pct(ends),
            "wave_loop_us_p0_10_50_90_100": pct(ends - starts),
+           "workgroup_end_us_by_blockIdx": wg_end,
            "set_up_split_ticks_per_pair": {k: round(v / pairs, 2) for k, v in extra.items()},
            "ticks_per_pair_total": round(total / pairs, 2)}
     out["on_target"]["%.2f" % ot] = row
