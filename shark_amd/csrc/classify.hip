@@ -855,12 +855,19 @@ __global__ __launch_bounds__(1024) void class_plan_kernel(const ClassifyParams P
   __threadfence();
   __syncthreads();
   // (by search, every thread a few shares: a trimmed sample's untouched pairs are one class that two thirds of the shares start in)
-  for (uint32_t sh = threadIdx.x; sh < CLS_SHARES && (uint64_t)sh * share_len < P.n; sh += blockDim.x) {
+  // (a thread takes a run of consecutive shares: one search, then steps forward along the sorted list)
+  const uint32_t per_thread = (CLS_SHARES + blockDim.x - 1u) / blockDim.x;
+  uint32_t lo = 0;
+  for (uint32_t i = 0, sh = threadIdx.x * per_thread; i < per_thread && sh < CLS_SHARES && (uint64_t)sh * share_len < P.n; ++i, ++sh) {
     const uint32_t e = sh * share_len;
-    uint32_t lo = 0, hi = tot_c;                    // the last class that starts at or before entry e
-    while (hi - lo > 1u) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (list[mid].z <= e) lo = mid; else hi = mid;
+    if (i == 0) {
+      uint32_t hi = tot_c;                          // the last class that starts at or before entry e
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (list[mid].z <= e) lo = mid; else hi = mid;
+      }
+    } else {
+      while (lo + 1u < tot_c && list[lo + 1u].z <= e) ++lo;
     }
     share_first[sh] = lo;
   }

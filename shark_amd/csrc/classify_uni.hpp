@@ -251,7 +251,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // (Workgroups taking CHUNKS of the batch from one counter of the launch, on top of this, was built and measured: 3.15 -> 3.21 ms.  The
   //  spread of the workgroups' ends that suggested it -- 4.2 ... 4.85 ms in the stamped build -- was that build's own doing: 4 096 waves
   //  adding their sums to sixteen words of one cache line as they finish.)
-  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS * AREAS + (DYN ? 2 : 0)];
+  // CLS: the same for the SHARES of a batch taken class by class (sixteen per wave)
+  constexpr bool DYNC = CLS && !SHK_NO_DYN;
+  __shared__ uint64_t lds[UG::SUM_WORDS64 + WAVES * WORDS * AREAS + ((DYN || DYNC) ? 2 : 0)];
   uint32_t *const dyn_ctr = reinterpret_cast<uint32_t *>(lds + UG::SUM_WORDS64 + WAVES * WORDS * AREAS);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -305,6 +307,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
     if (DYN && threadIdx.x == 0) *dyn_ctr = 2u * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave)
+    if (DYNC && threadIdx.x == 0) *dyn_ctr = (uint32_t)WAVES;   // (its first share)
     __syncthreads();
   } else if (DYN) {
     if (threadIdx.x == 0) *dyn_ctr = 2u * WAVES;
@@ -1900,7 +1903,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   if (ent_end < share_end) {
     ++cls_j;
   } else {
-    share += n_waves;
+    if (DYNC) {
+      uint32_t t = 0u;
+      if (lane == 0) t = atomicAdd(dyn_ctr, 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      const uint64_t sh = (uint64_t)(t / (uint32_t)WAVES) * n_waves + (blockIdx.x * WAVES + t % (uint32_t)WAVES);
+      if (sh >= CLS_SHARES) break;
+      share = (uint32_t)sh;
+    } else {
+      share += n_waves;
+    }
     if (share >= CLS_SHARES || (uint64_t)share * share_len >= P.n) break;
     ent_end = share * share_len;
     share_end = (uint64_t)ent_end + share_len < P.n ? ent_end + share_len : (uint32_t)P.n;

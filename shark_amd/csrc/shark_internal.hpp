@@ -224,7 +224,7 @@ enum {
 constexpr uint32_t UNI_FLAG_WORDS = 16;
 constexpr uint32_t COUNTER_BLOCK_WORDS = 16;   // CTR_WORDS rounded up: Slot::d_uni_flag = d_counters + this
 static_assert(CTR_WORDS <= COUNTER_BLOCK_WORDS, "the counters and the uniformity words share one allocation");
-constexpr uint32_t CLS_SHARES = 4096;     // equal shares of a sorted batch: one per wave of the exact-table kernels' grid
+constexpr uint32_t CLS_SHARES = 65536;    // equal shares of a sorted batch: sixteen per wave of the exact-table kernels' grid, taken in turns (classify_uni.hpp, DYN)
 constexpr uint32_t CLS_MIN_FILL = 16;     // by classes only if a non-empty class holds that many pairs on average
 
 // ---- one batch in flight ---------------------------------------------------------------------
