@@ -20,7 +20,7 @@ for name, head in SECTIONS:
         if not ln.startswith("{"):
             continue
         r = json.loads(ln)
-        if "kernel_ms" in r and "genes" in r:
+        if "kernel_ms" in r and "genes" in r and "bf_log2" in r:
             on = r.get("anchored", r.get("with"))
             print("genes %-6d bf 2^%d k %2d q %2d on-target %.2f read_len %3d pairs %d mode %-22s kernel_ms %7.3f n_assoc %d%s" % (
                 r["genes"], r["bf_log2"], r["k"], r["q"], r["on_target"], r["read_len"], r["pairs"], r["mode"], r["kernel_ms"], r["n_assoc"],
