@@ -1236,6 +1236,17 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
                                  (double)ctx->last.last_n_assoc > 0.8 * (double)ctx->last.last_n_reads;
     if (!mostly_assigned) mode = PM_KTAB;
   }
+  // The anchored extension settles a pair from a gene from the reference itself -- behind a SAMPLE of eight probes, a dependent memory
+  // round trip that a pair from elsewhere pays in front of its first rounds for nothing.  While the batch just finished left seven
+  // eighths of its reads unassigned or more, the kernel is launched without it (ref_total = 0: `anchored` returns at once, every
+  // read takes the usual order; results are the same either way): 60 000 genes at 0 / 2 / 10 % on-target 17.7 / 17.7 / 18.3 -> 14.5 /
+  // 15.0 / 16.6 ms per 10 M pairs, 10 000 genes 15.2 / 15.4 / 15.2 -> 13.6 / 14.0 / 14.8; the two meet at a quarter of the pairs
+  // on-target.  On the position table the gain is smaller and the two meet earlier (1 000 genes behind the L2 summary 9.4 / 9.5 / 9.7
+  // -> 8.1 / 8.6 / 10.2; the configs[4] shape, k = 31, 24.2 -> 22.4 at 0 %, 24.3 -> 24.7 at 10 %): one twentieth there.
+  // (SHK_ANCHOR_ALWAYS=1, the tests' switch, keeps it on whatever the stream looks like)
+  if (!pm_lds(mode) && p.ref_total && ctx->last.last_n_reads != 0 && !ctx->env_anchor_always &&
+      (double)ctx->last.last_n_assoc < (mode == PM_KTAB ? 0.125 : 0.05) * (double)ctx->last.last_n_reads)
+    p.ref_total = 0;
   const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10) && !many_assigned;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;

@@ -613,6 +613,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     ctx->env_big_lds_always = getenv("SHK_BIG_LDS_ALWAYS") != nullptr;
     { const char *nt = getenv("SHK_KTAB_NT"); ctx->env_ktab_nt = nt && nt[0] == '1'; ctx->env_ktab_plain = nt && nt[0] == '0'; }
     ctx->env_ktab_always = getenv("SHK_KTAB") != nullptr;
+    ctx->env_anchor_always = getenv("SHK_ANCHOR_ALWAYS") != nullptr;
     ctx->env_no_tri = getenv("SHK_NO_TRI") != nullptr;
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }

@@ -327,6 +327,7 @@ struct Ctx {
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
   bool env_no_tri = false;          // SHK_NO_TRI=1: no three-pairs-per-pass instantiation (A/B timing, tests)
+  bool env_anchor_always = false;   // SHK_ANCHOR_ALWAYS=1: the anchored extension for every batch of an index that has the reference arrays (tests, A/B timing)
   bool env_ktab_always = false;     // SHK_KTAB=1: the minimiser table for every batch of an index that has it (tests)
   bool env_ktab_nt = false, env_ktab_plain = false;   // SHK_KTAB_NT=1 / 0: the minimiser table probed with / without non-temporal loads whatever its size (A/B timing, tests)
   bool env_force_generic = false, env_big_lds_always = false, env_cls_always = false;   // SHK_CLS_MIN_FILL given: no adapting to the stream

@@ -1373,6 +1373,32 @@ def test_panel_sized_index_follows_the_assigned_fraction(oracle, monkeypatch):
         h.close()
 
 
+def test_anchored_extension_follows_the_assigned_fraction(oracle, monkeypatch):
+    """table modes: a batch behind one that left nearly all of its reads unassigned is launched without the anchored extension (its
+    sample is a memory round trip that pairs from elsewhere pay for nothing), the batch behind one with many reads assigned with it;
+    identical results either way, in every order of batches, and with the switching turned off (SHK_ANCHOR_ALWAYS=1)"""
+    rng = np.random.default_rng(2626)
+    genes = synth.make_genes(rng, 24, 900, 3500, share_every=3)
+    on = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=1.0)
+    off = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.0)
+    few = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.02)
+    monkeypatch.setenv("SHK_NO_LDS_SUMMARY", "1")      # (the position table behind the L2 summary, as in test_anchored_extension_reads)
+    for always in (False, True):
+        if always:
+            monkeypatch.setenv("SHK_ANCHOR_ALWAYS", "1")
+        o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 26)
+        assert h.probe_mode() in ("table", "summary+table"), h.probe_mode()
+        seen = []
+        for b in (on, off, few, on, on, few, off, on):
+            goff, _ = _compare_classify(o, h, b)
+            seen.append((int(goff[-1]) / 2000, "+anchored-extension" in h.last_kernel()))
+        # (the first batch has no predecessor: with the extension)
+        assert seen[0][1]
+        for (frac_before, _), (_, with_ext) in zip(seen, seen[1:]):
+            assert with_ext == (always or frac_before >= 0.05), seen
+        h.close()
+
+
 @pytest.mark.parametrize("k,bf_bits,n_bases", [
     (17, 1 << 33, 25_600),      # lds-summary+table: walks per round; 25 584 keys in 32 768 slots
     (17, 5 << 32, 25_600),      # the same with hash % size
@@ -1644,6 +1670,7 @@ def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
     pal = np.frombuffer(b"ACGT" * 16, dtype=np.uint8)                 # its own reverse complement at every even k
     genes[9][200:200 + len(pal)] = pal
     genes[11][50:50 + len(pal)] = pal
+    monkeypatch.setenv("SHK_ANCHOR_ALWAYS", "1")     # (else a batch behind one with few reads assigned runs without the extension)
     for anchor in (True, False):
         if anchor:
             monkeypatch.delenv("SHK_NO_ANCHOR", raising=False)
