@@ -149,6 +149,9 @@ __device__ unsigned long long shk_stamp_waves[2 * 4096];   // per wave of the la
 #ifndef SHK_NO_DYN
 #define SHK_NO_DYN 0   // (-DSHK_NO_DYN=1: every wave walks its own fixed sequence of reads, for A/B timing)
 #endif
+#ifndef SHK_NO_TILE_FIRST
+#define SHK_NO_TILE_FIRST 0   // (-DSHK_NO_TILE_FIRST=1: a build without the tiles' round in front of three staged pairs)
+#endif
 #ifndef SHK_NO_SPARSE
 #define SHK_NO_SPARSE 0
 #endif
@@ -212,7 +215,7 @@ __host__ __device__ inline bool tri_applies(const uint32_t L1, const uint32_t L2
   const uint32_t ns = nk2 ? (c1 << 4) + nk2 : nk1;
   return L1 != 0u && c1 + c2 <= 21u && ns <= S;
 }
-template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false, bool TRI = false>
+template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false, bool TRI = false, bool TFK = false>
 __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
   static_assert(!CLS || UNI, "CLS is a form of the uniform instantiation");
@@ -690,6 +693,32 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // DYN: turn q of the workgroup is position blockIdx.x * WAVES + q % WAVES + (q / WAVES) * stride of the batch -- the positions the
   // workgroup's waves walk together in the fixed order, whoever takes them
   uint32_t dyn_q = (uint32_t)WAVES + wave;
+  // TF (three pairs per pass, one-gene index; P.tile_first: the host's reading of the stream): THE TILES' ROUND.  A pair is the gene's
+  // as soon as k-mers of it that are in the filter are seen to cover c * len bases (sparse_first: "a lower bound that passes settles
+  // a read") -- and DISJOINT k-mers cover k bases each, so up to 8 per mate, 16 per pair, one lane each, say so for THREE pairs in ONE
+  // hash round: 2 x 150 bp, k = 17, c = 0.6 needs 11 of its 16 tiles (187 >= 180 bases), which a pair from the gene with 1 % errors has
+  // 97 times in 100.  Such a pair ends here, behind a third of a round instead of a whole one and without any of its own set-up; a
+  // pair with fewer matching tiles (more errors; from elsewhere) goes through the usual rounds as if nothing had happened -- having
+  // paid a third of a round for it, which is why the host asks for this only behind a batch with many reads assigned (two fifths: where
+  // the two kernels were measured to meet).  Pairs with invalid characters take part: a tile counts when its k characters are valid.
+  // (An instantiation of its own, TFK: as a run-time switch of the three-pairs kernel its per-lane constants and masks cost that
+  //  kernel a fifth of its speed with the round switched OFF -- 3.18 -> 3.82 ms per 10 M pairs from elsewhere; 110 -> 173 spilled scalars.)
+  constexpr bool TF = TFK && TRI && SPARSE && !LXM && !SHK_NO_TILE_FIRST;
+  bool tf_on = false, tf_want = false;
+  uint32_t tf_slot = 0u, tf_area = 0u;
+  if (TF && spT != 0u && cutE == 2u && thr_full != 0u) {
+    const uint32_t m1 = nk1 ? ((nk1 - 1u) / k + 1u < 8u ? (nk1 - 1u) / k + 1u : 8u) : 0u;   // disjoint k-mers of a mate: slots 0, k, 2k, ...
+    const uint32_t m2 = nk2 ? ((nk2 - 1u) / k + 1u < 8u ? (nk2 - 1u) / k + 1u : 8u) : 0u;
+    if ((m1 + m2) * k >= thr_full) {
+      tf_on = true;
+      const uint32_t j = (uint32_t)lane & 15u;
+      if (lane < 48) {
+        tf_area = (uint32_t)lane >> 4;
+        tf_want = j < 8u ? j < m1 : j - 8u < m2;
+        tf_slot = tf_want ? (j < 8u ? j * k : P2 + (j - 8u) * k) : 0u;
+      }
+    }
+  }
   for (;;) {
     uint32_t nxt;
     if (DYN) nxt = dyn_pos(dyn_q);
@@ -801,8 +830,75 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // (a generic lambda called once per pair, not a loop: with the pair's area a compile-time offset from the wave's, the LDS
     //  addresses of a pair's windows stay what they are for one area -- the lane's offset from a loop-invariant base, the area as the
     //  instruction's immediate -- instead of an addition per address and pair)
+    // the slot ss of a staged pair (its two code streams at fwp / rvp) as a probe of the exact LDS table (LX): is its k-mer in the
+    // filter?  payload = the gene of the matched entry's single-gene list, or the escape value.  (Not validated: the caller looks
+    // at the slot when something matched.)
+    auto lx_probe = [&](const uint32_t *fwp, const uint32_t *rvp, const uint32_t ss, uint32_t &payload) -> bool {
+      const uint32_t q = rcap - k - ss;
+      const uint32_t *f = fwp + (ss >> 4);
+      const uint32_t *r = rvp + (q >> 4);
+      const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
+      const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
+      const uint32_t af = (ss & 15u) << 1, ar = (q & 15u) << 1;
+      const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, af) << 32) | __builtin_amdgcn_alignbit(d1, d0, af);
+      const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, ar) << 32) | __builtin_amdgcn_alignbit(e1, e0, ar);
+      const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
+      const uint64_t h = xxh64_u64(fwd < rc ? fwd : rc);
+      const uint32_t *T = lsum;
+      const char *D = reinterpret_cast<const char *>(lsum + LTAB_T_WORDS);
+      const uint32_t tagmask15 = (uint32_t)(P.bf_mask >> LTAB_SLOT_LG);
+      const uint32_t gmask2 = (tagmask15 & ((1u << LTAB_GROUP_LG) - 1u)) << 1;
+      const uint32_t dd = *reinterpret_cast<const uint16_t *>(D + (((uint32_t)h >> (LTAB_SLOT_LG - 1)) & gmask2));
+      const uint32_t tg = __builtin_amdgcn_alignbit((uint32_t)(h >> 32), (uint32_t)h, LTAB_SLOT_LG) & tagmask15;
+      const uint32_t base = (uint32_t)h + (tg >> LTAB_GROUP_LG) * P.lsum_shift;
+      const uint32_t ee = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + (((base + dd) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
+      payload = ee & LTAB_ESC;
+      return (ee >> 13) == ((tg << 1) | 1u);
+    };
+    // (TRI) does pair p of the triple hold an invalid character (N)?  -- its threshold is then lower than the plan's, and its slots need
+    // their validity windows: per_pair's business
+    bool inv3[3] = {false, false, false};
+    if (TRI) {
+#pragma unroll
+      for (uint32_t p3 = 0; p3 < 3u; ++p3) inv3[p3] = __ballot((inv_real != 0u) & (tri_pr == p3)) != 0ull;
+    }
+    // TF: the tiles' round (see above) -- bit p of tf_done: pair p of the triple is settled
+    uint32_t tf_done = 0u;
+    if constexpr (TF) {
+      if (tf_on) {
+        uint32_t pay;
+        const uint32_t *fwp = reinterpret_cast<const uint32_t *>(wbase + tf_area * WORDS);
+        bool hit = tf_want & lx_probe(fwp, fwp + code_dwords_for(S), tf_slot, pay);
+        if (inv3[0] | inv3[1] | inv3[2]) {
+          // a pair with invalid characters: a tile counts when its k characters are valid (slot_valid's window); the pair's threshold
+          // is at most the plan's (fewer valid bases), so the plan's is the safe one to pass
+          const uint64_t *vb = reinterpret_cast<const uint64_t *>(fwp) + code_dwords_for(S);   // (the area's validity words behind its two code streams)
+          const uint32_t V = tf_slot >> 6, vs = tf_slot & 63u;
+          const uint64_t v0 = vb[V], v1 = vb[V + 1];
+          const uint64_t win = (v0 >> vs) | ((v1 << 1) << (63u - vs)), km = (1ull << k) - 1ull;
+          hit = hit & ((win & km) == km);
+        }
+        const uint64_t Hb = __ballot(hit);
+#pragma unroll
+        for (uint32_t p3 = 0; p3 < 3u; ++p3) {
+          const uint32_t cnt = (uint32_t)__builtin_popcount((uint32_t)(Hb >> (16u * p3)) & 0xFFFFu);
+          const uint32_t rd = 3u * it + p3;
+          if (cnt * k >= thr_full && rd < n_reads) {
+            if (lane == 0 && !SHK_ABL(P, 64u)) {
+              sp_count[rd] = 1u;
+              uint2 pk;
+              pk.x = P.lx_gene & 0xFFFFu;
+              pk.y = 0u;
+              *reinterpret_cast<uint2 *>(sp_inl + (uint64_t)rd * SHK_INLINE_IDS) = pk;
+            }
+            tf_done |= 1u << p3;
+          }
+        }
+      }
+    }
     auto per_pair = [&](auto tp_const) -> void {
     constexpr uint32_t tp = decltype(tp_const)::value;
+    if (TF && ((tf_done >> tp) & 1u)) return;
     if (TRI) {
       read = 3u * it + tp;
       if (read >= n_reads) return;
@@ -835,7 +931,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     uint32_t thr_r = thr_full;   // the smallest coverage that passes c * len for this read
     // a read without any invalid character (N, masked quality) -- most reads -- needs no validity window per slot: every existing
     // slot is a valid k-mer (table modes test validity before a probe; uniform branch around eight instructions per slot and round)
-    const bool any_inv = __ballot((inv_real != 0u) & (!TRI || tri_pr == tp)) != 0ull;
+    const bool any_inv = TRI ? inv3[tp < 3u ? tp : 0u] : __ballot(inv_real != 0u) != 0ull;
     if (cutE < (uint32_t)U || JA_ROUNDS < U) {
       // the plan assumed len = L1 + L2; a read with invalid characters (N, masked qualities) has a lower threshold
       if (any_inv) {
@@ -1643,27 +1739,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     };
     // the slot ss of the read as a probe of the exact LDS table (LX): is its k-mer in the filter?  (`want` false: no probe)
     auto lx_hit_at = [&](const uint32_t ss_in, const bool want, uint32_t &payload) -> bool {
-      const uint32_t ss = want ? ss_in : 0u;
-      const uint32_t q = rcap - k - ss;
-      const uint32_t *f = fw + (ss >> 4);
-      const uint32_t *r = rv + (q >> 4);
-      const uint32_t d0 = f[0], d1 = f[1], d2 = f[2];
-      const uint32_t e0 = r[0], e1 = r[1], e2 = r[2];
-      const uint32_t af = (ss & 15u) << 1, ar = (q & 15u) << 1;
-      const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, af) << 32) | __builtin_amdgcn_alignbit(d1, d0, af);
-      const uint64_t y = ((uint64_t)__builtin_amdgcn_alignbit(e2, e1, ar) << 32) | __builtin_amdgcn_alignbit(e1, e0, ar);
-      const uint64_t fwd = y & kmer_mask, rc = ~x & kmer_mask;
-      const uint64_t h = xxh64_u64(fwd < rc ? fwd : rc);
-      const uint32_t *T = lsum;
-      const char *D = reinterpret_cast<const char *>(lsum + LTAB_T_WORDS);
-      const uint32_t tagmask15 = (uint32_t)(P.bf_mask >> LTAB_SLOT_LG);
-      const uint32_t gmask2 = (tagmask15 & ((1u << LTAB_GROUP_LG) - 1u)) << 1;
-      const uint32_t dd = *reinterpret_cast<const uint16_t *>(D + (((uint32_t)h >> (LTAB_SLOT_LG - 1)) & gmask2));
-      const uint32_t tg = __builtin_amdgcn_alignbit((uint32_t)(h >> 32), (uint32_t)h, LTAB_SLOT_LG) & tagmask15;
-      const uint32_t base = (uint32_t)h + (tg >> LTAB_GROUP_LG) * P.lsum_shift;
-      const uint32_t ee = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + (((base + dd) << 2) & ((LTAB_T_WORDS - 1u) << 2)));
-      payload = ee & LTAB_ESC;                          // the gene of the matched entry's single-gene list, or the escape value
-      return want & ((ee >> 13) == ((tg << 1) | 1u));   // (not validated: the caller looks at the slot when something matched)
+      return want & lx_probe(fw, rv, want ? ss_in : 0u, payload);
     };
     // the first two rounds of a one-gene index in the sparse order (see spT above).  true: the read is settled.  false: mt / slo of
     // the rounds 0 and 1 are what probe_rounds would have left (matches validated), the read goes on behind the cut's first stop.
@@ -1943,6 +2019,7 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
       const bool applies = host_knows && tri_applies(p.uni_L1, p.uni_L2, p.k, 64u * U);
       if (!host_knows || applies) {
         if (p.lx_multi) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+        else if (p.tile_first) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, false, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
         else hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
         if (applies) return;
       }

@@ -615,6 +615,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     ctx->env_ktab_always = getenv("SHK_KTAB") != nullptr;
     ctx->env_anchor_always = getenv("SHK_ANCHOR_ALWAYS") != nullptr;
     ctx->env_no_tri = getenv("SHK_NO_TRI") != nullptr;
+    ctx->env_tile_first = getenv("SHK_TILE_FIRST") ? (getenv("SHK_TILE_FIRST")[0] == '0' ? -1 : 1) : 0;
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };

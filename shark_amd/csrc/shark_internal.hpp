@@ -140,6 +140,7 @@ struct ClassifyParams {
   uint32_t lsum_shift;
   uint32_t lx_gene;          // exact table in LDS (LSL = 21): the gene of a one-gene index (DeviceIndex::ltab_gene), else 0xFFFFFFFF
   uint32_t tri;              // 1 = the three-pairs-per-pass instantiation (classify_uni.hpp, TRI) is launched beside the ordinary uniform one: the one whose lengths qualify works
+  uint32_t tile_first;       // (with tri, one-gene index) 1 = a round of disjoint k-mers for the three staged pairs together in front of the pairs' own rounds (classify_uni.hpp, TF)
   uint32_t lx_multi;         // exact table in LDS of an index of SEVERAL genes: the sparse first rounds with the early decision's argument (classify_uni.hpp)
   uint64_t bf_bits;
   uint64_t bf_mask;
@@ -326,6 +327,7 @@ struct Ctx {
   // test / A-B switches of the environment, read ONCE when the context is created (never per launch):
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
+  int env_tile_first = 0;           // SHK_TILE_FIRST=1: the tiles' round for every batch it can serve (tests); =0: never; unset: by the last batch's assigned fraction
   bool env_no_tri = false;          // SHK_NO_TRI=1: no three-pairs-per-pass instantiation (A/B timing, tests)
   bool env_anchor_always = false;   // SHK_ANCHOR_ALWAYS=1: the anchored extension for every batch of an index that has the reference arrays (tests, A/B timing)
   bool env_ktab_always = false;     // SHK_KTAB=1: the minimiser table for every batch of an index that has it (tests)

@@ -1373,6 +1373,34 @@ def test_panel_sized_index_follows_the_assigned_fraction(oracle, monkeypatch):
         h.close()
 
 
+def test_tiles_first_follows_the_assigned_fraction(oracle, monkeypatch):
+    """one-gene index in LDS, uniform batches: behind a batch with two fifths of its reads assigned or more the three-pairs kernel is
+    launched with the tiles' round in front (a pair from the gene ends behind a third of a hash round), behind a batch of reads from
+    elsewhere without it (they would pay that third for nothing); identical results either way, in every order of batches; pairs
+    with more errors than the tiles forgive, with N, and chimeric pairs on either side of the threshold go on through the usual rounds"""
+    monkeypatch.delenv("SHK_TILE_FIRST", raising=False)
+    monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
+    rng = np.random.default_rng(3131)
+    genes = synth.make_genes(rng, 1, 8_000, 8_000)
+    mk = lambda ot, n_rate=0.0: synth.make_reads(rng, genes, 3001, read_len=150, paired=True, on_target=ot, n_rate=n_rate)
+    on, off, few, mix = mk(1.0), mk(0.0), mk(0.05), mk(0.5, 0.003)
+    noisy = _sequenced_pairs(rng, genes, 3001, 150, 150, False, False, 0.03, 0.002, 0.003)
+    chim = _chimeric_batch(rng, genes, 3001, 150, 150, False, with_n=True, qual=False, k_hint=17)
+    o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 30)
+    assert h.probe_mode() == "lds-table"
+    seen = []
+    for b in (on, mix, off, few, on, noisy, chim, noisy, off, mix, on):
+        goff, _ = _compare_classify(o, h, b)
+        n = len(b["off1"]) - 1
+        seen.append((int(goff[-1]) / n, "+tiles-first" in h.last_kernel(), "+three-pairs" in h.last_kernel()))
+    assert all(t for _, _, t in seen), seen
+    assert not seen[0][1]                                       # (no predecessor: without)
+    for (frac_before, _, _), (_, tiles, _) in zip(seen, seen[1:]):
+        assert tiles == (frac_before >= 0.4), seen
+    assert any(t for _, t, _ in seen) and not all(t for _, t, _ in seen[1:])
+    h.close()
+
+
 def test_anchored_extension_follows_the_assigned_fraction(oracle, monkeypatch):
     """table modes: a batch behind one that left nearly all of its reads unassigned is launched without the anchored extension (its
     sample is a memory round trip that pairs from elsewhere pay for nothing), the batch behind one with many reads assigned with it;
@@ -1709,8 +1737,11 @@ def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
     if k <= 6:
         gene = gene[:900]          # (4^5 k-mers: nearly every k-mer of any read is in the filter)
     genes = [gene]
-    n_assigned = 0
-    for sparse in (True, False):
+    n_assigned = n_tiles = 0
+    for sparse in (True, "tiles", False):
+        # ("tiles": the sparse order with the tiles' round of three staged pairs in front of it, for every batch it can serve -- uniform
+        #  ones without qualities at U = 3 ... 5; True: never; the default follows the stream, test_tiles_first_follows_the_assigned_fraction)
+        monkeypatch.setenv("SHK_TILE_FIRST", "1" if sparse == "tiles" else "0")
         if sparse:
             monkeypatch.delenv("SHK_NO_SPARSE", raising=False)
         else:
@@ -1725,12 +1756,17 @@ def test_sparse_first_round_one_gene_index(oracle, monkeypatch, L1, L2, k):
                     n_assigned += int(goff[-1])
                     # the A side ran the sparse order, the B side the usual one (the switch is read when the index is built)
                     if ", 21, " in h.last_kernel():
-                        assert ("+sparse-first-round" in h.last_kernel()) == sparse, h.last_kernel()
+                        assert ("+sparse-first-round" in h.last_kernel()) == bool(sparse), h.last_kernel()
+                        assert ("+tiles-first" in h.last_kernel()) <= (sparse == "tiles"), h.last_kernel()
+                        n_tiles += "+tiles-first" in h.last_kernel()
                 batch = _chimeric_batch(rng, genes, 700, L1, L2, ragged, with_n=True, qual=q > 0, k_hint=k)
                 goff, _ = _compare_classify(o, h, batch)
                 n_assigned += int(goff[-1])
             h.close()
     assert n_assigned > 0
+    # (the tiles' round exists where three pairs share a staging pass: 2 x 100 ... 2 x 160 bp here)
+    if (L1, L2, k) in ((150, 150, 17), (150, 150, 31), (140, 140, 17), (125, 125, 12), (151, 101, 17), (101, 151, 17)):
+        assert n_tiles > 0, (n_tiles, L1, L2, k)
 
 
 @pytest.mark.parametrize("n_genes,share,L1,L2,k", [(2, 0, 150, 150, 17), (10, 0, 150, 150, 17), (10, 3, 150, 150, 17), (6, 2, 100, 100, 17), (4, 2, 150, 150, 31),
@@ -1794,11 +1830,12 @@ def test_three_pairs_per_staging_pass(oracle, monkeypatch, L1, L2, k, n_genes):
     fits = u in (3, 4, 5) and c1 + c2 <= 21 and ((c1 * 16 + nk2) if nk2 else nk1) <= 64 * u
     assert fits == ((L1, L2) not in ((33, 17), (170, 170), (100, 100)))      # (2 x 100 bp: 112 + 84 slots do not fit U = 3's 192)
     dev = torch.device("cuda:0")
-    for no_tri in (False, True):
+    for no_tri, tiles in ((False, False), (False, True), (True, False)):
         if no_tri:
             monkeypatch.setenv("SHK_NO_TRI", "1")
         else:
             monkeypatch.delenv("SHK_NO_TRI", raising=False)
+        monkeypatch.setenv("SHK_TILE_FIRST", "1" if tiles else "0")      # (one-gene indices: the tiles' round in front of the three pairs)
         o, h, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=0.5)
         assert h.probe_mode() == "lds-table"
         total = 0
@@ -1815,6 +1852,7 @@ def test_three_pairs_per_staging_pass(oracle, monkeypatch, L1, L2, k, n_genes):
             lk = h.last_kernel()
             if ", 21, " in lk:
                 assert ("+three-pairs" in lk) == (fits and not no_tri), (lk, n)
+                assert ("+tiles-first" in lk) == (fits and not no_tri and tiles and n_genes == 1), (lk, n)
             # the same batch resident in HBM, in buffers that end with the last read
             t = {kk: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) for kk, v in bb.items() if v is not None}
             torch.cuda.synchronize()
