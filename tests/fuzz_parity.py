@@ -23,7 +23,7 @@ from tests import synth
 
 ALL_MODES = ["bitvector-mod", "bitvector", "summary+bitvector", "table", "summary+table", "lds-summary+table", "table-mod",
              "lds-summary+table-mod", "lds-table", "minimiser-table"]
-ENV_KEYS = ("SHK_PROBE", "SHK_FORCE_GENERIC", "SHK_NO_LDS_TABLE", "SHK_KTAB", "SHK_NO_LDS_SUMMARY", "SHK_NO_SUMMARY")
+ENV_KEYS = ("SHK_PROBE", "SHK_FORCE_GENERIC", "SHK_NO_LDS_TABLE", "SHK_KTAB", "SHK_NO_LDS_SUMMARY", "SHK_NO_SUMMARY", "SHK_TILE_FIRST")
 
 
 def run_case(seed, bias=""):
@@ -57,6 +57,7 @@ def run_case(seed, bias=""):
         n_genes = int(rng.choice([1, 2, 7]))
         read_len = int(rng.choice([1, 8, 16, 17, 31, 33, 50, 76, 100, 125, 150, 151, 200, 250, 256, 259, 300]))
         var_len = bool(rng.random() < 0.15)
+        env["SHK_TILE_FIRST"] = "1" if rng.random() < 0.5 else "0"     # (one-gene indices, three pairs per pass: the tiles' round in front or not)
     elif bias == "mid":
         env.pop("SHK_PROBE", None)
         k = int(rng.choice([13, 17, 21, 31]))
