@@ -1265,11 +1265,11 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     // three pairs per staging pass (classify_uni.hpp, TRI): uniform batches without qualities, U = 3 ... 5 (SHK_NO_TRI=1: not)
     p.tri = (rmode == 1 && !hasq && u >= 3 && u <= 5 && !ctx->env_no_tri) ? 1u : 0u;
     // ... with a round of disjoint k-mers for the three pairs together in front (classify_uni.hpp, TF: an instantiation of its own)
-    // while the batch just finished had two fifths of its reads assigned or more: a pair from the gene then ends behind a THIRD of a
-    // hash round, a pair from elsewhere pays that third on top of its own two rounds.  Per 10 M pairs at 0 / 50 / 100 % on-target:
-    // 3.23 / 3.15 / 3.11 ms without, (4.3) / 2.97 / 1.66 with -- the two meet at about 42 %
+    // while the batch just finished had a quarter of its reads assigned or more: a pair from the gene then ends behind a THIRD of a
+    // hash round, a pair from elsewhere pays that third on top of its own two rounds (217 VALU instructions against 191).  Per 10 M
+    // pairs at 0 / 50 / 100 % on-target: 3.23 / 3.15 / 3.11 ms without, (3.7) / 2.69 / 1.69 with -- the two meet at about a quarter
     p.tile_first = (p.tri && p.lx_gene != 0xFFFFFFFFu && ctx->env_tile_first >= 0 &&
-                    (ctx->env_tile_first > 0 || (ctx->last.last_n_reads != 0 && (double)ctx->last.last_n_assoc >= 0.4 * (double)ctx->last.last_n_reads))) ? 1u : 0u;
+                    (ctx->env_tile_first > 0 || (ctx->last.last_n_reads != 0 && (double)ctx->last.last_n_assoc >= 0.25 * (double)ctx->last.last_n_reads))) ? 1u : 0u;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : (mode == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));   // (= UniGeom::MIN_WAVES)

@@ -699,7 +699,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // hash round: 2 x 150 bp, k = 17, c = 0.6 needs 11 of its 16 tiles (187 >= 180 bases), which a pair from the gene with 1 % errors has
   // 97 times in 100.  Such a pair ends here, behind a third of a round instead of a whole one and without any of its own set-up; a
   // pair with fewer matching tiles (more errors; from elsewhere) goes through the usual rounds as if nothing had happened -- having
-  // paid a third of a round for it, which is why the host asks for this only behind a batch with many reads assigned (two fifths: where
+  // paid a third of a round for it, which is why the host asks for this only behind a batch with many reads assigned (a quarter: where
   // the two kernels were measured to meet).  Pairs with invalid characters take part: a tile counts when its k characters are valid.
   // (An instantiation of its own, TFK: as a run-time switch of the three-pairs kernel its per-lane constants and masks cost that
   //  kernel a fifth of its speed with the round switched OFF -- 3.18 -> 3.82 ms per 10 M pairs from elsewhere; 110 -> 173 spilled scalars.)
@@ -883,7 +883,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         for (uint32_t p3 = 0; p3 < 3u; ++p3) {
           const uint32_t cnt = (uint32_t)__builtin_popcount((uint32_t)(Hb >> (16u * p3)) & 0xFFFFu);
           const uint32_t rd = 3u * it + p3;
-          if (cnt * k >= thr_full && rd < n_reads) {
+          // (said to be uniform in so many words: taken for a per-lane value, tf_done lived in a vector register and every pair of the
+          //  triple behind an exec-mask branch)
+          if (__builtin_amdgcn_readfirstlane((int)(cnt * k >= thr_full && rd < n_reads))) {
             if (lane == 0 && !SHK_ABL(P, 64u)) {
               sp_count[rd] = 1u;
               uint2 pk;
@@ -898,7 +900,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     auto per_pair = [&](auto tp_const) -> void {
     constexpr uint32_t tp = decltype(tp_const)::value;
-    if (TF && ((tf_done >> tp) & 1u)) return;
+    if (TF && (((uint32_t)__builtin_amdgcn_readfirstlane((int)tf_done) >> tp) & 1u)) return;
     if (TRI) {
       read = 3u * it + tp;
       if (read >= n_reads) return;

@@ -1374,7 +1374,7 @@ def test_panel_sized_index_follows_the_assigned_fraction(oracle, monkeypatch):
 
 
 def test_tiles_first_follows_the_assigned_fraction(oracle, monkeypatch):
-    """one-gene index in LDS, uniform batches: behind a batch with two fifths of its reads assigned or more the three-pairs kernel is
+    """one-gene index in LDS, uniform batches: behind a batch with a quarter of its reads assigned or more the three-pairs kernel is
     launched with the tiles' round in front (a pair from the gene ends behind a third of a hash round), behind a batch of reads from
     elsewhere without it (they would pay that third for nothing); identical results either way, in every order of batches; pairs
     with more errors than the tiles forgive, with N, and chimeric pairs on either side of the threshold go on through the usual rounds"""
@@ -1396,7 +1396,7 @@ def test_tiles_first_follows_the_assigned_fraction(oracle, monkeypatch):
     assert all(t for _, _, t in seen), seen
     assert not seen[0][1]                                       # (no predecessor: without)
     for (frac_before, _, _), (_, tiles, _) in zip(seen, seen[1:]):
-        assert tiles == (frac_before >= 0.4), seen
+        assert tiles == (frac_before >= 0.25), seen
     assert any(t for _, t, _ in seen) and not all(t for _, t, _ in seen[1:])
     h.close()
 
