@@ -602,7 +602,7 @@ __global__ __launch_bounds__((FastGeom<MODE, U>::THREADS), (FastGeom<MODE, U>::M
 
 // Does every read of the batch have the same length per mate, and does such a read fit `slot_cap` slots and 64 staging
 // groups?  flag = {1 | 0, L1, L2}.  One pass over the offsets (16 B per pair), a few tens of microseconds for 10 M pairs.
-__global__ __launch_bounds__(256) void uniform_check_kernel(const ClassifyParams P, uint32_t slot_cap, uint32_t *__restrict__ flag)
+__global__ __launch_bounds__(1024) void uniform_check_kernel(const ClassifyParams P, uint32_t slot_cap, uint32_t *__restrict__ flag)
 {
   // flag[3] (scratch) counts violations; the last workgroup to finish writes the verdict
   __shared__ uint32_t bad_s;
@@ -1323,10 +1323,12 @@ int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *f
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream)
 {
   // (flag[] is zero: cleared with the batch's counters, shark_hip.hip enqueue_classify)
-  const uint64_t want = (p.n + 255) / 256;
   // (every workgroup ends with an atomic on the same word -- and three more when the batch is ragged --, 40-50 ns each one after the
-  //  other: 1 024 workgroups spent half of the kernel's 0.08 ms there)
-  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 256 ? want : 256))), dim3(256), 0, stream, p, slot_cap, flag);
+  //  other: 1 024 workgroups spent half of the kernel's 0.08 ms there.  So 256 workgroups -- of 1 024 threads for large batches:
+  //  160 MB of offsets per 10 M pairs want more loads in flight than 65 536 threads have)
+  const unsigned threads = p.n >= (1ull << 20) ? 1024u : 256u;
+  const uint64_t want = (p.n + threads - 1) / threads;
+  hipLaunchKernelGGL(uniform_check_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 256 ? want : 256))), dim3(threads), 0, stream, p, slot_cap, flag);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 
