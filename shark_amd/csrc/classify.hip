@@ -1271,6 +1271,17 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.tile_first = (p.tri && p.lx_gene != 0xFFFFFFFFu && ctx->env_tile_first >= 0 &&
                     (ctx->env_tile_first > 0 || (ctx->last.last_n_reads != 0 && (double)ctx->last.last_n_assoc >= 0.25 * (double)ctx->last.last_n_reads))) ? 1u : 0u;
   }
+  // The pairs a base-for-base comparison with the reference settles, settled in front of the table kernel (anchor_verdict.hip): uniform
+  // batches on an index that carries the reference arrays, while the anchored extension is on (above).  The table kernel then skips
+  // the reads that have their result, and its own verdict by mismatch count (classify_uni.hpp (2b)) is left to the batches this
+  // kernel does not take (SHK_NO_PRE_VERDICT=1: never)
+  bool pre = false;
+  if (rmode == 1 && (!pm_lds(mode) || big) && !ctx->env_no_pre_verdict && anchor_verdict_applies(p)) {
+    if (int rc = launch_anchor_verdict(p, ctx->idx.pow2, stream)) return rc;
+    pre = true;
+    p.pre_verdict = 1u;
+    p.refext = nullptr;
+  }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : (mode == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));   // (= UniGeom::MIN_WAVES)
   const uint64_t wpb = lx ? SHK_LX_WAVES : (wg16 ? 16 : 8);
@@ -1289,9 +1300,9 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   if (rmode == 2) return SHK_OK;             // (shk_last_kernel names the uniform / ragged launch)
   // (with p.uni_flag both instantiations are launched and one returns at once: the name says UNI = "device")
   if (uni || !p.uni_flag)
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s", u, mode, hasq ? "true" : "false",
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s%s%s", u, mode, hasq ? "true" : "false",
              (lx && (u <= 5 || u == 10)) ? 21 : ((big && (u <= 5 || u == 10)) ? 20 : 18), p.uni_flag ? "device" : (uni ? "true" : "false"),
-             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "",
+             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "", (!pm_lds(mode) && p.ref_total && p.refext) ? " +mismatch-verdict" : "", pre ? " +pre-verdict" : "",
              (lx && p.lx_gene != 0xFFFFFFFFu) ? " +sparse-first-round" : ((lx && p.lx_multi) ? " +sparse-first-rounds" : ""));
   if (lx && p.tri && (uni || !p.uni_flag) && (p.uni_flag || tri_applies_host(p.uni_L1, p.uni_L2, p.k, 64u * u))) {
     const size_t l = strlen(ctx->last_kernel);

@@ -69,6 +69,16 @@ __device__ __forceinline__ uint64_t bf_pos_np(uint64_t h, const ClassifyParams &
   return P.mod_fast ? bf_pos_fastmod(h, P.mod_shift, P.mod_m, P.mod_c) : h % P.bf_bits;
 }
 
+// the smallest integer t with (double)t >= c * (double)len: an integer coverage passes the reference's test (ReadAnalyzer.hpp:104)
+// iff it is >= t.  0 when the product is not positive (or NaN): nothing can be ruled out
+__device__ __forceinline__ uint32_t cov_threshold(const double c, const uint32_t len)
+{
+  const double x = c * (double)len;
+  if (!(x > 0.0)) return 0u;
+  if (x >= 4294967295.0) return 0xFFFFFFFFu;
+  return (uint32_t)ceil(x);
+}
+
 // Per-wave staging area of a read (LDS in the fast kernel, a global scratch slice in the general
 // kernel).  The read's bases live at PACKED positions: mate 1 at [0, L1), mate 2 at [P2, P2+L2)
 // with P2 = L1 rounded up to 8.  A k-mer SLOT is a packed position pp: slot pp is the k-mer that

@@ -64,16 +64,7 @@ typedef const uint64_t __attribute__((address_space(4))) *ConstU64;
 // after two rounds the rest covers 22 + 150 = 172 < 180 bases, so an off-target pair costs 128 probes instead of 320.)
 // The result is the reference's for every read; tests/test_gpu_parity.py walks chimeric reads across the boundary.
 
-// the smallest integer t with (double)t >= c * (double)len: an integer coverage passes the reference's test iff it is >= t.
-// 0 when the product is not positive (or NaN): nothing can be ruled out
-__device__ __forceinline__ uint32_t cov_threshold(const double c, const uint32_t len)
-{
-  const double x = c * (double)len;
-  if (!(x > 0.0)) return 0u;
-  if (x >= 4294967295.0) return 0xFFFFFFFFu;
-  return (uint32_t)ceil(x);
-}
-
+// (cov_threshold: classify_common.hpp)
 // bases covered by the existing slots at packed positions >= s (mate 1: slots [0, nk1) cover [0, l1); mate 2 likewise at P2)
 __device__ __forceinline__ uint32_t bases_behind(const uint32_t s, const uint32_t nk1, const uint32_t nk2, const uint32_t P2,
                                                  const uint32_t l1, const uint32_t l2)
@@ -664,6 +655,17 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   auto plan_index = [&](const ReadMeta &m) -> uint32_t { return (m.L1 <= L1 && m.L2 <= L2) ? m.L1 * (L2 + 1u) + m.L2 : 0u; };
   auto plan_issue = [&](const ReadMeta &m) -> uint4 { return has_plans ? P.plan_tab[plan_index(m)] : make_uint4(0u, 0u, 0u, 0u); };
   uint4 pl_cur = make_uint4(0u, 0u, 0u, 0u);
+  // PRE (uniform batches beyond the exact-table instantiations): anchor_verdict_kernel may have run in front of this launch
+  // (P.pre_verdict): a read whose count[] is set has its result already and is passed over -- its flag is fetched with its bases
+  constexpr bool PRE = UNI && !CLS && !LX;
+  const uint32_t *pre_count = nullptr;
+  uint32_t done_cur = 0u;
+  if (PRE && P.pre_verdict) pre_count = P.out->count;
+  auto pre_fetch = [&](const uint32_t r) -> uint32_t {
+    const uint32_t *cp = pre_count + r;
+    asm volatile("" : "+v"(cp));   // (a vector load: a scalar one would share lgkmcnt with the LDS accesses of the read at hand)
+    return *cp;
+  };
   if (CLS) {
     entry_fetch(it, w_cur, q_cur);
     read = read_nxt;
@@ -672,6 +674,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     tri_retire(t_cur);
   } else if (UNI) {
     issue(read, w_cur, q_cur);
+    if (PRE && pre_count) done_cur = pre_fetch(read);
   } else {
     m_cur = fetch_meta(P, read);
     fetch_groups(m_cur, w_cur, q_cur);
@@ -748,8 +751,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (DYN) {
       if (lane == 0) dyn_take = atomicAdd(dyn_ctr, 1u);
     }
+    uint32_t done_nxt = 0u;
+    if (PRE && pre_count && have_nxt) done_nxt = pre_fetch(nxt);
     SHK_STAMP(0);
     bool skip = false;
+    if (PRE && __builtin_amdgcn_readfirstlane((int)done_cur) != 0) skip = true;
     if (!UNI) {
       const uint32_t ns = nk2 ? ((m_cur.L1 + 7u) & ~7u) + nk2 : nk1;
       // longer than the batch's layout (FIXLAY) / this specialisation holds: the general kernel's queue (as process_read does)
@@ -1582,21 +1588,50 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       // lies in the reference (64 slots of a round read 256 contiguous bytes), so that these loads and the reference bases below
       // are one memory round trip, not two
       uint32_t inb_mask = 0u, okv_mask = 0u;
+      auto request_payloads = [&]() {
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const uint32_t pp = (uint32_t)lane + 64u * j;
-        const bool in2 = (pp - P2) < nk2;
-        const bool okv = slot_valid(pp);
-        const bool have = in2 ? ahave[1] : ahave[0];
-        const bool opp = in2 ? aopp[1] : aopp[0];
-        const uint32_t x0 = in2 ? ax[1] : ax[0];
-        const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
-        const uint32_t xr = opp ? x0 - dd : x0 + dd;               // where the slot's k-mer starts in the reference
-        const bool inb = okv & have & (xr < ref_total);
-        slo[j] = refpay[inb ? xr : 0u];
-        inb_mask |= inb ? (1u << j) : 0u;
-        okv_mask |= okv ? (1u << j) : 0u;
+        for (int j = 0; j < U; ++j) {
+          const uint32_t pp = (uint32_t)lane + 64u * j;
+          const bool in2 = (pp - P2) < nk2;
+          const bool okv = slot_valid(pp);
+          const bool have = in2 ? ahave[1] : ahave[0];
+          const bool opp = in2 ? aopp[1] : aopp[0];
+          const uint32_t x0 = in2 ? ax[1] : ax[0];
+          const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
+          const uint32_t xr = opp ? x0 - dd : x0 + dd;               // where the slot's k-mer starts in the reference
+          const bool inb = okv & have & (xr < ref_total);
+          slo[j] = refpay[inb ? xr : 0u];
+          inb_mask |= inb ? (1u << j) : 0u;
+          okv_mask |= okv ? (1u << j) : 0u;
+        }
+      };
+      // (2b) THE VERDICT BY MISMATCH COUNT (round 6; `refext`, shark_internal.hpp).  refext[x] says how far around x the reference's
+      // k-mers answer with ONE single-gene list {g}.  If every slot of every mate falls on such a position (both anchors' extents
+      // cover their mates, same g), then each slot whose k bases agree with the reference is a hit of g and of g alone -- equal k-mers
+      // have equal filter positions, as in (3) -- whichever slots those are.  With e = the bases of the pair that do NOT agree (or are
+      // invalid characters): a disagreeing base lies in at most k slots, so at least n = nk1 + nk2 - e k slots are g's alone, and they
+      // cover at least n + k - 1 bases (the union of [p, p + k) contains every p and k - 1 bases behind the last); the other slots --
+      // the only ones another gene's list can sit under -- cover at most 2 k - 1 bases per disagreeing base.  n + k - 1 >= c len and
+      // n + k - 1 > e (2 k - 1) therefore make g the pair's only association (ReadAnalyzer.hpp:90-108), by the early decision's own
+      // argument -- without a payload, a match-bit window or a vote per slot: 2 x 150 bp, k = 17, c = 0.6 passes up to e = 5.
+      // Everything else goes on as before, its payloads requested one round trip later.
+      bool mc_try = false;
+      uint32_t mc_gene = 0u;
+      if (const uint32_t *refext = H->refext; refext != nullptr && thr_r != 0u && (nk1 | nk2) != 0u && (nk1 == 0u || ahave[0]) && (nk2 == 0u || ahave[1])) {
+        // (wave-uniform addresses: one request each)
+        const uint32_t x1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refext[nk1 ? ax[0] : ax[1]]);
+        const uint32_t x2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refext[nk2 ? ax[1] : ax[0]]);
+        auto covers = [&](const uint32_t ev, const uint32_t before, const uint32_t after, const bool opp) -> bool {
+          const uint32_t left = (ev >> 16) & 0xFFu, right = ev >> 24;
+          return ev != REFEXT_NONE && (opp ? (right >= before) & (left >= after) : (left >= before) & (right >= after));
+        };
+        const bool ok1 = nk1 == 0u || covers(x1, as0[0], nk1 - 1u - as0[0], aopp[0]);
+        const bool ok2 = nk2 == 0u || covers(x2, as0[1] - P2, P2 + nk2 - 1u - as0[1], aopp[1]);
+        mc_try = ok1 && ok2 && ((x1 ^ x2) & 0xFFFFu) == 0u;
+        mc_gene = x1 & 0xFFFFu;
       }
+      if (!mc_try) request_payloads();
+      uint32_t mc_mis = 0u;
       {
         const uint32_t *ref2 = H->ref2;
         const uint32_t m = (uint32_t)lane >> 5, c16 = ((uint32_t)lane & 31u) << 4;
@@ -1625,6 +1660,16 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         e = (e | (e >> 4)) & 0x00FF00FFu;
         e = (e | (e >> 8)) & 0xFFFFu;
         const uint32_t M16 = inr ? (e & ((1u << n_in) - 1u)) : 0u;
+        if (mc_try) {
+          // bases of the chunk that do not agree with the reference, or are no valid character (N, a masked quality)
+          uint32_t ok16 = M16;
+          if (any_inv) {
+            const uint8_t *vb = reinterpret_cast<const uint8_t *>(vbits);
+            const uint32_t byv = n_in ? (b0 >> 3) : 0u;
+            ok16 &= (uint32_t)vb[byv] | ((uint32_t)vb[byv + 1u] << 8);
+          }
+          mc_mis = n_in - (uint32_t)__builtin_popcount(ok16);
+        }
         // bytes 2 c and 2 c + 1 of the mate's part of the stream (mate 2 starts at byte P2 / 8; mate 1's last chunk may reach past it:
         // those bytes are mate 2's).  Bytes behind the mate are cleared as far as the stream goes: no stale bit of an earlier read
         constexpr uint32_t MBYTES = vbit_words_for(S) * 8u;
@@ -1632,6 +1677,27 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t by = b0 >> 3, end = m ? MBYTES : (P2 >> 3);
         if (by < end) mb[by] = (uint8_t)M16;
         if (by + 1u < end) mb[by + 1u] = (uint8_t)(M16 >> 8);
+      }
+      if (mc_try) {
+        const uint32_t e_mis = wave_sum_u32(mc_mis), nks = nk1 + nk2, killed = e_mis * k;
+        if (killed < nks) {
+          const uint32_t cov_lb = nks - killed + k - 1u;
+          if (cov_lb >= thr_r && cov_lb > e_mis * (2u * k - 1u)) {
+            if (lane == 0 && !SHK_ABL(P, 64u)) {
+              const ClassifyOut *O = H->out;
+              O->count[read] = 1u;
+              uint2 pk;
+              pk.x = mc_gene;
+              pk.y = 0u;
+              *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
+#ifdef SHK_ANCH_STATS
+              atomicAdd(&O->counters[CTR_UNUSED3], 1u);
+#endif
+            }
+            return true;
+          }
+        }
+        request_payloads();
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1970,6 +2036,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       pl_cur = pl_nxt;
     }
     it = nxt;
+    if (PRE) done_cur = done_nxt;
     if (DYN) dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
     read = CLS ? read_nxt : it;
 #pragma unroll

@@ -341,6 +341,24 @@ __global__ __launch_bounds__(256) void ref_multi_write_kernel(uint32_t *__restri
   ent[n_set + 1 + x] = out;
 }
 
+// What the anchored extension's early verdict needs to know about the surroundings of an anchor (DeviceIndex::refext).  Position x
+// whose k-mer answers with the single-gene list {g}: g | left << 16 | right << 24, where left / right count the positions directly
+// in front of / behind x whose k-mers answer with the SAME single-gene list (clipped at REFEXT_CLIP); REFEXT_NONE where no valid k-mer
+// starts or its list has several genes.  A mate anchored at x whose slots all fall on positions within those extents needs no
+// per-slot payload: every k-mer of it that equals the reference's is g's alone.  One thread per position, neighbours from refpay
+// (a run of equal payloads is walked by every thread inside it: 2 x 254 coalesced, cache-resident loads at most).
+__global__ __launch_bounds__(256) void ref_extent_kernel(const uint32_t *__restrict__ refpay, uint64_t total, uint32_t *__restrict__ refext)
+{
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= total) return;
+  const uint32_t v = refpay[x];
+  if (v == REFPAY_NONE || (v >> 31) != 0u || v > 0xFFFFu) { refext[x] = REFEXT_NONE; return; }
+  uint32_t left = 0, right = 0;
+  while (left < REFEXT_CLIP && x > left && refpay[x - 1 - left] == v) ++left;
+  while (right < REFEXT_CLIP && x + 1 + right < total && refpay[x + 1 + right] == v) ++right;
+  refext[x] = v | (left << 16) | (right << 24);
+}
+
 // ---- the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab) ----
 // Every canonical k-mer x (4^k / 2 of them) is asked what the reference asks of it: is bit XXH64(x) mod size set
 // (bloomfilter.h:87-89)?  The k-mers for which it is -- the reference's own and the filter's false positives alike -- become
@@ -669,8 +687,8 @@ int build_index(Ctx *ctx)
           ListEntry *ent_all = nullptr;
           uint16_t *ids_all = nullptr;
           auto drop_anchor = [&]() {
-            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.atab);
-            ix.ref2 = ix.refpay = nullptr;
+            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.atab); (void)hipFree(ix.refext);
+            ix.ref2 = ix.refpay = ix.refext = nullptr;
             ix.atab = nullptr;
             ix.ref_total = 0;
           };
@@ -732,6 +750,20 @@ int build_index(Ctx *ctx)
             AX_HIP(hipStreamSynchronize(st));
             return true;
           }();
+          // the surroundings of every anchor (ref_extent_kernel), for the anchored extension's verdict by mismatch count; optional by
+          // itself (SHK_NO_REFEXT=1: not built; the tests run both)
+          if (ix.refext) { (void)hipFree(ix.refext); ix.refext = nullptr; }
+          if (have && !getenv("SHK_NO_REFEXT")) {
+            const bool ok = [&]() -> bool {
+              AX_HIP(hipMalloc((void **)&ix.refext, (total + 8) * sizeof(uint32_t)));
+              AX_HIP(hipMemsetAsync(ix.refext + total, 0xFF, 8 * sizeof(uint32_t), st));
+              hipLaunchKernelGGL(ref_extent_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const uint32_t *)ix.refpay, total, ix.refext);
+              AX_HIP(hipGetLastError());
+              AX_HIP(hipStreamSynchronize(st));
+              return true;
+            }();
+            if (!ok) { (void)hipFree(ix.refext); ix.refext = nullptr; }
+          }
 #undef AX_HIP
           (void)hipGetLastError();   // (nothing that failed above is an error of the build)
           (void)hipFree(ent_all); (void)hipFree(ids_all); (void)hipFree(d_lens); (void)hipFree(d_stmp);

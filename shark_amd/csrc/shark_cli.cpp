@@ -12,6 +12,7 @@
 // per GPU calls shk_classify (ReadAnalyzer role), and the main thread writes
 // batches in input order (ReadOutput role).  Extra flags: --gpus N, --batch N.
 #include <getopt.h>
+#include <sched.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -1075,6 +1076,30 @@ class ReadOutput {
 
 }  // namespace
 
+// CPUs this process can actually run threads on: the machine's count, cut down to its affinity mask and to its cgroup's CPU quota
+// (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us)
+static unsigned usable_cpus()
+{
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int c = CPU_COUNT(&set);
+    if (c > 0) n = std::min(n, (unsigned)c);
+  }
+  long quota = -1, period = -1;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+    fclose(f);
+  } else {
+    if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%ld", &quota) != 1) quota = -1; fclose(fq); }
+    if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%ld", &period) != 1) period = -1; fclose(fp); }
+  }
+  if (quota > 0 && period > 0) n = std::min(n, (unsigned)std::max(1L, (quota + period - 1) / period));
+  return std::max(1u, n);
+}
+
 int main(int argc, char *argv[])
 {
   Options opt_parsed = parse_arguments(argc, argv);
@@ -1129,13 +1154,25 @@ int main(int argc, char *argv[])
   // the readers fill it while the runtime initialises -- and it costs nothing to set up.  SHARK_PINNED=1: page-locked.
   const bool pin_ring = getenv("SHARK_PINNED") && getenv("SHARK_PINNED")[0] == '1';
   std::thread ctx_thread([&] {
-    for (int g = 0; g < n_gpus; ++g) {
+    // N workers start like N workers (main.cpp:219-223 starts the reference's N threads at once): every context is created on a
+    // thread of its own -- the runtime comes up once, whoever gets there first; streams, the filter's allocation and its clearing,
+    // the slots' buffers then proceed side by side (serially, two contexts took 2.3 x one context's time, eight would have taken
+    // longer than a 16 M-pair sample on one GPU)
+    std::vector<int> rcs((size_t)n_gpus, SHK_OK);
+    auto create = [&](const int g) {
       shk_params p{};
       p.k = opt.k; p.c = opt.c; p.bf_bits = opt.bf_size; p.min_quality = opt.min_quality; p.single = opt.single;
-      p.device = opt.devices[(size_t)g];   // worker g's device (--devices; the reference's N workers come from one command line too, main.cpp:219-223)
-      const int rc = shk_create(&p, &ctxs[(size_t)g]);
-      if (rc != SHK_OK) { ctx_rc = rc; ctx_bad = g; break; }
+      p.device = opt.devices[(size_t)g];   // worker g's device (--devices)
+      rcs[(size_t)g] = shk_create(&p, &ctxs[(size_t)g]);
+    };
+    {
+      std::vector<std::thread> th;
+      for (int g = 1; g < n_gpus; ++g) th.emplace_back(create, g);
+      create(0);
+      for (auto &t : th) t.join();
     }
+    for (int g = n_gpus - 1; g >= 0; --g)
+      if (rcs[(size_t)g] != SHK_OK) { ctx_rc = rcs[(size_t)g]; ctx_bad = g; }
     timeline("contexts created");
     std::unique_lock<std::mutex> l(ctx_m);
     ctx_created = true;
@@ -1168,8 +1205,11 @@ int main(int argc, char *argv[])
   //   analyzers one thread per GPU, batch i -> GPU i mod N, SHK_PIPE_DEPTH batches in flight per GPU
   //   output    this thread, batches in input order (ReadOutput.hpp:37-50)
   {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::min(16u, hw);
+    // readers / parsers / formatters: sixteen per worker (what one GPU's feed was measured to use), as far as this process has cores
+    // to run them on -- its affinity mask and its cgroup's CPU quota count, not the machine's (a one-GPU share of a host is 16 cores
+    // whatever hardware_concurrency() says: more threads than that only take turns)
+    const unsigned hw = usable_cpus();
+    unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::max(1u, std::min(16u * (unsigned)n_gpus, hw));
     // (the reference opens its outputs unchecked and writes nothing to a file it could not open, main.cpp:99-106: same here)
     OffsetWriter w1, w2;
     // one writer thread per output file: tmpfs takes 8.7 GB/s from ONE thread writing a file and 3.6-4.6 GB/s from 2-12 threads
@@ -1744,9 +1784,13 @@ int main(int argc, char *argv[])
   // statics, which costs more than a tenth of a second and changes nothing
   fflush(stdout);
   fflush(stderr);
-  // (a profiler or another preloaded tool writes its results from exit handlers: under one, leave the ordinary way)
-  for (const char *var : {"ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "SHARK_CLEAN_EXIT"})
-    if (const char *v = getenv(var))
-      if (v[0]) exit(0);
+  // (a profiler writes its results from exit handlers: under one -- ROCP_TOOL_LIBRARIES, or an LD_PRELOAD that names a rocprofiler
+  //  library -- or when asked to (SHARK_CLEAN_EXIT=1), leave the ordinary way.  Any other preloaded library, an allocator say, does
+  //  not change how the process leaves.  The contexts are destroyed above: exit handlers find no live context.)
+  bool clean_exit = false;
+  if (const char *v = getenv("ROCP_TOOL_LIBRARIES")) clean_exit = v[0] != 0;
+  if (const char *v = getenv("SHARK_CLEAN_EXIT")) clean_exit = clean_exit || (v[0] != 0 && v[0] != '0');
+  if (const char *v = getenv("LD_PRELOAD")) clean_exit = clean_exit || strstr(v, "rocprof") != nullptr || strstr(v, "roctracer") != nullptr;
+  if (clean_exit) exit(0);
   _exit(0);
 }

@@ -27,7 +27,7 @@ int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
 
 static void free_index(DeviceIndex &ix)
 {
-  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.atab); hipFree(ix.ktab);
+  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.refext); hipFree(ix.atab); hipFree(ix.ktab);
   ix = DeviceIndex{};
 }
 
@@ -151,7 +151,7 @@ static void fill_params(Ctx *ctx, Slot &s, const shk_batch *b)
   p.tab_nt = ix.tab_lg && (16ull << ix.tab_lg) > (256ull << 20);   // beyond L2 + Infinity Cache
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
   p.lx_gene = 0xFFFFFFFFu;   // (launch_classify_uni sets it when it chooses the exact LDS table)
-  p.ref2 = ix.ref2; p.refpay = ix.refpay; p.atab = ix.atab; p.ref_total = ix.ref_total;
+  p.ref2 = ix.ref2; p.refpay = ix.refpay; p.atab = ix.atab; p.ref_total = ix.ref_total; p.refext = ix.refext;
   p.ktab = ix.ktab_lg ? ix.ktab : nullptr; p.ktab_lg = ix.ktab_lg; p.ktab_w = ix.ktab_w;
   // (far beyond the caches: streaming loads -- 17.8 / 18.1 -> 16.7 / 17.3 ms per 10 M pairs at 0 / 50 % on-target on the 60 000-gene index)
   p.ktab_nt = (ix.ktab_lg && (16ull << ix.ktab_lg) > (256ull << 20) && !ctx->env_ktab_plain) || ctx->env_ktab_nt ? 1u : 0u;
@@ -614,6 +614,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     { const char *nt = getenv("SHK_KTAB_NT"); ctx->env_ktab_nt = nt && nt[0] == '1'; ctx->env_ktab_plain = nt && nt[0] == '0'; }
     ctx->env_ktab_always = getenv("SHK_KTAB") != nullptr;
     ctx->env_anchor_always = getenv("SHK_ANCHOR_ALWAYS") != nullptr;
+    ctx->env_no_pre_verdict = getenv("SHK_NO_PRE_VERDICT") != nullptr;
     ctx->env_no_tri = getenv("SHK_NO_TRI") != nullptr;
     ctx->env_tile_first = getenv("SHK_TILE_FIRST") ? (getenv("SHK_TILE_FIRST")[0] == '0' ? -1 : 1) : 0;
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }

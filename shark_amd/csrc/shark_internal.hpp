@@ -85,7 +85,10 @@ struct DeviceIndex {
   //            reverse complement); 0xFFFFFFFF = unset.  Same buckets, same high words: the anchored extension's sample probes THIS
   //            table, and the bucket that says "the k-mer is in the index" says where in the reference in the same memory round trip
   //            (round 3 kept the occurrences in an array of their own, indexed by the slot that had matched: a dependent load)
-  uint32_t *ref2 = nullptr, *refpay = nullptr;
+  //   refext : per base position x with a single-gene list {g} under its k-mer: g | left << 16 | right << 24 -- how many positions
+  //            directly in front of / behind x answer with the same list (clipped at REFEXT_CLIP); REFEXT_NONE elsewhere.  What the
+  //            anchored extension's verdict by mismatch count needs instead of a payload per slot (classify_uni.hpp)
+  uint32_t *ref2 = nullptr, *refpay = nullptr, *refext = nullptr;
   uint64_t *atab = nullptr;
   uint32_t ref_total = 0;    // bases in ref2 / entries in refpay; 0 = not built
   // ---- the index a third time, keyed by the K-MER and bucketed by its MINIMISER (k = 15 ... 17, tables beyond the caches) ----
@@ -102,6 +105,7 @@ struct DeviceIndex {
   uint32_t ktab_w = 0;       // w (the minimiser's length)
   uint64_t ktab_keys = 0;    // keys it holds (reference k-mers + false positives of the filter)
 };
+constexpr uint32_t REFEXT_NONE = 0xFFFFFFFFu, REFEXT_CLIP = 254u;   // (an extent never reads 255: no entry looks like REFEXT_NONE)
 constexpr uint32_t REFPAY_NONE = 0xFFFFFFFFu;   // (multi with payload 2^30-1: not a rank, n_set <= 2^30-1 entries have ranks below that)
 
 // per-wave staging area of a read for a slot capacity S (layout: classify.hip)
@@ -163,6 +167,8 @@ struct ClassifyParams {
   const uint32_t *refpay;
   const uint64_t *atab;
   uint32_t ref_total;
+  const uint32_t *refext;    // DeviceIndex::refext; nullptr: no verdict by mismatch count
+  uint32_t pre_verdict;      // 1 = anchor_verdict_kernel ran in front of this launch: a read whose count[] is set has its result
   // the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab; classify_uni_kernel's PM_KTAB instantiations)
   const uint64_t *ktab;
   uint32_t ktab_lg, ktab_w;
@@ -291,6 +297,9 @@ int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *f
 bool class_kernel_available(const Ctx *ctx, uint32_t max_slots);
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);
 bool uni_kernel_available(const Ctx *ctx);
+// anchor_verdict.hip
+bool anchor_verdict_applies(const ClassifyParams &p);
+int launch_anchor_verdict(const ClassifyParams &p, bool pow2, hipStream_t stream);
 uint32_t fast_kernel_max_slots();
 uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
 uint32_t uni_kernel_max_groups(uint32_t max_slots);   // staging groups per pair classify_uni_kernel can take at that specialisation
@@ -329,6 +338,7 @@ struct Ctx {
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
   int env_tile_first = 0;           // SHK_TILE_FIRST=1: the tiles' round for every batch it can serve (tests); =0: never; unset: by the last batch's assigned fraction
   bool env_no_tri = false;          // SHK_NO_TRI=1: no three-pairs-per-pass instantiation (A/B timing, tests)
+  bool env_no_pre_verdict = false;  // SHK_NO_PRE_VERDICT=1: no anchor_verdict_kernel in front of the table kernels (A/B timing, tests)
   bool env_anchor_always = false;   // SHK_ANCHOR_ALWAYS=1: the anchored extension for every batch of an index that has the reference arrays (tests, A/B timing)
   bool env_ktab_always = false;     // SHK_KTAB=1: the minimiser table for every batch of an index that has it (tests)
   bool env_ktab_nt = false, env_ktab_plain = false;   // SHK_KTAB_NT=1 / 0: the minimiser table probed with / without non-temporal loads whatever its size (A/B timing, tests)

@@ -1721,6 +1721,112 @@ def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
 
 
 # ---------------------------------------------------------------------------
+# the anchored extension's verdict by mismatch count (classify_uni.hpp (2b); DeviceIndex::refext)
+# ---------------------------------------------------------------------------
+def _pairs_with_counted_mismatches(rng, genes, n, L1, L2, ragged, qual):
+    """pairs cut from a gene with a CHOSEN number of disagreeing bases (0 ... 12 per pair: on both sides of what the verdict accepts
+    for any threshold), spread, clustered or at the mates' ends, as substitutions or N; fragments that start in one gene's own
+    sequence and run into a stretch it shares with another gene (the extents of `refext` end inside the read), mates of two
+    genes, a mate shifted by an insertion, either strand"""
+    m1s, m2s, q1s, q2s = [], [], [], []
+    for _ in range(n):
+        gi = int(rng.integers(0, len(genes)))
+        g = genes[gi]
+        l1 = int(rng.integers(max(1, (2 * L1) // 3), L1 + 1)) if ragged else L1
+        l2 = (int(rng.integers(max(1, (2 * L2) // 3), L2 + 1)) if ragged else L2) if L2 else 0
+        if len(g) < max(l1, l2) + 2:
+            g = max(genes, key=len)
+        frag = int(rng.integers(max(l1, l2), min(len(g), max(l1, l2) * 3) + 1))
+        st = int(rng.integers(0, len(g) - frag + 1))
+        f = g[st:st + frag]
+        a = f[:l1].copy()
+        b = synth.revcomp(f)[:l2].copy() if L2 else None
+        if L2 and rng.random() < 0.1:                                     # mate 2 from another gene
+            g2 = genes[int(rng.integers(0, len(genes)))]
+            if len(g2) > l2:
+                s2 = int(rng.integers(0, len(g2) - l2))
+                b = g2[s2:s2 + l2].copy()
+        if rng.random() < 0.5 and L2 and l1 == l2:
+            a, b = b, a
+        e = int(rng.integers(0, 13))
+        mates = [a, b] if L2 else [a]
+        form = int(rng.integers(0, 4))
+        for _i in range(e):
+            m = mates[int(rng.integers(0, len(mates)))]
+            if form == 0:
+                p_ = int(rng.integers(0, len(m)))                        # anywhere
+            elif form == 1:
+                p_ = int(min(len(m) - 1, rng.integers(0, 24)))            # the mate's first bases
+            elif form == 2:
+                p_ = int(max(0, len(m) - 1 - rng.integers(0, 24)))        # its last bases
+            else:
+                c0 = len(m) // 2
+                p_ = int(np.clip(c0 + rng.integers(-10, 11), 0, len(m) - 1))   # one cluster
+            if rng.random() < 0.25:
+                m[p_] = ord("N")
+            else:
+                m[p_] = [x for x in b"ACGT" if x != m[p_]][int(rng.integers(0, 3))]          # another base
+        if rng.random() < 0.05:                                           # an insertion: everything behind it is shifted
+            m = mates[0]
+            p_ = int(rng.integers(1, len(m)))
+            m[p_:] = np.concatenate([synth.random_seq(rng, 1), m[p_:-1]])
+        m1s.append(mates[0])
+        if L2:
+            m2s.append(mates[1])
+        if qual:
+            for lst, m in zip((q1s, q2s), mates):
+                q = np.where(rng.random(len(m)) < 0.97, rng.integers(25, 42, size=len(m)), rng.integers(2, 20, size=len(m)))
+                lst.append((q + 33).astype(np.uint8))
+    return synth.batch_from_lists(m1s, m2s if L2 else None, q1s if qual else None, q2s if (qual and L2) else None)
+
+
+@pytest.mark.parametrize("env", [{"SHK_NO_LDS_SUMMARY": "1"}, {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1"},
+                                 {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1", "BF": str(3 << 24)}])
+@pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (100, 100, 16), (150, 0, 20), (76, 76, 11), (250, 250, 21), (300, 300, 17), (150, 12, 17)])
+def test_verdict_by_mismatch_count(oracle, monkeypatch, env, L1, L2, k):
+    """(2b) of the anchored extension: pairs whose anchors' surroundings answer with one single-gene list are decided from the
+    NUMBER of bases that disagree with the reference.  Pairs with 0 ... 12 such bases -- spread, clustered, at the ends, as N --,
+    thresholds on both sides of what their matched slots cover, references with shared halves (extents that end inside a read),
+    repeats inside a gene, mates of two genes: the oracle's result with `refext` and without it (SHK_NO_REFEXT=1 at build time)."""
+    bf_bits = 1 << 26
+    for name, v in env.items():
+        if name == "BF":
+            bf_bits = int(v)
+        else:
+            monkeypatch.setenv(name, v)
+    rng = np.random.default_rng(6100 + L1 + 3 * L2 + k)
+    genes = synth.make_genes(rng, 18, 900, 3500, share_every=3)
+    genes[4][300:303] = ord("N")
+    rep = genes[6][100:100 + 3 * k].copy()                               # a repeat inside a gene: an anchor may name the other copy
+    genes[6][700:700 + len(rep)] = rep
+    genes[8] = np.concatenate([genes[8], genes[10][:400]])               # one gene's start is the tail of another
+    monkeypatch.setenv("SHK_ANCHOR_ALWAYS", "1")
+    # "pre": anchor_verdict_kernel in front of the table kernel for uniform batches (trimmed ones: the table kernel's own verdict, (2b));
+    # "2b": no kernel in front, (2b) for every batch; "none": the index carries no `refext`
+    for how in ("pre", "2b", "none"):
+        monkeypatch.delenv("SHK_NO_REFEXT", raising=False)
+        monkeypatch.delenv("SHK_NO_PRE_VERDICT", raising=False)
+        if how == "none":
+            monkeypatch.setenv("SHK_NO_REFEXT", "1")
+        if how == "2b":
+            monkeypatch.setenv("SHK_NO_PRE_VERDICT", "1")
+        for c, single, q in ((0.6, False, 0), (0.2, True, 0), (0.85, False, 0), (0.97, False, 0), (0.6, False, 20)):
+            if how != "pre" and c != 0.6:
+                continue
+            o, h, info = _build_both(oracle, genes, k=k, bf_bits=bf_bits, c=c, min_quality=q, single=single)
+            assert h.probe_mode() in ("table", "summary+table", "table-mod"), h.probe_mode()
+            for ragged in (False, True):
+                batch = _pairs_with_counted_mismatches(rng, genes, 600, L1, L2, ragged, q > 0)
+                goff, _ = _compare_classify(o, h, batch)
+                assert goff[-1] > 0 or c > 0.9
+                if "classify_uni_kernel" in h.last_kernel():
+                    lk = h.last_kernel()
+                    assert ("+pre-verdict" in lk) == (how == "pre" and not ragged), lk
+                    assert ("+mismatch-verdict" in lk) == (how == "2b" or (how == "pre" and ragged)), lk
+            h.close()
+
+
+# ---------------------------------------------------------------------------
 # one-gene indices in LDS: the sparse first round (classify_uni.hpp, spT / sparse_first)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (140, 140, 17), (100, 100, 17), (125, 125, 12), (151, 101, 17), (101, 151, 17),

@@ -6,7 +6,7 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/tools/variants; mkdir -p $OUT/$NAME
 cd $ROOT/shark_amd/csrc
-for f in classify_uni_u10 classify_uni_u5 classify_uni_u8 classify_uni_u6 classify_uni_u4 classify_uni_u3 classify_uni_u2 classify index_build shark_hip device_scan device_sort measure; do
+for f in classify_uni_u10 classify_uni_u5 classify_uni_u8 classify_uni_u6 classify_uni_u4 classify_uni_u3 classify_uni_u2 classify anchor_verdict index_build shark_hip device_scan device_sort measure; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc "$@" -c $f.hip -o $OUT/$NAME/$f.o &
 done
 wait
