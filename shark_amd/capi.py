@@ -99,28 +99,30 @@ def load():
     L.shk_gene_counts_allreduce.restype = C.c_int; L.shk_gene_counts_allreduce.argtypes = [C.POINTER(p), C.c_int, p, C.c_uint32]
     L.shk_classify_submit.restype = C.c_int; L.shk_classify_submit.argtypes = [p, C.POINTER(ShkBatch), C.POINTER(C.c_uint64)]
     L.shk_classify_wait.restype = C.c_int; L.shk_classify_wait.argtypes = [p, C.c_uint64, C.POINTER(ShkResult)]
-    if os.environ.get("SHK_LIB_PATH"):
-        # (a library variant for A/B timing, tools/build_variant.sh, possibly built from an older tree: entry points it lacks are
-        #  simply not callable; the product library is checked symbol by symbol in tests/test_cabi_cpu.py)
-        for name in ("shk_classify_device_submit", "shk_measure_valu_mix"):
-            if not hasattr(L, name):
-                setattr(L, name, None)
-        if L.shk_classify_device_submit is None or L.shk_measure_valu_mix is None:
-            _lib = L
-            return L
-    L.shk_classify_device_submit.restype = C.c_int
-    L.shk_classify_device_submit.argtypes = [p, C.POINTER(ShkBatch), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
-    L.shk_dist_unique_id.restype = C.c_int; L.shk_dist_unique_id.argtypes = [p]
-    L.shk_dist_init.restype = C.c_int; L.shk_dist_init.argtypes = [p, p, C.c_int, C.c_int]
-    L.shk_dist_gene_counts_allreduce.restype = C.c_int; L.shk_dist_gene_counts_allreduce.argtypes = [p, p, C.c_uint32]
-    L.shk_dist_info.restype = C.c_int; L.shk_dist_info.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.shk_measure_random_lookups.restype = C.c_int
-    L.shk_measure_random_lookups.argtypes = [p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
-    L.shk_measure_valu_mix.restype = C.c_int
-    L.shk_measure_valu_mix.argtypes = [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
-    if hasattr(L, "shk_measure_valu_mix_clock"):      # (absent from older variant libraries, see above)
-        L.shk_measure_valu_mix_clock.restype = C.c_int
-        L.shk_measure_valu_mix_clock.argtypes = [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    # The later entry points, prototype by prototype: a library variant named by SHK_LIB_PATH (A/B timing, tools/build_variant.sh) may
+    # come from an older tree and lack some of them -- such a name is set to None ("not callable") and every name that exists gets its
+    # prototype, so that no call ever goes through ctypes' default int conversion.  The product library is checked symbol by symbol
+    # in tests/test_cabi_cpu.py; without SHK_LIB_PATH a missing symbol is an error here as well.
+    later = {
+        "shk_classify_device_submit": (C.c_int, [p, C.POINTER(ShkBatch), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+        "shk_dist_unique_id": (C.c_int, [p]),
+        "shk_dist_init": (C.c_int, [p, p, C.c_int, C.c_int]),
+        "shk_dist_gene_counts_allreduce": (C.c_int, [p, p, C.c_uint32]),
+        "shk_dist_info": (C.c_int, [p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "shk_measure_random_lookups": (C.c_int, [p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+        "shk_measure_valu_mix": (C.c_int, [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "shk_measure_valu_mix_clock": (C.c_int, [p, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    }
+    variant = bool(os.environ.get("SHK_LIB_PATH"))
+    for name, (res, args) in later.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        elif variant:
+            setattr(L, name, None)
+        else:
+            raise SharkHipError("libsharkhip.so lacks %s: rebuild it (make -C shark_amd/csrc)" % name)
     _lib = L
     return L
 

@@ -1,37 +1,56 @@
 // anchor_verdict.hip -- anchor_verdict_kernel: the pairs a reference base-for-base comparison settles, settled in FRONT of
-// classify_uni_kernel's table instantiations, three pairs per wavefront pass (round 6).
+// classify_uni_kernel's table instantiations, six pairs per wavefront pass (round 6).
 //
 // What it replaces.  ReadAnalyzer::operator() (ReadAnalyzer.hpp:39-110) looks every k-mer of a read up (bloomfilter.h:78-102) and
 // votes.  For a pair drawn from ONE gene's own sequence nearly all of that is foregone: its k-mers are the reference's k-mers at
-// neighbouring positions, and the index knows, per reference position, how far around it every k-mer answers with one and the same
-// single-gene list {g} (DeviceIndex::refext).  classify_uni_kernel's anchored extension uses the reference that way per slot (sample
-// -> anchor -> per-slot payloads -> match-bit windows -> vote: ~570 VALU + 350 scalar instructions per pair, three dependent memory
-// round trips per pair and wave).  This kernel keeps only what the verdict needs:
-//   * a lane holds 16 bases of one mate (a chunk); 10 lanes a 150-bp mate, 20 a pair, THREE pairs per wave pass;
-//   * the k-mer that starts at a chunk's first base is one more look at the neighbouring lane's bases -- so every chunk lane samples
-//     one k-mer (hash, bucket of `atab`: "is it in the index, and where in the reference") in the SAME instructions;
-//   * the first sampled k-mer of a mate that is in the index anchors the mate: every chunk lane of the mate compares its 16 bases
-//     with the 16 reference bases they stand against (one xor) and counts the bases that disagree or are invalid characters;
-//   * `refext` at the anchor says whether every slot of the mate falls on positions that answer {g}, same g for both mates.
-// THE VERDICT (the early decision's argument, classify_uni.hpp `vote`, made on counts): a base that disagrees lies in at most k
-// slots, so with e such bases at least n = nk1 + nk2 - e k slots hold k-mers EQUAL to the reference's -- equal filter positions,
-// hence hits of g and of g alone -- covering at least n + k - 1 bases (the union of [p, p + k) holds every p and k - 1 more bases);
-// every other slot -- the only ones another gene's list can sit under -- lies within k - 1 bases of a disagreeing base: together
-// they cover at most e (2 k - 1) bases.  n + k - 1 >= ceil(c len) and n + k - 1 > e (2 k - 1) therefore make g the pair's one
-// association (ReadAnalyzer.hpp:90-108) whatever the other probes would say: count = 1, gene g, exactly what the vote writes.
-// (2 x 150 bp, k = 17, c = 0.6: up to five disagreeing bases.)  A pair that does not pass is simply left alone -- count[] stays 0 --
-// and classify_uni_kernel, launched behind this kernel with `pre_verdict` set, skips the pairs that have their result.
-// Nothing is assumed: a chance anchor, a repeat, an indel, another gene's mate all show as disagreeing bases or uncovered extents.
+// neighbouring positions, and the index knows, per reference position, the gene of the record it lies in and whether the list under
+// its k-mer is that gene alone (DeviceIndex::refext, refmul).  classify_uni_kernel's anchored extension uses the reference that way
+// per slot (sample -> anchor -> per-slot payloads -> match-bit windows -> vote: ~570 VALU + 350 scalar instructions per pair, three
+// dependent memory round trips per pair and wave).  This kernel keeps only what the verdict needs:
+//   * a lane holds 32 bases of one mate (a chunk) as 2-bit codes in a register pair; 5 lanes a 150-bp mate, 10 a pair, SIX pairs per
+//     wave pass -- everything below is done once per pass, for six pairs at a time;
+//   * the k-mer that starts at a chunk's first base lies inside the chunk (k <= 31) -- so a chunk lane samples one k-mer (hash,
+//     bucket of `atab`: "is it in the index, and where in the reference") without looking anywhere else;
+//   * the first sampled k-mer of a mate that is in the index anchors the mate: every chunk lane of the mate compares its 32 bases
+//     with the 32 reference bases they stand against (one 64-bit xor): one bit per base, "agrees and is a valid character";
+//   * `refext` at the anchor says whether every slot of the mate falls on positions of g's record that start a valid k-mer (same
+//     g for both mates), `refmul` which of those positions carry a list of several genes.
+// THE VERDICT (the early decision's argument, classify_uni.hpp `vote`, made on bit masks).  A slot whose k bases all agree with the
+// reference holds the reference's k-mer at that position: equal k-mers, equal filter positions (bloomfilter.h:87-88), hence exactly
+// that position's list.  Where that list is {g} alone the slot is a hit of g and of no other gene -- a MATCHED slot.  Every other
+// existing slot -- a disagreeing or invalid base in its window, a list of several genes under it -- is OPEN: nothing is assumed
+// about it.  g's coverage is then at least the bases the matched slots cover (the union of their [p, p + k), counted per mate as
+// the vote counts it), any other gene's at most the bases the open slots cover.  matched >= ceil(c len) and matched > open make
+// g the pair's one association (ReadAnalyzer.hpp:90-108) whatever a probe of the open slots would say: count = 1, gene g, exactly
+// what the vote writes.  A pair that does not pass is simply left alone -- count[] stays 0 -- and the kernel launched behind this one
+// with `pre_verdict` set passes over the pairs that have their result.  A chance anchor, a repeat, an indel, another gene's mate
+// all show as disagreeing bases or as positions outside the anchor's run: such pairs do not pass.
 #include "classify_common.hpp"
 
 namespace shk {
 
 constexpr int AV_WAVES = 4;            // waves per workgroup
-constexpr uint32_t AV_PASSES = 8;      // consecutive passes (groups of up to three pairs) a wave takes
+constexpr uint32_t AV_PASSES = 6;      // consecutive passes (groups of up to six pairs) a wave takes
+constexpr uint32_t AV_PPW = 6;         // pairs per pass at most
 
-struct AvRaw { uint32_t d0, d1, d2, d3, d4, sh; };
+struct AvRaw { uint32_t d[9]; uint32_t sh; };
 
-// uniform batches (one length per mate), pairs of at most 64 chunks of 16 bases.  POW2: the filter size is a power of two
+// 2-bit groups of a dword in reverse order
+__device__ __forceinline__ uint32_t av_rev2(const uint32_t v)
+{
+  const uint32_t r = __builtin_bitreverse32(v);
+  return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+// 16 x 2 bits -> 16 bits: bit i = both bits of group i set ... of `a`, where a has bit 2 i set iff group i qualifies
+__device__ __forceinline__ uint32_t av_squeeze(uint32_t e)
+{
+  e = (e | (e >> 1)) & 0x33333333u;
+  e = (e | (e >> 2)) & 0x0F0F0F0Fu;
+  e = (e | (e >> 4)) & 0x00FF00FFu;
+  return (e | (e >> 8)) & 0xFFFFu;
+}
+
+// uniform batches (one length per mate), pairs of at most 64 chunks of 32 bases.  POW2: the filter size is a power of two
 template <bool POW2, bool HASQ>
 __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const ClassifyParams P)
 {
@@ -44,9 +63,9 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   L1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L1);
   L2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L2);
   const uint32_t k = P.k;
-  const uint32_t c1 = (L1 + 15u) >> 4, c2 = (L2 + 15u) >> 4, lp = c1 + c2;   // chunks per mate, lanes per pair
+  const uint32_t c1 = (L1 + 31u) >> 5, c2 = (L2 + 31u) >> 5, lp = c1 + c2;   // chunks per mate, lanes per pair
   if (lp == 0u || lp > 64u) return;
-  const uint32_t ppw = 64u / lp < 3u ? 64u / lp : 3u;                        // pairs per pass
+  const uint32_t ppw = 64u / lp < AV_PPW ? 64u / lp : AV_PPW;                // pairs per pass
   const uint32_t nk1 = L1 >= k ? L1 - k + 1u : 0u, nk2 = L2 >= k ? L2 - k + 1u : 0u, nks = nk1 + nk2;
   const uint32_t thr = cov_threshold(P.c, L1 + L2);   // (a pair with invalid characters has a lower threshold: passing this one is sufficient)
   if (nks == 0u || thr == 0u) return;
@@ -61,27 +80,34 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   // ---- lane geometry: pair of the pass, chunk of the pair, mate ----
   const uint32_t ln = (uint32_t)lane;
   const bool act = ln < ppw * lp;
-  const uint32_t pr = act ? (ln >= lp ? 1u : 0u) + (ln >= 2u * lp ? 1u : 0u) : 0u;
+  uint32_t pr = 0u;
+  for (uint32_t j = 1u; j < AV_PPW; ++j) pr += (act && ln >= j * lp) ? 1u : 0u;
   const uint32_t cl = act ? ln - pr * lp : 0u;
   const bool in2 = cl >= c1;
   const uint32_t cm = in2 ? cl - c1 : cl;                 // chunk of the mate
-  const uint32_t bofs = cm << 4;                          // its first base (mate coordinates)
+  const uint32_t bofs = cm << 5;                          // its first base (mate coordinates)
   const uint32_t Lm = in2 ? L2 : L1, nkm = in2 ? nk2 : nk1;
-  const uint32_t nb = act ? (Lm - bofs < 16u ? Lm - bofs : 16u) : 0u;       // bases of the mate in the chunk (>= 1 for an active lane)
-  const uint32_t tail = nb < 16u ? (0xFFFFu << nb) & 0xFFFFu : 0u;
-  const bool has_kmer = act && bofs + k <= Lm;            // a k-mer starts at the chunk's first base
-  // (a probe is a memory-side request on every index whose table has outgrown an XCD's L2, and their rate is what this kernel waits
-  //  for: every third chunk is sampled -- slots 0, 48, 96 of a 150-bp mate; all three miss with 1 % errors once in 150 mates)
-  const bool sampled = has_kmer && cm % 3u == 0u;
+  const uint32_t nb = act ? (Lm - bofs < 32u ? Lm - bofs : 32u) : 0u;       // bases of the mate in the chunk (>= 1 for an active lane)
+  const uint32_t tail = nb < 32u ? 0xFFFFFFFFu << nb : 0u;
+  const bool has_kmer = act && bofs + k <= Lm;            // a k-mer starts at the chunk's first base (and ends inside the chunk: k <= 31)
+  // (a probe is a memory-side request on every index whose table has outgrown an XCD's L2: every other chunk is sampled -- slots 0,
+  //  64, 128 of a 150-bp mate; all three hold an error, at 1 % per base, once in 150 mates)
+  const uint32_t nkc = Lm >= k ? ((Lm - k) >> 5) + 1u : 0u;   // chunks of the mate at whose first base a k-mer starts
+  const bool sampled = has_kmer && (nkc <= 3u || (cm & 1u) == 0u);
   const uint32_t fm = pr * lp + (in2 ? c1 : 0u);          // first lane of my mate
   const uint32_t cmn = in2 ? c2 : c1;                     // its lanes
   const uint32_t f1 = pr * lp + (nk1 ? 0u : c1);          // first lane of the pair's first mate that has slots
   const uint64_t pair_mask = (lp < 64u ? (1ull << lp) - 1ull : ~0ull) << (pr * lp);
+  // the pair's field in the packed sums (pairs 0-2 in one word, 3-5 in another): ten bits while a pair has at most 21 lanes (672
+  // bases), fifteen for the longer pairs, of which a pass holds two at most
+  const uint32_t fbits = ppw > 2u ? 10u : 15u, fsh = fbits * (pr % 3u), fmask = (1u << fbits) - 1u;
+  const bool hi3 = pr >= 3u;
   const uint8_t *sb = (in2 ? P.seq2 : P.seq1) + bofs;
   const uint8_t *qb = HASQ ? (in2 ? P.qual2 : P.qual1) + bofs : nullptr;
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;   // (k <= 31)
+  const uint32_t kbits = (1u << k) - 1u;
   const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
-  const uint32_t guard = Lmin ? (19u + Lmin - 1u) / Lmin : 0u;   // an unguarded fetch reads up to 19 bytes from the chunk's first: the last reads take the guarded form
+  const uint32_t guard = Lmin ? (35u + Lmin - 1u) / Lmin : 0u;   // an unguarded fetch reads up to 35 bytes from the chunk's first: the last reads take the guarded form
   const uint32_t pmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
   const uint32_t pspare = 1u << P.tab_lg;
   const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
@@ -89,7 +115,10 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   const uint32_t ref_total = P.ref_total;
 
   auto issue = [&](const uint8_t *base, const uint32_t gg) -> AvRaw {
-    AvRaw r{0u, 0u, 0u, 0u, 0u, 0u};
+    AvRaw r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.d[i] = 0u;
+    r.sh = 0u;
     const uint32_t rd = ppw * gg + pr;
     if (act && rd < n_reads) {
       const uint8_t *sp = base + (uint64_t)rd * Lm;
@@ -97,62 +126,60 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
       const uint32_t *q = reinterpret_cast<const uint32_t *>(sp - sh);
       r.sh = sh;
       if (n_reads - rd > guard) {
-        r.d0 = q[0]; r.d1 = q[1]; r.d2 = q[2]; r.d3 = q[3]; r.d4 = q[4];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.d[i] = q[i];
       } else {
-        const uint32_t last = sh + nb - 1u;              // index of the last wanted byte relative to q
-        r.d0 = q[0];
-        r.d1 = last >= 4u ? q[1] : 0u;
-        r.d2 = last >= 8u ? q[2] : 0u;
-        r.d3 = last >= 12u ? q[3] : 0u;
-        r.d4 = last >= 16u ? q[4] : 0u;
+        const uint32_t last = sh + nb - 1u;              // index of the last wanted byte relative to q: only dwords that hold a byte of the mate are touched
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.d[i] = last >= 4u * (uint32_t)i ? q[i] : 0u;
       }
     }
     return r;
   };
-  AvRaw cur = issue(sb, g), qcur{0u, 0u, 0u, 0u, 0u, 0u};
+  // 32 bytes -> their 2-bit codes (first base LOW: classify_uni.hpp's `fw` stream) and one bit per byte: not one of ACGTacgt
+  auto codes_of = [&](const AvRaw &r, uint64_t &code, uint32_t &inv) {
+    uint32_t msb[2] = {0u, 0u};
+    inv = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t b = __builtin_amdgcn_alignbyte(r.d[i + 1], r.d[i], r.sh);
+      uint32_t c4, i4;
+      classify4(b, c4, i4);
+      msb[i >> 2] |= pack4(c4) << (24 - 8 * (i & 3));      // first base in bits 31:30
+      inv |= gather4(i4) << (4 * i);
+    }
+    code = ((uint64_t)av_rev2(msb[1]) << 32) | av_rev2(msb[0]);
+  };
+  auto qmask_of = [&](const AvRaw &r) -> uint32_t {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m |= gather4(qmask4(__builtin_amdgcn_alignbyte(r.d[i + 1], r.d[i], r.sh), P.mq)) << (4 * i);   // FastqSplitter.hpp:104-109
+    return m;
+  };
+  AvRaw cur = issue(sb, g), qcur;
   if (HASQ) qcur = issue(qb, g);
   for (; g < g_end; ++g) {
-    AvRaw nxt{0u, 0u, 0u, 0u, 0u, 0u}, qnxt{0u, 0u, 0u, 0u, 0u, 0u};
+    AvRaw nxt, qnxt;
     if (g + 1u < g_end) {
       nxt = issue(sb, g + 1u);
       if (HASQ) qnxt = issue(qb, g + 1u);
+    } else {
+      nxt = cur;
+      if (HASQ) qnxt = qcur;
     }
     const uint32_t rd = ppw * g + pr;
     const bool live = act && rd < n_reads;
-    // ---- the chunk's 16 bases as 2-bit codes, first base LOW (classify_uni.hpp's `fw` stream), and which of them are invalid ----
-    uint32_t code, inv16;
-    {
-      const uint32_t b0 = __builtin_amdgcn_alignbyte(cur.d1, cur.d0, cur.sh), b1 = __builtin_amdgcn_alignbyte(cur.d2, cur.d1, cur.sh);
-      const uint32_t b2 = __builtin_amdgcn_alignbyte(cur.d3, cur.d2, cur.sh), b3 = __builtin_amdgcn_alignbyte(cur.d4, cur.d3, cur.sh);
-      uint32_t e0, e1, e2, e3, i0, i1, i2, i3;
-      classify4(b0, e0, i0);
-      classify4(b1, e1, i1);
-      classify4(b2, e2, i2);
-      classify4(b3, e3, i3);
-      const uint32_t msb32 = (pack4(e0) << 24) | (pack4(e1) << 16) | (pack4(e2) << 8) | pack4(e3);      // first base in bits 31:30
-      inv16 = gather4(i0) | (gather4(i1) << 4) | (gather4(i2) << 8) | (gather4(i3) << 12) | tail;
-      if (HASQ) {
-        const uint32_t q0 = __builtin_amdgcn_alignbyte(qcur.d1, qcur.d0, qcur.sh), q1 = __builtin_amdgcn_alignbyte(qcur.d2, qcur.d1, qcur.sh);
-        const uint32_t q2 = __builtin_amdgcn_alignbyte(qcur.d3, qcur.d2, qcur.sh), q3 = __builtin_amdgcn_alignbyte(qcur.d4, qcur.d3, qcur.sh);
-        inv16 |= gather4(qmask4(q0, P.mq)) | (gather4(qmask4(q1, P.mq)) << 4) | (gather4(qmask4(q2, P.mq)) << 8) | (gather4(qmask4(q3, P.mq)) << 12);   // FastqSplitter.hpp:104-109
-      }
-      code = __builtin_bitreverse32(msb32);
-      code = ((code >> 1) & 0x55555555u) | ((code & 0x55555555u) << 1);
-      if (!live) inv16 = 0xFFFFu;
-    }
-    // ---- the k-mer that starts at the chunk's first base: this chunk's bases and the next chunk's first k - 16 ----
-    const uint32_t nx_code = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((ln + 1u) & 63u) << 2), (int)code);
-    const uint32_t nx_inv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((ln + 1u) & 63u) << 2), (int)inv16);
-    const uint64_t x = (((uint64_t)nx_code << 32) | code) & kmer_mask;        // first base low: ~x is the reverse complement (kmer_utils.hpp:47-55)
-    const uint32_t own_need = k >= 16u ? 0xFFFFu : (1u << k) - 1u, nx_need = k > 16u ? (1u << (k - 16u)) - 1u : 0u;
-    const bool kvalid = has_kmer && ((inv16 & own_need) | (nx_inv & nx_need)) == 0u;
-    uint64_t fwd;                                                              // the k-mer as kmer_utils.hpp:67-69 packs it: first base most significant
-    {
-      uint32_t lo = __builtin_bitreverse32((uint32_t)(x >> 32)), hi = __builtin_bitreverse32((uint32_t)x);
-      lo = ((lo >> 1) & 0x55555555u) | ((lo & 0x55555555u) << 1);
-      hi = ((hi >> 1) & 0x55555555u) | ((hi & 0x55555555u) << 1);
-      fwd = (((uint64_t)hi << 32) | lo) >> (64u - 2u * k);
-    }
+    // ---- the chunk's 32 bases as 2-bit codes, and which of them are invalid (N, a masked quality, behind the mate's end) ----
+    uint64_t code;
+    uint32_t inv;
+    codes_of(cur, code, inv);
+    inv |= tail;
+    if (HASQ) inv |= qmask_of(qcur);
+    if (!live) inv = 0xFFFFFFFFu;
+    // ---- the k-mer that starts at the chunk's first base ----
+    const uint64_t x = code & kmer_mask;                                       // first base low: ~x is the reverse complement (kmer_utils.hpp:47-55)
+    const bool kvalid = has_kmer && (inv & kbits) == 0u;
+    const uint64_t fwd = (((uint64_t)av_rev2((uint32_t)x) << 32) | av_rev2((uint32_t)(x >> 32))) >> (64u - 2u * k);   // first base most significant (kmer_utils.hpp:67-69)
     const uint64_t rc = ~x & kmer_mask;
     const bool isrc = !(fwd < rc);                                             // canonical = min (KmerBuilder.hpp:49, ReadAnalyzer.hpp:55)
     const uint64_t hsh = xxh64_u64(isrc ? rc : fwd);
@@ -177,30 +204,68 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
     const bool have = act && nkm != 0u && mine != 0ull;
     const uint32_t src = fm + (have ? (uint32_t)__builtin_ctzll(mine) : 0u);
     const uint32_t a_src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)a);
-    const uint32_t x0 = a_src & 0x7FFFFFFFu, s0 = (src - fm) << 4;             // reference position and slot (mate coordinates) of the anchor
+    const uint32_t x0 = a_src & 0x7FFFFFFFu, s0 = (src - fm) << 5;             // reference position and slot (mate coordinates) of the anchor
     const bool opp = (a_src >> 31) != 0u;
-    // ---- what the reference says there: the anchor's surroundings, and the 16 bases this chunk stands against ----
+    // ---- what the reference says there: the anchor's run, the 32 bases this chunk stands against, the lists under its 32 slots ----
     // (the base at mate position b stands against reference base x0 - s0 + b, or, on the other strand, against the complement of base
-    //  x0 + s0 + k - 1 - b: classify_uni.hpp, anchored extension (3))
+    //  x0 + s0 + k - 1 - b; slot b on position x0 - s0 + b, or x0 + s0 - b: classify_uni.hpp, anchored extension (3))
     const uint32_t ev = have ? P.refext[x0] : REFEXT_NONE;
-    const uint32_t lo = opp ? x0 + s0 + k - 16u - bofs : x0 + bofs - s0;       // (mod 2^32: a chunk that would leave the reference fails the bound)
+    const uint32_t lo = opp ? x0 + s0 + k - 32u - bofs : x0 + bofs - s0;       // (mod 2^32: a chunk that would leave the reference fails the bound)
     const bool inr = have && lo < ref_total;
     const uint32_t ls = inr ? lo : 0u;
-    const uint32_t g0 = P.ref2[ls >> 4], g1 = P.ref2[(ls >> 4) + 1u];
-    uint32_t G = __builtin_amdgcn_alignbit(g1, g0, (ls & 15u) << 1);
-    if (opp) {   // the other strand: base order reversed (2-bit groups), complemented
-      G = __builtin_bitreverse32(G);
-      G = ~(((G >> 1) & 0x55555555u) | ((G & 0x55555555u) << 1));
+    const uint32_t r0 = P.ref2[ls >> 4], r1 = P.ref2[(ls >> 4) + 1u], r2 = P.ref2[(ls >> 4) + 2u];
+    const uint32_t w = opp ? x0 + s0 - bofs - 31u : x0 + bofs - s0;
+    const bool inw = have && w < ref_total;
+    const uint32_t wd = inw ? w : 0u;
+    const uint32_t f0 = P.refmul[wd >> 5], f1w = P.refmul[(wd >> 5) + 1u];
+    uint32_t ok32;                                                             // bases that agree with the reference and are valid characters
+    {
+      uint32_t Glo = __builtin_amdgcn_alignbit(r1, r0, (ls & 15u) << 1), Ghi = __builtin_amdgcn_alignbit(r2, r1, (ls & 15u) << 1);
+      if (opp) {   // the other strand: base order reversed (2-bit groups), complemented
+        const uint32_t t = ~av_rev2(Ghi);
+        Ghi = ~av_rev2(Glo);
+        Glo = t;
+      }
+      const uint32_t dl = (uint32_t)code ^ Glo, dh = (uint32_t)(code >> 32) ^ Ghi;
+      const uint32_t e32 = av_squeeze(~(dl | (dl >> 1)) & 0x55555555u) | (av_squeeze(~(dh | (dh >> 1)) & 0x55555555u) << 16);
+      ok32 = inr ? (e32 & ~inv) : 0u;
     }
-    const uint32_t df = code ^ G;
-    uint32_t e = ~(df | (df >> 1)) & 0x55555555u;                              // bit 2 i: base i agrees
-    e = (e | (e >> 1)) & 0x33333333u;
-    e = (e | (e >> 2)) & 0x0F0F0F0Fu;
-    e = (e | (e >> 4)) & 0x00FF00FFu;
-    e = (e | (e >> 8)) & 0xFFFFu;
-    const uint32_t ok16 = inr ? (e & ~inv16) : 0u;                             // (inv16 holds the bases behind the mate's end as well)
-    const uint32_t mis = (live && nkm != 0u) ? nb - (uint32_t)__builtin_popcount(ok16) : 0u;
-    // every slot of the mate on a position that answers with the anchor's single-gene list?  (slots [0, nkm) <-> positions
+    // ---- which of the chunk's 32 slots (the k-mers that START at its bases) equal the reference's k-mer: k agreeing bases in a row,
+    // i.e. the agreement bits of this chunk and of the next one (k <= 31), eroded by k ----
+    uint32_t eq32;
+    {
+      const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((ln + 1u) & 63u) << 2), (int)ok32);
+      uint64_t E = (uint64_t)ok32 | ((uint64_t)(cm + 1u < cmn ? n1 : 0u) << 32);
+      uint32_t len = 1u;
+      while (2u * len <= k) { E &= E >> len; len <<= 1; }
+      if (len < k) E &= E >> (k - len);
+      eq32 = (uint32_t)E;
+    }
+    // the lists under those 32 positions: 1 = not a single-gene list
+    uint32_t fo32 = 0xFFFFFFFFu;
+    {
+      uint32_t F = __builtin_amdgcn_alignbit(f1w, f0, wd & 31u);               // bit j: position w + j
+      if (opp) F = __builtin_bitreverse32(F);
+      if (inw) fo32 = F;
+    }
+    const uint32_t nex = nkm > bofs ? nkm - bofs : 0u;                        // slots of the mate that start in this chunk
+    const uint32_t ex32 = (live && nex != 0u) ? (nex >= 32u ? 0xFFFFFFFFu : (1u << nex) - 1u) : 0u;
+    const uint32_t m32 = eq32 & ex32 & ~fo32;                                  // matched: g's, and g's alone
+    const uint32_t o32 = ex32 & ~m32;                                          // open
+    // ---- bases of this chunk that the matched / the open slots cover: slots of this chunk and of the one in front, dilated by k ----
+    uint32_t covm, covo;
+    {
+      const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((ln + 63u) & 63u) << 2), (int)m32);
+      const uint32_t po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((ln + 63u) & 63u) << 2), (int)o32);
+      uint64_t DM = (uint64_t)(cm >= 1u ? pm : 0u) | ((uint64_t)m32 << 32);
+      uint64_t DO = (uint64_t)(cm >= 1u ? po : 0u) | ((uint64_t)o32 << 32);
+      uint32_t len = 1u;
+      while (2u * len <= k) { DM |= DM << len; DO |= DO << len; len <<= 1; }
+      if (len < k) { DM |= DM << (k - len); DO |= DO << (k - len); }
+      covm = (uint32_t)__builtin_popcount((uint32_t)(DM >> 32) & ~tail);
+      covo = (uint32_t)__builtin_popcount((uint32_t)(DO >> 32) & ~tail);
+    }
+    // every slot of the mate on a position of the anchor's run (valid k-mer starts of one record)?  (slots [0, nkm) <-> positions
     // x0 - s0 ... x0 - s0 + nkm - 1, or mirrored)
     const uint32_t before = s0, after = nkm - 1u - s0, left = (ev >> 16) & 0xFFu, right = ev >> 24;
     bool okm = nkm == 0u || (have && ev != REFEXT_NONE && (opp ? (right >= before) & (left >= after) : (left >= before) & (right >= after)));
@@ -208,10 +273,15 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
     const uint32_t gene1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(f1 << 2), (int)gene);
     okm = okm && (nkm == 0u || gene == gene1);
     const uint64_t BAD = __ballot(live && !okm);
-    const uint32_t tot = wave_sum_u32(mis << (10u * pr));                      // (three fields of ten bits: at most 64 x 16 per pair)
-    const uint32_t e_mis = (tot >> (10u * pr)) & 1023u, killed = e_mis * k;
-    const uint32_t cov_lb = nks - killed + k - 1u;
-    const bool pass = (BAD & pair_mask) == 0ull && killed < nks && cov_lb >= thr && cov_lb > e_mis * (2u * k - 1u);
+    // per pair: the bases its matched / open slots cover, summed over its lanes in packed fields (three pairs a word)
+    const uint32_t sm_lo = wave_sum_u32(hi3 ? 0u : covm << fsh), so_lo = wave_sum_u32(hi3 ? 0u : covo << fsh);
+    uint32_t sm_hi = 0u, so_hi = 0u;
+    if (ppw > 3u) {   // (wave-uniform)
+      sm_hi = wave_sum_u32(hi3 ? covm << fsh : 0u);
+      so_hi = wave_sum_u32(hi3 ? covo << fsh : 0u);
+    }
+    const uint32_t cov_m = ((hi3 ? sm_hi : sm_lo) >> fsh) & fmask, cov_o = ((hi3 ? so_hi : so_lo) >> fsh) & fmask;
+    const bool pass = (BAD & pair_mask) == 0ull && cov_m >= thr && cov_m > cov_o;
     if (live && cl == 0u && pass) {
       const ClassifyOut *O = P.out;
       O->count[rd] = 1u;
@@ -228,18 +298,18 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
 // does the kernel apply to uniform batches of these lengths?  (lengths only the device knows: it decides itself)
 bool anchor_verdict_applies(const ClassifyParams &p)
 {
-  if (!p.ref_total || !p.refext || !p.atab || !p.ref2 || p.n == 0 || p.n >= (1ull << 32)) return false;
+  if (!p.ref_total || !p.refext || !p.refmul || !p.atab || !p.ref2 || p.n == 0 || p.n >= (1ull << 32)) return false;
   if (p.uni_flag) return true;
-  const uint32_t lp = ((p.uni_L1 + 15u) >> 4) + ((p.seq2 ? p.uni_L2 : 0u) + 15u) / 16u;
+  const uint32_t lp = ((p.uni_L1 + 31u) >> 5) + (((p.seq2 ? p.uni_L2 : 0u) + 31u) >> 5);
   return lp != 0u && lp <= 64u;
 }
 
 int launch_anchor_verdict(const ClassifyParams &p, bool pow2, hipStream_t s)
 {
   // (lengths only the device knows: a pass may hold one pair only -- the grid is sized for that, waves without work return at once)
-  const uint32_t lp = p.uni_flag ? 0u : ((p.uni_L1 + 15u) >> 4) + ((p.seq2 ? p.uni_L2 : 0u) + 15u) / 16u;
-  const uint64_t ppw = p.uni_flag ? 1u : (64u / lp < 3u ? 64u / lp : 3u);
-  const uint64_t n_pass = p.uni_flag ? p.n : (p.n + ppw - 1) / ppw;
+  const uint32_t lp = p.uni_flag ? 0u : ((p.uni_L1 + 31u) >> 5) + (((p.seq2 ? p.uni_L2 : 0u) + 31u) >> 5);
+  const uint64_t ppw = p.uni_flag ? 1u : (64u / lp < AV_PPW ? 64u / lp : AV_PPW);
+  const uint64_t n_pass = (p.n + ppw - 1) / ppw;
   const uint64_t waves = (n_pass + AV_PASSES - 1) / AV_PASSES;
   const unsigned grid = (unsigned)((waves + AV_WAVES - 1) / AV_WAVES);
   const bool hasq = p.hasq != 0;

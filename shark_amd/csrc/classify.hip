@@ -1272,15 +1272,13 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
                     (ctx->env_tile_first > 0 || (ctx->last.last_n_reads != 0 && (double)ctx->last.last_n_assoc >= 0.25 * (double)ctx->last.last_n_reads))) ? 1u : 0u;
   }
   // The pairs a base-for-base comparison with the reference settles, settled in front of the table kernel (anchor_verdict.hip): uniform
-  // batches on an index that carries the reference arrays, while the anchored extension is on (above).  The table kernel then skips
-  // the reads that have their result, and its own verdict by mismatch count (classify_uni.hpp (2b)) is left to the batches this
-  // kernel does not take (SHK_NO_PRE_VERDICT=1: never)
+  // batches on an index that carries the reference arrays, while the anchored extension is on (above); also in front of the 128 KiB
+  // LDS summary's kernel.  The kernel behind it passes over the reads that have their result (SHK_NO_PRE_VERDICT=1: never)
   bool pre = false;
   if (rmode == 1 && (!pm_lds(mode) || big) && !ctx->env_no_pre_verdict && anchor_verdict_applies(p)) {
     if (int rc = launch_anchor_verdict(p, ctx->idx.pow2, stream)) return rc;
     pre = true;
     p.pre_verdict = 1u;
-    p.refext = nullptr;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU
   const int min_waves = wg16 ? 4 : ((u > 8 || (u > 5 && !pm_lds(mode))) ? 4 : (u > 5 ? 6 : (pm_lds(mode) ? SHK_UNI_WAVES : (mode == PM_KTAB ? SHK_KT_WAVES : SHK_TAB_WAVES))));   // (= UniGeom::MIN_WAVES)
@@ -1300,9 +1298,9 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   if (rmode == 2) return SHK_OK;             // (shk_last_kernel names the uniform / ragged launch)
   // (with p.uni_flag both instantiations are launched and one returns at once: the name says UNI = "device")
   if (uni || !p.uni_flag)
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s%s%s", u, mode, hasq ? "true" : "false",
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s%s", u, mode, hasq ? "true" : "false",
              (lx && (u <= 5 || u == 10)) ? 21 : ((big && (u <= 5 || u == 10)) ? 20 : 18), p.uni_flag ? "device" : (uni ? "true" : "false"),
-             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "", (!pm_lds(mode) && p.ref_total && p.refext) ? " +mismatch-verdict" : "", pre ? " +pre-verdict" : "",
+             (!pm_lds(mode) && p.ref_total) ? " +anchored-extension" : "", pre ? " +pre-verdict" : "",
              (lx && p.lx_gene != 0xFFFFFFFFu) ? " +sparse-first-round" : ((lx && p.lx_multi) ? " +sparse-first-rounds" : ""));
   if (lx && p.tri && (uni || !p.uni_flag) && (p.uni_flag || tri_applies_host(p.uni_L1, p.uni_L2, p.k, 64u * u))) {
     const size_t l = strlen(ctx->last_kernel);
@@ -1400,6 +1398,24 @@ int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const
   const uint64_t want = h_gene_off ? (n_off / 4 + 255) / 256 : 1;
   hipLaunchKernelGGL(publish_results_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 512 ? want : 512))), dim3(256), 0, stream, counters, h_counters,
                      gene_off, h_gene_off, n_off, gene_ids, h_gene_ids, h_ids_cap, uni_flag);
+  return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
+}
+
+// shk_classify_device_submit takes the caller's word for "every read of mate m has length L_m": the kernels then never read an
+// offset.  One thread looks at three offsets per mate (first, middle, last: r L_m each); what it finds goes to the host with the
+// batch's counters and shk_classify_wait refuses the batch (SHK_ERR_ARG) instead of handing out results of reads cut at the wrong places.
+__global__ void vouch_check_kernel(const uint64_t *__restrict__ off1, const uint64_t *__restrict__ off2, uint64_t n, uint32_t L1, uint32_t L2,
+                                   uint32_t *__restrict__ counters)
+{
+  const uint64_t h = n / 2;
+  bool bad = off1[0] != 0ull || off1[h] != h * L1 || off1[n] != n * L1;
+  if (off2) bad = bad || off2[0] != 0ull || off2[h] != h * L2 || off2[n] != n * L2;
+  if (bad) counters[CTR_VOUCH_BAD] = 1u;
+}
+
+int launch_vouch_check(const ClassifyParams &p, uint32_t L1, uint32_t L2, uint32_t *counters, hipStream_t stream)
+{
+  hipLaunchKernelGGL(vouch_check_kernel, dim3(1), dim3(1), 0, stream, p.off1, p.seq2 ? p.off2 : nullptr, p.n, L1, L2, counters);
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

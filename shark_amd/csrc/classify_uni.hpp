@@ -300,11 +300,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
-    if (DYN && threadIdx.x == 0) *dyn_ctr = 2u * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave)
+    if (DYN && threadIdx.x == 0) *dyn_ctr = (UNI && !CLS && !LX && P.pre_verdict) ? (uint32_t)WAVES : 2u * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave; of blocks -- see BM below --, the first)
     if (DYNC && threadIdx.x == 0) *dyn_ctr = (uint32_t)WAVES;   // (its first share)
     __syncthreads();
   } else if (DYN) {
-    if (threadIdx.x == 0) *dyn_ctr = 2u * WAVES;
+    if (threadIdx.x == 0) *dyn_ctr = (UNI && !CLS && !LX && P.pre_verdict) ? (uint32_t)WAVES : 2u * WAVES;
     __syncthreads();
   }
   const uint32_t *lsum = reinterpret_cast<const uint32_t *>(lds);
@@ -505,23 +505,29 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // (with the pointer it measured 4.25 -> 4.40 ms)
   constexpr bool RUNPTR = !LX && !DYN;   // (a wave that takes turns has no fixed step)
   const uint8_t *snext[G], *qnext[G];
-  uint32_t sstep[G];
+  uint32_t r_at = blockIdx.x * WAVES + wave;   // the read the running pointers stand at
   {
-    const uint32_t r0 = blockIdx.x * WAVES + wave;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const uint64_t o = (uint64_t)r0 * Lm[g];
+      const uint64_t o = (uint64_t)r_at * Lm[g];
       snext[g] = sbase[g] + o;
       qnext[g] = HASQ ? qbase[g] + o : nullptr;
-      sstep[g] = stride * Lm[g];   // (< 2^23: at most 8 192 waves, reads of at most 1 024 bases)
     }
   }
-  // (fetches the read the pointers stand at -- r, for the guard -- and moves them on)
+  // (moves the running pointers on to read r -- `stride` reads further, or, where reads that have their result are passed over, as
+  //  many as it takes -- and fetches it)
   auto issue = [&](const uint32_t r, Raw8 (&w)[G], Raw8 (&q)[G]) {
+    const uint32_t r_step = r - r_at;
+    if (RUNPTR) r_at = r;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       w[g] = Raw8{0u, 0u, 0u, 0u};
       q[g] = Raw8{0u, 0u, 0u, 0u};
+      if (RUNPTR) {
+        const uint64_t d = (uint64_t)r_step * Lm[g];
+        snext[g] += d;
+        if (HASQ) qnext[g] += d;
+      }
       if (act[g]) {
         const uint64_t o = RUNPTR ? 0ull : (uint64_t)r * Lm[g];
         const uint8_t *sp = RUNPTR ? snext[g] : sbase[g] + o;
@@ -534,10 +540,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           w[g] = load8_issue(sp, rem);
           if (HASQ) q[g] = load8_issue(qp, rem);
         }
-      }
-      if (RUNPTR) {
-        snext[g] += sstep[g];
-        if (HASQ) qnext[g] += sstep[g];
       }
     }
   };
@@ -656,16 +658,50 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   auto plan_issue = [&](const ReadMeta &m) -> uint4 { return has_plans ? P.plan_tab[plan_index(m)] : make_uint4(0u, 0u, 0u, 0u); };
   uint4 pl_cur = make_uint4(0u, 0u, 0u, 0u);
   // PRE (uniform batches beyond the exact-table instantiations): anchor_verdict_kernel may have run in front of this launch
-  // (P.pre_verdict): a read whose count[] is set has its result already and is passed over -- its flag is fetched with its bases
+  // (P.pre_verdict): a read whose count[] is set has its result already.  The batch is then walked in BLOCKS of 64 consecutive reads --
+  // a wave's sequence of positions (fixed steps, or turns) is a sequence of blocks --: one coalesced load brings a block's 64 flags,
+  // fetched a block ahead, a ballot says which of its reads are left, and only those are ever fetched, staged or waited for.
+  // (Passing over a settled read inside the usual loop cost its prefetch's round trip: 1.2 ms per 10 M pairs at 100 % on-target.)
   constexpr bool PRE = UNI && !CLS && !LX;
   const uint32_t *pre_count = nullptr;
-  uint32_t done_cur = 0u;
   if (PRE && P.pre_verdict) pre_count = P.out->count;
-  auto pre_fetch = [&](const uint32_t r) -> uint32_t {
-    const uint32_t *cp = pre_count + r;
-    asm volatile("" : "+v"(cp));   // (a vector load: a scalar one would share lgkmcnt with the LDS accesses of the read at hand)
-    return *cp;
+  const bool BM = PRE && pre_count != nullptr;
+  const uint32_t n_blk = (n_reads + 63u) >> 6;
+  uint32_t bm_pos = 0u, bm_pn = 0u, bm_fn = 1u;   // the block at hand, the next one of the wave's sequence and (per lane) its flags
+  uint64_t bm_bits = 0ull;                          // reads of the block at hand that are left behind the current one
+  // the position behind `cur` in the wave's sequence of blocks (n_blk: none)
+  auto bm_next_pos = [&](const uint32_t cur) -> uint32_t {
+    if (DYN) {
+      uint32_t t = 0u;
+      if (lane == 0) t = atomicAdd(dyn_ctr, 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      const uint64_t v = (uint64_t)(t / (uint32_t)WAVES) * stride + (blockIdx.x * WAVES + t % (uint32_t)WAVES);
+      return v < n_blk ? (uint32_t)v : n_blk;
+    }
+    return n_blk - cur > stride ? cur + stride : n_blk;
   };
+  // (per lane) 0: read 64 pos + lane is left to do
+  auto bm_flags = [&](const uint32_t pos) -> uint32_t {
+    const uint32_t r = (pos << 6) + (uint32_t)lane;
+    return (pos < n_blk && r < n_reads) ? pre_count[r] : 1u;
+  };
+  if (BM) {
+    bm_pos = it;                                     // (the wave's first position, as a block)
+    if (bm_pos >= n_blk) return;
+    uint64_t m = __ballot(bm_flags(bm_pos) == 0u);
+    bm_pn = bm_next_pos(bm_pos);
+    bm_fn = bm_flags(bm_pn);
+    while (m == 0ull) {
+      if (bm_pn >= n_blk) return;
+      bm_pos = bm_pn;
+      m = __ballot(bm_fn == 0u);
+      bm_pn = bm_next_pos(bm_pos);
+      bm_fn = bm_flags(bm_pn);
+    }
+    it = (bm_pos << 6) + (uint32_t)__builtin_ctzll(m);
+    bm_bits = m & (m - 1ull);
+    read = it;
+  }
   if (CLS) {
     entry_fetch(it, w_cur, q_cur);
     read = read_nxt;
@@ -674,7 +710,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     tri_retire(t_cur);
   } else if (UNI) {
     issue(read, w_cur, q_cur);
-    if (PRE && pre_count) done_cur = pre_fetch(read);
   } else {
     m_cur = fetch_meta(P, read);
     fetch_groups(m_cur, w_cur, q_cur);
@@ -724,7 +759,26 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   }
   for (;;) {
     uint32_t nxt;
-    if (DYN) nxt = dyn_pos(dyn_q);
+    if (BM) {
+      // the next read that is left: of the block at hand, else of the next block of the wave's sequence that has one
+      nxt = n32;
+      if (bm_bits) {
+        nxt = (bm_pos << 6) + (uint32_t)__builtin_ctzll(bm_bits);
+        bm_bits &= bm_bits - 1ull;
+      } else {
+        while (bm_pn < n_blk) {
+          const uint64_t m = __ballot(bm_fn == 0u);
+          bm_pos = bm_pn;
+          bm_pn = bm_next_pos(bm_pos);
+          bm_fn = bm_flags(bm_pn);
+          if (m) {
+            nxt = (bm_pos << 6) + (uint32_t)__builtin_ctzll(m);
+            bm_bits = m & (m - 1ull);
+            break;
+          }
+        }
+      }
+    } else if (DYN) nxt = dyn_pos(dyn_q);
     else nxt = n32 - it > stride ? it + stride : n32;   // saturates at n32
     const bool have_nxt = nxt < n32;
     Raw8 w_nxt[G], q_nxt[G];
@@ -748,14 +802,11 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     // (DYN) the turn after the next: asked for here, behind the next one's loads, wanted at the end of this pass
     uint32_t dyn_take = 0u;
-    if (DYN) {
+    if (DYN && !BM) {
       if (lane == 0) dyn_take = atomicAdd(dyn_ctr, 1u);
     }
-    uint32_t done_nxt = 0u;
-    if (PRE && pre_count && have_nxt) done_nxt = pre_fetch(nxt);
     SHK_STAMP(0);
     bool skip = false;
-    if (PRE && __builtin_amdgcn_readfirstlane((int)done_cur) != 0) skip = true;
     if (!UNI) {
       const uint32_t ns = nk2 ? ((m_cur.L1 + 7u) & ~7u) + nk2 : nk1;
       // longer than the batch's layout (FIXLAY) / this specialisation holds: the general kernel's queue (as process_read does)
@@ -1588,50 +1639,21 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       // lies in the reference (64 slots of a round read 256 contiguous bytes), so that these loads and the reference bases below
       // are one memory round trip, not two
       uint32_t inb_mask = 0u, okv_mask = 0u;
-      auto request_payloads = [&]() {
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const uint32_t pp = (uint32_t)lane + 64u * j;
-          const bool in2 = (pp - P2) < nk2;
-          const bool okv = slot_valid(pp);
-          const bool have = in2 ? ahave[1] : ahave[0];
-          const bool opp = in2 ? aopp[1] : aopp[0];
-          const uint32_t x0 = in2 ? ax[1] : ax[0];
-          const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
-          const uint32_t xr = opp ? x0 - dd : x0 + dd;               // where the slot's k-mer starts in the reference
-          const bool inb = okv & have & (xr < ref_total);
-          slo[j] = refpay[inb ? xr : 0u];
-          inb_mask |= inb ? (1u << j) : 0u;
-          okv_mask |= okv ? (1u << j) : 0u;
-        }
-      };
-      // (2b) THE VERDICT BY MISMATCH COUNT (round 6; `refext`, shark_internal.hpp).  refext[x] says how far around x the reference's
-      // k-mers answer with ONE single-gene list {g}.  If every slot of every mate falls on such a position (both anchors' extents
-      // cover their mates, same g), then each slot whose k bases agree with the reference is a hit of g and of g alone -- equal k-mers
-      // have equal filter positions, as in (3) -- whichever slots those are.  With e = the bases of the pair that do NOT agree (or are
-      // invalid characters): a disagreeing base lies in at most k slots, so at least n = nk1 + nk2 - e k slots are g's alone, and they
-      // cover at least n + k - 1 bases (the union of [p, p + k) contains every p and k - 1 bases behind the last); the other slots --
-      // the only ones another gene's list can sit under -- cover at most 2 k - 1 bases per disagreeing base.  n + k - 1 >= c len and
-      // n + k - 1 > e (2 k - 1) therefore make g the pair's only association (ReadAnalyzer.hpp:90-108), by the early decision's own
-      // argument -- without a payload, a match-bit window or a vote per slot: 2 x 150 bp, k = 17, c = 0.6 passes up to e = 5.
-      // Everything else goes on as before, its payloads requested one round trip later.
-      bool mc_try = false;
-      uint32_t mc_gene = 0u;
-      if (const uint32_t *refext = H->refext; refext != nullptr && thr_r != 0u && (nk1 | nk2) != 0u && (nk1 == 0u || ahave[0]) && (nk2 == 0u || ahave[1])) {
-        // (wave-uniform addresses: one request each)
-        const uint32_t x1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refext[nk1 ? ax[0] : ax[1]]);
-        const uint32_t x2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refext[nk2 ? ax[1] : ax[0]]);
-        auto covers = [&](const uint32_t ev, const uint32_t before, const uint32_t after, const bool opp) -> bool {
-          const uint32_t left = (ev >> 16) & 0xFFu, right = ev >> 24;
-          return ev != REFEXT_NONE && (opp ? (right >= before) & (left >= after) : (left >= before) & (right >= after));
-        };
-        const bool ok1 = nk1 == 0u || covers(x1, as0[0], nk1 - 1u - as0[0], aopp[0]);
-        const bool ok2 = nk2 == 0u || covers(x2, as0[1] - P2, P2 + nk2 - 1u - as0[1], aopp[1]);
-        mc_try = ok1 && ok2 && ((x1 ^ x2) & 0xFFFFu) == 0u;
-        mc_gene = x1 & 0xFFFFu;
+      for (int j = 0; j < U; ++j) {
+        const uint32_t pp = (uint32_t)lane + 64u * j;
+        const bool in2 = (pp - P2) < nk2;
+        const bool okv = slot_valid(pp);
+        const bool have = in2 ? ahave[1] : ahave[0];
+        const bool opp = in2 ? aopp[1] : aopp[0];
+        const uint32_t x0 = in2 ? ax[1] : ax[0];
+        const uint32_t dd = pp - (in2 ? as0[1] : as0[0]);          // (modulo 2^32: out-of-range positions fail the bound below)
+        const uint32_t xr = opp ? x0 - dd : x0 + dd;               // where the slot's k-mer starts in the reference
+        const bool inb = okv & have & (xr < ref_total);
+        slo[j] = refpay[inb ? xr : 0u];
+        inb_mask |= inb ? (1u << j) : 0u;
+        okv_mask |= okv ? (1u << j) : 0u;
       }
-      if (!mc_try) request_payloads();
-      uint32_t mc_mis = 0u;
       {
         const uint32_t *ref2 = H->ref2;
         const uint32_t m = (uint32_t)lane >> 5, c16 = ((uint32_t)lane & 31u) << 4;
@@ -1660,16 +1682,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         e = (e | (e >> 4)) & 0x00FF00FFu;
         e = (e | (e >> 8)) & 0xFFFFu;
         const uint32_t M16 = inr ? (e & ((1u << n_in) - 1u)) : 0u;
-        if (mc_try) {
-          // bases of the chunk that do not agree with the reference, or are no valid character (N, a masked quality)
-          uint32_t ok16 = M16;
-          if (any_inv) {
-            const uint8_t *vb = reinterpret_cast<const uint8_t *>(vbits);
-            const uint32_t byv = n_in ? (b0 >> 3) : 0u;
-            ok16 &= (uint32_t)vb[byv] | ((uint32_t)vb[byv + 1u] << 8);
-          }
-          mc_mis = n_in - (uint32_t)__builtin_popcount(ok16);
-        }
         // bytes 2 c and 2 c + 1 of the mate's part of the stream (mate 2 starts at byte P2 / 8; mate 1's last chunk may reach past it:
         // those bytes are mate 2's).  Bytes behind the mate are cleared as far as the stream goes: no stale bit of an earlier read
         constexpr uint32_t MBYTES = vbit_words_for(S) * 8u;
@@ -1677,27 +1689,6 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         const uint32_t by = b0 >> 3, end = m ? MBYTES : (P2 >> 3);
         if (by < end) mb[by] = (uint8_t)M16;
         if (by + 1u < end) mb[by + 1u] = (uint8_t)(M16 >> 8);
-      }
-      if (mc_try) {
-        const uint32_t e_mis = wave_sum_u32(mc_mis), nks = nk1 + nk2, killed = e_mis * k;
-        if (killed < nks) {
-          const uint32_t cov_lb = nks - killed + k - 1u;
-          if (cov_lb >= thr_r && cov_lb > e_mis * (2u * k - 1u)) {
-            if (lane == 0 && !SHK_ABL(P, 64u)) {
-              const ClassifyOut *O = H->out;
-              O->count[read] = 1u;
-              uint2 pk;
-              pk.x = mc_gene;
-              pk.y = 0u;
-              *reinterpret_cast<uint2 *>(O->inl + (uint64_t)read * SHK_INLINE_IDS) = pk;
-#ifdef SHK_ANCH_STATS
-              atomicAdd(&O->counters[CTR_UNUSED3], 1u);
-#endif
-            }
-            return true;
-          }
-        }
-        request_payloads();
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -2036,8 +2027,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       pl_cur = pl_nxt;
     }
     it = nxt;
-    if (PRE) done_cur = done_nxt;
-    if (DYN) dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
+    if (DYN && !BM) dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
     read = CLS ? read_nxt : it;
 #pragma unroll
     for (int g = 0; g < G; ++g) { w_cur[g] = w_nxt[g]; q_cur[g] = q_nxt[g]; }

@@ -341,22 +341,51 @@ __global__ __launch_bounds__(256) void ref_multi_write_kernel(uint32_t *__restri
   ent[n_set + 1 + x] = out;
 }
 
-// What the anchored extension's early verdict needs to know about the surroundings of an anchor (DeviceIndex::refext).  Position x
-// whose k-mer answers with the single-gene list {g}: g | left << 16 | right << 24, where left / right count the positions directly
-// in front of / behind x whose k-mers answer with the SAME single-gene list (clipped at REFEXT_CLIP); REFEXT_NONE where no valid k-mer
-// starts or its list has several genes.  A mate anchored at x whose slots all fall on positions within those extents needs no
-// per-slot payload: every k-mer of it that equals the reference's is g's alone.  One thread per position, neighbours from refpay
-// (a run of equal payloads is walked by every thread inside it: 2 x 254 coalesced, cache-resident loads at most).
+// What anchor_verdict_kernel needs to know about the surroundings of an anchor (DeviceIndex::refext, refmul).
+// refext[x], x a position where a valid k-mer starts: g | left << 16 | right << 24 -- g = the gene of x's RECORD, left / right = how
+// many positions directly in front of / behind x start a valid k-mer too (clipped at REFEXT_CLIP).  Such a run never leaves its
+// record (k >= 2: the last k - 1 positions of a record start no k-mer), so the list under every k-mer of the run contains g; g is
+// read off the nearest position of the run whose list is {g} alone (a single-gene list under a k-mer of g's record is {g}).
+// REFEXT_NONE: no valid k-mer starts at x, or no single-gene list within reach.
+// One thread per position, neighbours from refpay (2 x 254 coalesced, cache-resident loads at most).
 __global__ __launch_bounds__(256) void ref_extent_kernel(const uint32_t *__restrict__ refpay, uint64_t total, uint32_t *__restrict__ refext)
 {
   const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= total) return;
   const uint32_t v = refpay[x];
-  if (v == REFPAY_NONE || (v >> 31) != 0u || v > 0xFFFFu) { refext[x] = REFEXT_NONE; return; }
-  uint32_t left = 0, right = 0;
-  while (left < REFEXT_CLIP && x > left && refpay[x - 1 - left] == v) ++left;
-  while (right < REFEXT_CLIP && x + 1 + right < total && refpay[x + 1 + right] == v) ++right;
-  refext[x] = v | (left << 16) | (right << 24);
+  if (v == REFPAY_NONE) { refext[x] = REFEXT_NONE; return; }
+  constexpr uint32_t NF = 0xFFFFFFFFu;
+  auto single = [](const uint32_t u) { return (u >> 31) == 0u && u <= 0xFFFFu; };
+  uint32_t gene = single(v) ? v : NF, left = 0, right = 0;
+  while (left < REFEXT_CLIP && x > left) {
+    const uint32_t u = refpay[x - 1 - left];
+    if (u == REFPAY_NONE) break;
+    if (gene == NF && single(u)) gene = u;
+    ++left;
+  }
+  while (right < REFEXT_CLIP && x + 1 + right < total) {
+    const uint32_t u = refpay[x + 1 + right];
+    if (u == REFPAY_NONE) break;
+    if (gene == NF && single(u)) gene = u;
+    ++right;
+  }
+  refext[x] = gene == NF ? REFEXT_NONE : (gene | (left << 16) | (right << 24));
+}
+
+// refmul: one bit per position, 32 positions per dword, LSB first: 1 = the list under the k-mer that starts there is NOT a single-gene
+// list (several genes -- a stretch that genes share, or a collision in the filter --, or no valid k-mer at all); positions behind the
+// reference read as 1.  One thread per dword.
+__global__ __launch_bounds__(256) void ref_multi_bits_kernel(const uint32_t *__restrict__ refpay, uint64_t total, uint32_t *__restrict__ refmul, uint64_t n_dwords)
+{
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_dwords) return;
+  uint32_t v = 0;
+  for (uint32_t j = 0; j < 32; ++j) {
+    const uint64_t x = (w << 5) + j;
+    const uint32_t u = x < total ? refpay[x] : REFPAY_NONE;
+    v |= ((u >> 31) != 0u || u > 0xFFFFu ? 1u : 0u) << j;
+  }
+  refmul[w] = v;
 }
 
 // ---- the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab) ----
@@ -687,8 +716,8 @@ int build_index(Ctx *ctx)
           ListEntry *ent_all = nullptr;
           uint16_t *ids_all = nullptr;
           auto drop_anchor = [&]() {
-            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.atab); (void)hipFree(ix.refext);
-            ix.ref2 = ix.refpay = ix.refext = nullptr;
+            (void)hipFree(ix.ref2); (void)hipFree(ix.refpay); (void)hipFree(ix.atab); (void)hipFree(ix.refext); (void)hipFree(ix.refmul);
+            ix.ref2 = ix.refpay = ix.refext = ix.refmul = nullptr;
             ix.atab = nullptr;
             ix.ref_total = 0;
           };
@@ -750,19 +779,24 @@ int build_index(Ctx *ctx)
             AX_HIP(hipStreamSynchronize(st));
             return true;
           }();
-          // the surroundings of every anchor (ref_extent_kernel), for the anchored extension's verdict by mismatch count; optional by
-          // itself (SHK_NO_REFEXT=1: not built; the tests run both)
+          // the surroundings of every anchor (ref_extent_kernel, ref_multi_bits_kernel), for anchor_verdict_kernel; optional by
+          // itself (SHK_NO_REFEXT=1: not built; the tests run both).  k = 1: runs of valid positions do not end with their record
           if (ix.refext) { (void)hipFree(ix.refext); ix.refext = nullptr; }
-          if (have && !getenv("SHK_NO_REFEXT")) {
+          if (ix.refmul) { (void)hipFree(ix.refmul); ix.refmul = nullptr; }
+          if (have && k >= 2 && !getenv("SHK_NO_REFEXT")) {
+            const uint64_t n_mw = (total + 31) / 32 + 2;
             const bool ok = [&]() -> bool {
               AX_HIP(hipMalloc((void **)&ix.refext, (total + 8) * sizeof(uint32_t)));
+              AX_HIP(hipMalloc((void **)&ix.refmul, n_mw * sizeof(uint32_t)));
               AX_HIP(hipMemsetAsync(ix.refext + total, 0xFF, 8 * sizeof(uint32_t), st));
               hipLaunchKernelGGL(ref_extent_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const uint32_t *)ix.refpay, total, ix.refext);
+              AX_HIP(hipGetLastError());
+              hipLaunchKernelGGL(ref_multi_bits_kernel, dim3(grid_for(n_mw, 256)), dim3(256), 0, st, (const uint32_t *)ix.refpay, total, ix.refmul, n_mw);
               AX_HIP(hipGetLastError());
               AX_HIP(hipStreamSynchronize(st));
               return true;
             }();
-            if (!ok) { (void)hipFree(ix.refext); ix.refext = nullptr; }
+            if (!ok) { (void)hipFree(ix.refext); (void)hipFree(ix.refmul); ix.refext = ix.refmul = nullptr; }
           }
 #undef AX_HIP
           (void)hipGetLastError();   // (nothing that failed above is an error of the build)

@@ -27,7 +27,7 @@ int set_hip_error(Ctx *ctx, hipError_t e, const char *what)
 
 static void free_index(DeviceIndex &ix)
 {
-  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.refext); hipFree(ix.atab); hipFree(ix.ktab);
+  hipFree(ix.bf64); hipFree(ix.rank_w); hipFree(ix.ent); hipFree(ix.ids); hipFree(ix.sum32); hipFree(ix.tab); hipFree(ix.lsum32); hipFree(ix.lbig32); hipFree(ix.ltab); hipFree(ix.ref2); hipFree(ix.refpay); hipFree(ix.refext); hipFree(ix.refmul); hipFree(ix.atab); hipFree(ix.ktab);
   ix = DeviceIndex{};
 }
 
@@ -151,7 +151,7 @@ static void fill_params(Ctx *ctx, Slot &s, const shk_batch *b)
   p.tab_nt = ix.tab_lg && (16ull << ix.tab_lg) > (256ull << 20);   // beyond L2 + Infinity Cache
   p.lsum32 = ix.lsum_shift ? ix.lsum32 : nullptr; p.lsum_shift = ix.lsum_shift;
   p.lx_gene = 0xFFFFFFFFu;   // (launch_classify_uni sets it when it chooses the exact LDS table)
-  p.ref2 = ix.ref2; p.refpay = ix.refpay; p.atab = ix.atab; p.ref_total = ix.ref_total; p.refext = ix.refext;
+  p.ref2 = ix.ref2; p.refpay = ix.refpay; p.atab = ix.atab; p.ref_total = ix.ref_total; p.refext = ix.refext; p.refmul = ix.refmul;
   p.ktab = ix.ktab_lg ? ix.ktab : nullptr; p.ktab_lg = ix.ktab_lg; p.ktab_w = ix.ktab_w;
   // (far beyond the caches: streaming loads -- 17.8 / 18.1 -> 16.7 / 17.3 ms per 10 M pairs at 0 / 50 % on-target on the 60 000-gene index)
   p.ktab_nt = (ix.ktab_lg && (16ull << ix.ktab_lg) > (256ull << 20) && !ctx->env_ktab_plain) || ctx->env_ktab_nt ? 1u : 0u;
@@ -373,6 +373,8 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
       // the one length per mate (UNI_YES), or the longest mates: the ragged instantiation stages the batch in their layout
       s.p.uni_L1 = uni_L1;
       s.p.uni_L2 = uni_L2;
+      // (a resident batch whose caller vouched for the lengths: nobody has looked at its offsets)
+      if (uni_mode == UNI_YES && !s.host_batch && n != 0 && (rc = launch_vouch_check(s.p, uni_L1, uni_L2, s.d_counters, st))) return rc;
     }
     if (with_plans) SHK_HIP(ctx, hipMemsetAsync(s.d_plan, 0, classes * sizeof(uint4), st));
   }
@@ -892,7 +894,10 @@ int shk_classify_device_submit(shk_ctx *ctx, const shk_batch *b, uint32_t max_re
   const uint64_t n = b->n;
   if (n >= 0xFFFFFFFFull) { ctx->last_error = "batch too large (n must be < 2^32-1)"; return SHK_ERR_ARG; }
   const bool paired = b->seq2 != nullptr;
-  if (uniform_len1 > max_read_len || uniform_len2 > max_read_len || (!paired && uniform_len2)) return SHK_ERR_ARG;
+  if (uniform_len1 > max_read_len || uniform_len2 > max_read_len || (!paired && uniform_len2)) {
+    ctx->last_error = "uniform_len1 / uniform_len2 exceed max_read_len, or uniform_len2 given for a single-end batch";
+    return SHK_ERR_ARG;
+  }
   uint32_t max_slots = slots_for_len(max_read_len, ctx->prm.k, paired);
   // a bound beyond the largest specialisation: the device would have to be asked how many reads do not fit
   if (max_slots > fast_kernel_max_slots()) { ctx->last_error = "max_read_len beyond the kernels' specialisations: use shk_classify_device"; return SHK_ERR_ARG; }
@@ -921,6 +926,11 @@ int shk_classify_wait(shk_ctx *ctx, uint64_t ticket, shk_result *result)
   bool redone = false;
   int rc = finish_classify(ctx, s, s.long_speculative, true, &redone);
   if (rc) { s.waited = true; return rc; }
+  if (!s.host_batch && s.h_counters[CTR_VOUCH_BAD]) {
+    ctx->last_error = "uniform_len1 / uniform_len2 do not describe the batch: its offsets are not r * length (shk_classify_device_submit)";
+    s.waited = true;
+    return SHK_ERR_ARG;
+  }
   // (finish_classify re-ran the tail when it had to, and the tail publishes the results again)
   const uint64_t n = s.n;
   const uint64_t n_assoc = ((uint64_t)s.h_counters[CTR_ASSOC_HI] << 32) | s.h_counters[CTR_ASSOC_LO];

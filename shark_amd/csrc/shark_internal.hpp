@@ -85,10 +85,11 @@ struct DeviceIndex {
   //            reverse complement); 0xFFFFFFFF = unset.  Same buckets, same high words: the anchored extension's sample probes THIS
   //            table, and the bucket that says "the k-mer is in the index" says where in the reference in the same memory round trip
   //            (round 3 kept the occurrences in an array of their own, indexed by the slot that had matched: a dependent load)
-  //   refext : per base position x with a single-gene list {g} under its k-mer: g | left << 16 | right << 24 -- how many positions
-  //            directly in front of / behind x answer with the same list (clipped at REFEXT_CLIP); REFEXT_NONE elsewhere.  What the
-  //            anchored extension's verdict by mismatch count needs instead of a payload per slot (classify_uni.hpp)
-  uint32_t *ref2 = nullptr, *refpay = nullptr, *refext = nullptr;
+  //   refext : per base position x where a valid k-mer starts: g | left << 16 | right << 24 -- the gene of x's record and how many
+  //            positions directly in front of / behind x start a valid k-mer too (clipped at REFEXT_CLIP; such a run stays inside its
+  //            record); REFEXT_NONE elsewhere.  refmul: one bit per position, 1 = the list under its k-mer is not a single-gene
+  //            list.  What anchor_verdict_kernel reads instead of a payload per slot (anchor_verdict.hip)
+  uint32_t *ref2 = nullptr, *refpay = nullptr, *refext = nullptr, *refmul = nullptr;
   uint64_t *atab = nullptr;
   uint32_t ref_total = 0;    // bases in ref2 / entries in refpay; 0 = not built
   // ---- the index a third time, keyed by the K-MER and bucketed by its MINIMISER (k = 15 ... 17, tables beyond the caches) ----
@@ -167,7 +168,8 @@ struct ClassifyParams {
   const uint32_t *refpay;
   const uint64_t *atab;
   uint32_t ref_total;
-  const uint32_t *refext;    // DeviceIndex::refext; nullptr: no verdict by mismatch count
+  const uint32_t *refext;    // DeviceIndex::refext / refmul; nullptr: no anchor_verdict_kernel
+  const uint32_t *refmul;
   uint32_t pre_verdict;      // 1 = anchor_verdict_kernel ran in front of this launch: a read whose count[] is set has its result
   // the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab; classify_uni_kernel's PM_KTAB instantiations)
   const uint64_t *ktab;
@@ -222,6 +224,7 @@ enum {
   CTR_UNUSED3 = 3,
   CTR_MAX_SLOTS = 4, // max k-mer slots over queued long reads
   CTR_UNUSED5 = 5,
+  CTR_VOUCH_BAD = 5, // 1 = the caller of shk_classify_device_submit vouched for read lengths that the batch's offsets do not have (vouch_check_kernel)
   CTR_ASSOC_LO = 6,  // number of associations of the batch (the scan's total), 64 bits
   CTR_ASSOC_HI = 7,
   CTR_VERDICT = 8,   // (host copy only) 1 + uni_flag[0] of a batch the device looked at: 1 ragged, 2 uniform, 3 by classes; 0: the host knew
@@ -290,6 +293,7 @@ int launch_finalize_total(const uint64_t *total, uint32_t *counters, uint64_t ge
 int launch_gene_hist(const uint16_t *gene_ids, const uint32_t *counters, bool skip_if_long, unsigned long long *gene_counts, uint64_t n_reads, uint64_t n_genes,
                      hipStream_t stream);
 int launch_fill_offsets(uint64_t *off, uint64_t n_plus_1, uint64_t stride, hipStream_t stream);
+int launch_vouch_check(const ClassifyParams &p, uint32_t L1, uint32_t L2, uint32_t *counters, hipStream_t stream);
 int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const uint32_t *gene_off, uint32_t *h_gene_off, uint64_t n_off,
                            const uint16_t *gene_ids, uint16_t *h_gene_ids, uint64_t h_ids_cap, const uint32_t *uni_flag, hipStream_t stream);
 int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, int rmode, hipStream_t stream);   // 0 ragged, 1 uniform, 2 by classes (CLS)

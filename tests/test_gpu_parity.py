@@ -1033,6 +1033,20 @@ def test_device_resident_pipeline_submit_wait(oracle):
         assert np.array_equal(wg, gg) and np.array_equal(wi, gi), specs[i]
     allids = np.concatenate([w[1] for w in want])
     assert np.array_equal(h.gene_counts(32), np.bincount(allids, minlength=32)[:32].astype(np.uint64))
+    # a caller that vouches for lengths the batch does not have (a base too short: every access stays inside the buffers) gets the
+    # batch refused in wait -- the device compared three offsets per mate with r * length -- and a message, not results
+    t = keep[0]
+    bad = h.submit_device(1500, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=150,
+                          uniform_len1=150, uniform_len2=149)
+    with pytest.raises(SharkHipError, match="do not describe the batch"):
+        h.wait_device(bad)
+    ok = h.submit_device(1500, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=150,
+                         uniform_len1=150, uniform_len2=150)
+    r = h.wait_device(ok)
+    assert int(r.n_assoc) == len(want[0][1])
+    with pytest.raises(SharkHipError, match="exceed max_read_len"):
+        h.submit_device(1500, t["seq1"].data_ptr(), t["off1"].data_ptr(), t["seq2"].data_ptr(), t["off2"].data_ptr(), max_read_len=100,
+                        uniform_len1=150, uniform_len2=150)
 
 
 def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
@@ -1721,7 +1735,7 @@ def test_anchored_extension_reads(oracle, monkeypatch, env, L1, L2, k):
 
 
 # ---------------------------------------------------------------------------
-# the anchored extension's verdict by mismatch count (classify_uni.hpp (2b); DeviceIndex::refext)
+# anchor_verdict_kernel in front of the table kernels (anchor_verdict.hip; DeviceIndex::refext / refmul)
 # ---------------------------------------------------------------------------
 def _pairs_with_counted_mismatches(rng, genes, n, L1, L2, ragged, qual):
     """pairs cut from a gene with a CHOSEN number of disagreeing bases (0 ... 12 per pair: on both sides of what the verdict accepts
@@ -1784,10 +1798,12 @@ def _pairs_with_counted_mismatches(rng, genes, n, L1, L2, ragged, qual):
                                  {"SHK_NO_LDS_SUMMARY": "1", "SHK_NO_SUMMARY": "1", "BF": str(3 << 24)}])
 @pytest.mark.parametrize("L1,L2,k", [(150, 150, 17), (150, 150, 31), (100, 100, 16), (150, 0, 20), (76, 76, 11), (250, 250, 21), (300, 300, 17), (150, 12, 17)])
 def test_verdict_by_mismatch_count(oracle, monkeypatch, env, L1, L2, k):
-    """(2b) of the anchored extension: pairs whose anchors' surroundings answer with one single-gene list are decided from the
-    NUMBER of bases that disagree with the reference.  Pairs with 0 ... 12 such bases -- spread, clustered, at the ends, as N --,
-    thresholds on both sides of what their matched slots cover, references with shared halves (extents that end inside a read),
-    repeats inside a gene, mates of two genes: the oracle's result with `refext` and without it (SHK_NO_REFEXT=1 at build time)."""
+    """anchor_verdict_kernel: pairs that agree with the reference around their anchors are settled from bit masks -- which slots hold
+    the reference's own k-mer under a single-gene list, what those cover, what all other slots cover.  Pairs with 0 ... 12
+    disagreeing bases -- spread, clustered, at the ends, as N --, thresholds on both sides of what their matched slots cover,
+    references with shared halves (lists of several genes under part of a read), a repeat inside a gene, a gene whose start is
+    another's tail, mates of two genes, an insertion: the oracle's result with the kernel in front and without it
+    (SHK_NO_PRE_VERDICT=1; SHK_NO_REFEXT=1 at build time: the index does not carry its arrays)."""
     bf_bits = 1 << 26
     for name, v in env.items():
         if name == "BF":
@@ -1801,14 +1817,12 @@ def test_verdict_by_mismatch_count(oracle, monkeypatch, env, L1, L2, k):
     genes[6][700:700 + len(rep)] = rep
     genes[8] = np.concatenate([genes[8], genes[10][:400]])               # one gene's start is the tail of another
     monkeypatch.setenv("SHK_ANCHOR_ALWAYS", "1")
-    # "pre": anchor_verdict_kernel in front of the table kernel for uniform batches (trimmed ones: the table kernel's own verdict, (2b));
-    # "2b": no kernel in front, (2b) for every batch; "none": the index carries no `refext`
-    for how in ("pre", "2b", "none"):
+    for how in ("pre", "off", "none"):
         monkeypatch.delenv("SHK_NO_REFEXT", raising=False)
         monkeypatch.delenv("SHK_NO_PRE_VERDICT", raising=False)
         if how == "none":
             monkeypatch.setenv("SHK_NO_REFEXT", "1")
-        if how == "2b":
+        if how == "off":
             monkeypatch.setenv("SHK_NO_PRE_VERDICT", "1")
         for c, single, q in ((0.6, False, 0), (0.2, True, 0), (0.85, False, 0), (0.97, False, 0), (0.6, False, 20)):
             if how != "pre" and c != 0.6:
@@ -1820,9 +1834,7 @@ def test_verdict_by_mismatch_count(oracle, monkeypatch, env, L1, L2, k):
                 goff, _ = _compare_classify(o, h, batch)
                 assert goff[-1] > 0 or c > 0.9
                 if "classify_uni_kernel" in h.last_kernel():
-                    lk = h.last_kernel()
-                    assert ("+pre-verdict" in lk) == (how == "pre" and not ragged), lk
-                    assert ("+mismatch-verdict" in lk) == (how == "2b" or (how == "pre" and ragged)), lk
+                    assert ("+pre-verdict" in h.last_kernel()) == (how == "pre" and not ragged), h.last_kernel()
             h.close()
 
 
