@@ -75,7 +75,7 @@ CLK_GHZ = 2.4               # max clock; a wave64 VALU instruction issues over 2
 VALU_PEAK_GINST = N_SIMD * CLK_GHZ / 2.0   # 1228.8 G wave-instructions/s
 LAUNCH_PAIRS = 10_000_000
 L2_LINE_BYTES = 128         # a memory-side request of gfx950's L2 is a 128-byte line (MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B)
-KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]
+KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "anchor_verdict.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]
 # one rocprofv3 --pmc pass per entry (gfx950: 8 SQ slots; FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2)
 COUNTER_SETS = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],
@@ -87,6 +87,8 @@ COUNTER_SETS = [
 ]
 COUNTER_SETS_FULL = COUNTER_SETS + [["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM", "SQ_INSTS_VALU"]]
 WORKLOADS = ("configs1", "configs2", "configs4_uniform", "configs4_ends")
+CAL_TABLE_BYTES = 8 << 30    # the FETCH_SIZE calibration's table (far beyond the 256 MiB Infinity Cache) and its lookups
+CAL_LOOKUPS = 1 << 30
 
 
 _T0 = time.time()
@@ -244,8 +246,13 @@ def counter_child(args):
     for wv in (4, 8):
         ms, wi = hm.measure_valu_mix(wv, 2000)
         mix.append({"waves_per_simd": wv, "wave_iterations_timed_launch": wi, "warmup_wave_iterations": wi // 2000 * 64})
+    # the calibration of FETCH_SIZE for the position table's access pattern: random 16-byte lookups in an 8 GiB table -- a KNOWN number
+    # of lines, once with one read per line, once with a read in each 64-byte half of every line (shk_measure_random_lookups, bit 1)
+    cal = {"table_bytes": CAL_TABLE_BYTES, "lines": hm.random_lookups_made(CAL_LOOKUPS)}
+    for both in (False, True):
+        cal["G_lines_per_s_%s" % ("both_halves" if both else "one_read")] = round(hm.measure_random_lookups(CAL_TABLE_BYTES, CAL_LOOKUPS, True, both), 2)
     hm.close()
-    print(json.dumps({"counter_child": order, "valu_mix": mix}), flush=True)
+    print(json.dumps({"counter_child": order, "valu_mix": mix, "lookup_calibration": cal}), flush=True)
 
 
 def parse_counter_dir(d, order):
@@ -276,7 +283,7 @@ def parse_counter_dir(d, order):
                 calls.append(cur)
                 last_did = did
             continue
-        if cur is None or "classify_" not in kn or "classify_general" in kn:
+        if cur is None or not ("classify_" in kn or "anchor_verdict" in kn) or "classify_general" in kn:
             continue
         name = kn.split("(")[0].replace("void shk::", "")
         cur.setdefault(name, {})
@@ -291,7 +298,20 @@ def parse_counter_dir(d, order):
             continue
         last = mine[-1]
         kn = max(last, key=lambda k: max(last[k].values()) if last[k] else 0.0)
-        out[o["workload"]] = {"kernel": kn, "counters": last[kn]}
+        # a launch's work may be split over two kernels (anchor_verdict_kernel in front of the table kernel): their counters are added --
+        # the library's kernel time covers both --, the instantiations that return at once add next to nothing
+        tot = {}
+        for name, cs in last.items():
+            for cn, v in cs.items():
+                if cn == "GRBM_PASS_NS":
+                    continue
+                tot[cn] = tot.get(cn, 0.0) + v
+        if "GRBM_PASS_NS" in last[kn]:
+            tot["GRBM_GUI_ACTIVE"] = last[kn].get("GRBM_GUI_ACTIVE", 0.0)       # (the clock: of the dominant kernel alone)
+            tot["GRBM_PASS_NS"] = last[kn]["GRBM_PASS_NS"]
+        parts = {name: {cn: cs[cn] for cn in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "TCC_MISS_sum", "FETCH_SIZE") if cn in cs}
+                 for name, cs in last.items() if cs and max(cs.values()) > 0.01 * max(last[kn].values())}
+        out[o["workload"]] = {"kernel": kn, "counters": tot, "kernels": parts}
     return out
 
 
@@ -349,11 +369,12 @@ def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
                 notes.append("set %d timed out" % si)
                 continue
             pr = subprocess.CompletedProcess(cmd, pp.returncode, so, se)
-            order, mix = None, None
+            order, mix, cal = None, None, None
             for ln in pr.stdout.splitlines():
                 if ln.startswith('{"counter_child"'):
                     order = json.loads(ln)["counter_child"]
                     mix = json.loads(ln).get("valu_mix")
+                    cal = json.loads(ln).get("lookup_calibration")
             if pr.returncode != 0 or order is None:
                 notes.append("set %d failed (rc %d): %s" % (si, pr.returncode, (pr.stderr or "")[-300:].replace("\n", " | ")))
                 continue
@@ -365,10 +386,20 @@ def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
                     res.setdefault("valu_mix", {})
                     for i, m in enumerate(mix):
                         res["valu_mix"][str(m["waves_per_simd"])] = vals[2 * i + 1] / float(m["wave_iterations_timed_launch"])
+            if cal:
+                # random_lookup_kernel's dispatches in this pass: (warm-up, timed) x (one read per line, both halves)
+                lc = res.setdefault("lookup_calibration", dict(cal))
+                for cn in cset:
+                    vals = parse_kernel_counter(d, "random_lookup_kernel", cn)
+                    if len(vals) == 4:
+                        lc[cn + "_per_line_one_read"] = vals[1] / cal["lines"]
+                        lc[cn + "_per_line_both_halves"] = vals[3] / cal["lines"]
             for o in order:
                 w = o["workload"]
                 if w in got:
                     res[w].setdefault("kernel", got[w]["kernel"])
+                    for name, part in got[w].get("kernels", {}).items():
+                        res[w].setdefault("kernels", {}).setdefault(name, {}).update(part)
                     res[w].setdefault("kernel_reported_by_library", o["kernel"])
                     res[w].setdefault("n_assoc", o["n_assoc"])
                     for cn, v in got[w]["counters"].items():
@@ -378,7 +409,7 @@ def collect_counters(args, workloads, sets=None, keep_dir=None, timeout_s=420):
     finally:
         if not keep_dir:
             shutil.rmtree(base, ignore_errors=True)
-    res = {w: e for w, e in res.items() if len(e) > 1 or w == "valu_mix"}
+    res = {w: e for w, e in res.items() if len(e) > 1 or w in ("valu_mix", "lookup_calibration")}
     note = "live: rocprofv3 --pmc child passes of this run (%d sets, %.0f s)" % (len(sets or COUNTER_SETS), time.time() - t0)
     if notes:
         note += "; " + "; ".join(notes)
@@ -439,7 +470,33 @@ def instruction_part(e, n_pairs, kern_ms):
     return d
 
 
-def request_rate_roofline(e, kern_ms, ceiling, alg_bytes, in_bytes, out_bytes, n_pairs, w):
+def fetch_calibration(lc):
+    """the counter child's calibration lookups -> what a random 16-byte lookup behind the caches moves and what FETCH_SIZE says it
+    moves.  A KNOWN number of lines is read once with one 16-byte read per 128-byte line and once with a read in each 64-byte half:
+    if the second read is free (same rate, same FETCH_SIZE per line) a memory-side request brings the whole line, else half of one.
+    -> dict(bytes_per_request, fetch_size_factor, ...) or None when the pass did not deliver the counters"""
+    if not lc:
+        return None
+    f1, f2 = lc.get("FETCH_SIZE_per_line_one_read"), lc.get("FETCH_SIZE_per_line_both_halves")
+    g1, g2 = lc.get("G_lines_per_s_one_read"), lc.get("G_lines_per_s_both_halves")
+    if not f1 or not f2 or not g1 or not g2:
+        return None
+    f1b, f2b = f1 * 1024.0, f2 * 1024.0          # (FETCH_SIZE is reported in KB)
+    whole_line = g2 >= 0.8 * g1 and f2b <= 1.3 * f1b
+    bpr = 128 if whole_line else 64
+    out = {"table_bytes": lc.get("table_bytes"), "lines": lc.get("lines"),
+           "G_lines_per_s": {"one_read_per_line": g1, "a_read_in_each_half": g2},
+           "FETCH_SIZE_bytes_per_line": {"one_read_per_line": round(f1b, 2), "a_read_in_each_half": round(f2b, 2)},
+           "TCC_MISS_per_line": {"one_read_per_line": round(lc.get("TCC_MISS_sum_per_line_one_read", 0.0), 3),
+                                 "a_read_in_each_half": round(lc.get("TCC_MISS_sum_per_line_both_halves", 0.0), 3)},
+           "second_half_is_free": bool(whole_line), "bytes_per_request": bpr, "fetch_size_factor": round(bpr / f1b, 3),
+           "how": "shk_measure_random_lookups in the FETCH_SIZE / TCC counter passes of this run: %d random lines of an %d GiB table, 16 bytes read of each, "
+                  "then 16 bytes of each 64-byte half; a second half that costs neither time nor FETCH_SIZE means a request brings the 128-byte line, "
+                  "else a request is 64 bytes; fetch_size_factor = that / FETCH_SIZE per line" % (lc.get("lines", 0), (lc.get("table_bytes") or 0) >> 30)}
+    return out
+
+
+def request_rate_roofline(e, kern_ms, ceiling, alg_bytes, in_bytes, out_bytes, n_pairs, w, cal=None):
     """an index far beyond the caches: the classify kernel is bound by the RATE of random memory-side requests (one 128-byte line
     per 16-byte bucket).  achieved = L2 misses per second (counter pass), peak = shk_measure_random_lookups in this run."""
     t = kern_ms * 1e-3
@@ -454,18 +511,30 @@ def request_rate_roofline(e, kern_ms, ceiling, alg_bytes, in_bytes, out_bytes, n
             rl["note"] = "measured request rate %.1f G/s exceeds the ceiling measured in this run (%.1f G/s): frac capped at 1" % (a, ceiling)
         rl["memory_side_requests_per_launch"] = int(req)
         rl["requests_per_pair"] = round(req / n_pairs, 1)
-        rl["line_traffic_GBps"] = round(L2_LINE_BYTES * req / t / 1e9, 1)
-        rl["line_traffic_frac_of_hbm"] = round(L2_LINE_BYTES * req / t / 1e9 / HBM_PEAK_GBPS, 4)
+        bpr = cal["bytes_per_request"] if cal else L2_LINE_BYTES
+        rl["bytes_per_request"] = bpr
+        rl["line_traffic_GBps"] = round(bpr * req / t / 1e9, 1)
+        rl["line_traffic_frac_of_hbm"] = round(bpr * req / t / 1e9 / HBM_PEAK_GBPS, 4)
     if e:
         fb, wb = fetch_write_bytes(e)
         if fb is not None:
-            traffic = 2.0 * fb + (wb or 0.0)              # the guide's gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B
+            # FETCH_SIZE's factor for THIS access pattern -- random 16-byte lookups -- calibrated in this run on a known number of them
+            # (fetch_calibration); without the calibration the guide's factor for wide streaming reads (2) and a note
+            fac = cal["fetch_size_factor"] if cal else 2.0
+            traffic = fac * fb + (wb or 0.0)
             rl["traffic"] = int(traffic)
-            rl["traffic_how"] = "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section), per launch"
+            rl["traffic_how"] = ("%.3g x FETCH_SIZE + WRITE_SIZE per launch; the factor calibrated on random 16-byte lookups in this run (roofline.fetch_calibration)" % fac
+                                 if cal else "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md's factor for wide streaming reads: UNCALIBRATED for this pattern), per launch")
             rl["traffic_over_algorithmic"] = round(traffic / alg_bytes, 2)
             rl["traffic_GBps"] = round(traffic / t / 1e9, 1)
         rl["instructions"] = instruction_part(e, n_pairs, kern_ms)
         rl["kernel"] = e.get("kernel")
+        if e.get("kernels") and len(e["kernels"]) > 1:
+            # the launch's work is split over two kernels (anchor_verdict_kernel in front of the table kernel): the counters above are their sums
+            rl["kernels"] = {name: {cn: (round(v / n_pairs, 1) if cn != "FETCH_SIZE" else round(v * 1024.0)) for cn, v in part.items()} for name, part in e["kernels"].items()}
+            rl["kernels_what"] = "per kernel of the launch: VALU / SALU instructions and memory-side requests per pair, FETCH_SIZE in bytes per launch"
+        if cal:
+            rl["fetch_calibration"] = cal
     rl["hbm_compulsory"] = {"bytes": int(in_bytes + out_bytes), "in": int(in_bytes), "out": int(out_bytes), "GBps": round((in_bytes + out_bytes) / t / 1e9, 1),
                             "frac_of_hbm_peak": round((in_bytes + out_bytes) / t / 1e9 / HBM_PEAK_GBPS, 4),
                             "what": "input bases (+ qualities) + result bytes of one launch / kernel time / 8 TB/s: what any implementation has to move"}
@@ -501,7 +570,35 @@ def mem_budget_bytes(base):
     return int(0.45 * min(lim))
 
 
-def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
+def render_ssv(ridx, gids, nd):
+    """"r<nd digits>/1 gene<id>\n" per association (ReadOutput.hpp:43: mate 1's id, the gene's name), ids of any number of digits:
+    a fixed-width byte matrix with NUL where a leading digit is not printed, flattened without the NULs"""
+    import numpy as np
+    gi = gids.astype(np.int64)
+    txt = np.zeros((len(ridx), 1 + nd + 3 + 4 + 5 + 1), np.uint8)
+    txt[:, 0] = ord("r")
+    for d in range(nd):
+        txt[:, 1 + d] = ord("0") + (ridx // 10 ** (nd - 1 - d)) % 10
+    txt[:, 1 + nd:4 + nd] = np.frombuffer(b"/1 ", np.uint8)
+    txt[:, 4 + nd:8 + nd] = np.frombuffer(b"gene", np.uint8)
+    for d in range(5):
+        p10 = 10 ** (4 - d)
+        dig = (gi // p10) % 10
+        shown = (gi >= p10) | (d == 4)
+        txt[:, 8 + nd + d] = np.where(shown, ord("0") + dig, 0)
+    txt[:, 13 + nd] = 10
+    flat = txt.ravel()
+    return flat[flat != 0].tobytes()
+
+
+def cli_end_to_end(args, genes, dev, h, L, n_gpus=1, ots=None, only_small=False, with_gz=True, with_shared=True, extra_args=(), alternate=0, k=None):
+    """(see below)  ots: the on-target rates to run (default 0.02 and 0.50); only_small: one sample size; extra_args: more options of the
+    command (-b 8 for the configs[2] index); alternate: pairs per stretch of a sample whose stretches are drawn from the genes and from
+    elsewhere by turns (the on-target rate reads "alternating")."""
+    return _cli_end_to_end(args, genes, dev, h, L, n_gpus, ots, only_small, with_gz, with_shared, list(extra_args), alternate, k if k is not None else args.k)
+
+
+def _cli_end_to_end(args, genes, dev, h, L, n_gpus, ots, only_small, with_gz, with_shared, extra_args, alternate, k_opt):
     """`shark` (shark_amd/bin/shark, the reference's command line: main.cpp:83-240, README.md:47-52) on FASTQ files, run as a user runs
     it, wall time of the whole process taken from outside.  Two on-target rates (0.02: one gene against a whole sample; 0.50: the
     north-star read mix, where ReadOutput.hpp:37-50 writes half the sample out again) x two sample sizes (so the fixed costs --
@@ -527,10 +624,11 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
     big = args.cli_big_pairs
     while big > small and 2 * big * W * 1.55 > budget:
         big -= chunk
-    sizes = [small] + ([big] if big > small else [])
+    sizes = [small] + ([big] if big > small and not only_small else [])
     if 2 * small * W * 1.55 > budget:
         return {"skipped": "not enough room in %s for %d pairs (budget %d bytes)" % (base, small, budget)}
-    same_len_names = len(genes) <= 10
+    same_len_names = True          # (the ssv is always rendered and compared: render_ssv)
+    gen_chunk = alternate if alternate else chunk
     threads_list = [min(16 * n_gpus, host_threads())] if n_gpus > 1 else [min(12, host_threads())]
     td = tempfile.mkdtemp(dir=base)
     out = {"what": "shark_amd/bin/shark -r g.fa -1 r1.fq -2 r2.fq -o o1.fq -p o2.fq -t T%s > out.ssv on synthetic pairs 2x%d bp in %s (files written and read once "
@@ -541,22 +639,24 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
         with open(os.path.join(td, "g.fa"), "wb") as f:
             for gi, g in enumerate(genes):
                 f.write(b">gene%d\n" % gi + g.tobytes() + b"\n")
-        for ot in ([0.02] if n_gpus > 1 else [0.02, 0.50]):
+        for ot in (ots if ots is not None else ([0.02] if n_gpus > 1 else [0.02, 0.50])):
             t0 = time.time()
             n_big = sizes[-1]
+            ot_label = "alternating" if alternate else ot
             # the compressed leg (ordinary gzip -1 files, one member each: inflated in parallel in two passes, gzip_parallel.hpp) on the
             # first gz_n pairs of the 0.02 sample
-            gz_n = min(args.cli_gz_pairs, small) if (ot == 0.02 and n_gpus == 1 and shutil.which("gzip")) else 0
+            gz_n = min(args.cli_gz_pairs, small) if (with_gz and ot == 0.02 and n_gpus == 1 and shutil.which("gzip")) else 0
             gz_md5, gz_lines, gz_assoc_reads = None, 0, 0
-            log("  cli: generating %d pairs at on-target %.2f" % (n_big, ot))
+            log("  cli: generating %d pairs at on-target %s" % (n_big, ot_label))
             md5 = hashlib.md5()
             md5_at, lines_at, assoc_reads_at = {}, {}, {}
             lines = assoc_reads = 0
             f1 = open(os.path.join(td, "r1.fq"), "wb")
             f2 = open(os.path.join(td, "r2.fq"), "wb")
-            for c0 in range(0, n_big, chunk):
-                m_all = min(chunk, n_big - c0)
-                b = synth.make_pairs_device(m_all, genes, dev, seed=synth.SEED + 99 + c0 // chunk + int(ot * 1000), read_len=L, on_target=ot)
+            for c0 in range(0, n_big, gen_chunk):
+                m_all = min(gen_chunk, n_big - c0)
+                ot_c = (1.0 if (c0 // gen_chunk) % 2 == 0 else 0.0) if alternate else ot      # (alternating: a stretch from the genes, a stretch from elsewhere)
+                b = synth.make_pairs_device(m_all, genes, dev, seed=synth.SEED + 99 + c0 // gen_chunk + int(ot * 1000), read_len=L, on_target=ot_c)
                 torch.cuda.synchronize()
                 r = h.classify_device(m_all, b["seq1"].data_ptr(), b["off1"].data_ptr(), b["seq2"].data_ptr(), b["off2"].data_ptr(), max_read_len=L)
                 goff = np.empty(m_all + 1, np.uint32)
@@ -570,19 +670,13 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                 if c0 == 0 and gz_n:    # (the compressed leg classifies the first gz_n pairs of this sample)
                     gz_lines = int(goff[gz_n])
                     gz_assoc_reads = int((cnt[:gz_n] > 0).sum())
-                if same_len_names:      # "r<9 digits>/1 gene<d>\n" per association, reads in input order, genes ascending (ReadOutput.hpp:43)
-                    ridx = np.repeat(np.arange(c0, c0 + m_all, dtype=np.int64), cnt)
-                    txt = np.empty((len(ridx), 1 + nd + 2 + 1 + 4 + 1 + 1), np.uint8)
-                    txt[:, 0] = ord("r")
-                    for d in range(nd):
-                        txt[:, 1 + d] = ord("0") + (ridx // 10 ** (nd - 1 - d)) % 10
-                    txt[:, 1 + nd:1 + nd + 3] = np.frombuffer(b"/1 ", np.uint8)
-                    txt[:, 4 + nd:8 + nd] = np.frombuffer(b"gene", np.uint8)
-                    txt[:, 8 + nd] = ord("0") + gids
-                    txt[:, 9 + nd] = 10
-                    md5.update(txt.tobytes())
+                if same_len_names:      # "r<9 digits>/1 gene<id>\n" per association, reads in input order, genes ascending (ReadOutput.hpp:43)
+                    for a0 in range(0, m_all, 4_000_000):       # (rendered 4 M pairs at a time)
+                        a1 = min(m_all, a0 + 4_000_000)
+                        ridx = np.repeat(np.arange(c0 + a0, c0 + a1, dtype=np.int64), cnt[a0:a1])
+                        md5.update(render_ssv(ridx, gids[int(goff[a0]):int(goff[a1])], nd))
                     if c0 == 0 and gz_n:
-                        gz_md5 = hashlib.md5(txt[:int(goff[gz_n])].tobytes()).hexdigest()
+                        gz_md5 = hashlib.md5(render_ssv(np.repeat(np.arange(0, gz_n, dtype=np.int64), cnt[:gz_n]), gids[:int(goff[gz_n])], nd)).hexdigest()
                 idx = torch.arange(c0, c0 + m_all, device=dev, dtype=torch.int64)
                 for mate, key, fh in ((1, "seq1", f1), (2, "seq2", f2)):
                     for s0 in range(0, m_all, 2_000_000):            # "@r<9 digits>/<mate>\n" + bases + "\n+\n" + qualities + "\n", 2 M records at a time
@@ -620,7 +714,7 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                 # workers: the command's own N (one per GPU), or -- on one GPU, small sample at 0.02 -- also two workers SHARING the
                 # device (`--devices 0,0`): the N-worker code paths (queues, ordered drain, parallel finalize) in front of the driver
                 worker_sets = [args.cli_devices]
-                if n_gpus == 1 and ot == 0.02 and n == small and not args.cli_devices:
+                if with_shared and n_gpus == 1 and ot == 0.02 and n == small and not args.cli_devices:
                     worker_sets.append("0,0")
                 for threads, devices in [(t, d) for t in threads_list for d in worker_sets]:
                     for fn in ("o1.fq", "o2.fq", "out.ssv"):
@@ -629,7 +723,7 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                         except OSError:
                             pass
                     cmd = [exe, "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq"), "-2", os.path.join(td, "r2.fq"),
-                           "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-k", str(args.k), "-v", "-t", str(threads)]
+                           "-o", os.path.join(td, "o1.fq"), "-p", os.path.join(td, "o2.fq"), "-k", str(k_opt), "-v", "-t", str(threads)] + extra_args
                     if devices:
                         cmd += ["--devices", devices]
                     elif n_gpus > 1:
@@ -654,7 +748,7 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
                     fq_bytes = sum(os.path.getsize(os.path.join(td, fn)) if os.path.exists(os.path.join(td, fn)) else 0 for fn in ("o1.fq", "o2.fq"))
                     ok_md5 = (got_md5.hexdigest() == md5_at[n]) if same_len_names else None
                     ok = pr.returncode == 0 and got_lines == lines_at[n] and ok_md5 is not False and fq_bytes == 2 * assoc_reads_at[n] * W
-                    run = {"pairs": n, "on_target": ot, "threads": threads, "devices": devices, "wall_s": round(dt, 3), "value": round(2 * n / dt, 1), "unit": "reads/s", "rc": pr.returncode,
+                    run = {"pairs": n, "on_target": ot_label, "threads": threads, "devices": devices, "wall_s": round(dt, 3), "value": round(2 * n / dt, 1), "unit": "reads/s", "rc": pr.returncode,
                            "ssv_lines": got_lines, "expected_ssv_lines": lines_at[n], "ssv_md5": got_md5.hexdigest(), "ssv_md5_equals_device_result": ok_md5,
                            "fastq_out_bytes": fq_bytes, "fastq_out_bytes_expected": 2 * assoc_reads_at[n] * W, "valid": ok,
                            "stage_s_since_start": stages, "input_bytes": 2 * n * W, "generate_s": round(gen_s, 1)}
@@ -729,6 +823,8 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
         out["two_size_fit"] = slopes
         # headline of this leg: the run a user's sample looks like least flattering -- the SMALL sample at 0.02 (fixed costs included)
         pick = [x for x in valid if x["on_target"] == 0.02 and x["pairs"] == small and x["devices"] == args.cli_devices]
+        if not pick and ots is not None:
+            pick = [x for x in valid if x["pairs"] == small and x["devices"] == args.cli_devices]      # (a leg with rates of its own)
         if pick:
             best = max(pick, key=lambda x: x["value"])
             out.update({k: best[k] for k in ("pairs", "on_target", "threads", "wall_s", "value", "unit")})
@@ -745,6 +841,57 @@ def cli_end_to_end(args, genes, dev, h, L, n_gpus=1):
         return out
     finally:
         shutil.rmtree(td, ignore_errors=True)
+
+
+def position_table_bytes(n_set):
+    """the size of an index's position table (index_build.hip): the smallest power of two of 16-byte buckets, two slots each, that
+    holds n_set keys at a load of at most 0.3"""
+    lg = 10
+    while n_set > 0.3 * 2.0 * (1 << lg):
+        lg += 1
+    return 16 << lg
+
+
+def boundary_leg(h, batch, nb, L, kinds=("pageable", "pinned"), n_batches=12):
+    """PCIe-inclusive rate of the host-buffer entry points on context h (never `value`): shk_classify_submit / shk_classify_wait over
+    the first nb pairs of `batch` copied to host buffers, two sets used alternately, SHK_PIPE_DEPTH batches in flight"""
+    import numpy as np
+    import torch
+    from shark_amd import synth
+    from shark_amd.capi import SHK_PIPE_DEPTH
+    hbp = synth.to_host_sample(batch, nb, L)
+    boundary = {"pairs_per_batch": nb, "batches": n_batches, "in_flight": SHK_PIPE_DEPTH,
+                "what": "shk_classify_submit / shk_classify_wait over host buffers: H2D + kernels + D2H, results on the host; "
+                        "the H2D of the next batches overlaps the kernels of the current one"}
+    for kind in kinds:
+        bufs = []
+        for rep in range(2):                      # two sets of host buffers, used alternately
+            arrs = {}
+            for kk in ("seq1", "seq2"):
+                t = torch.from_numpy(hbp[kk]).clone()
+                arrs[kk] = (t.pin_memory() if kind == "pinned" else t).numpy()
+            for kk in ("off1", "off2"):
+                t = torch.from_numpy(hbp[kk].view(np.int64)).clone()
+                arrs[kk] = (t.pin_memory() if kind == "pinned" else t).numpy().view(np.uint64)
+            bufs.append(arrs)
+
+        def stream(nbatches):
+            tickets, assoc = [], 0
+            for i in range(nbatches):
+                if len(tickets) == SHK_PIPE_DEPTH:
+                    assoc += int(h.wait(tickets.pop(0), copy=False)[0][-1])
+                a = bufs[i % 2]
+                tickets.append(h.submit(a["seq1"], a["off1"], a["seq2"], a["off2"]))
+            while tickets:
+                assoc += int(h.wait(tickets.pop(0), copy=False)[0][-1])
+            return assoc
+        stream(3)
+        t0 = time.perf_counter()
+        assoc = stream(n_batches)
+        tb = (time.perf_counter() - t0) / n_batches
+        boundary[kind] = {"value": round(2 * nb / tb, 1), "unit": "reads/s", "ms_per_batch": round(tb * 1e3, 2),
+                          "GBps_h2d": round((hbp["seq1"].nbytes + hbp["seq2"].nbytes) / tb / 1e9, 1), "assoc_per_batch": assoc // n_batches}
+    return boundary
 
 
 # =====================================================================================================================
@@ -1005,12 +1152,26 @@ def main():
             # The ceiling of random memory-side requests is measured here, in this run, with the library's own measurement entry
             # point (same device, a table of the index's size, plain and streaming loads, the better of the two).
             w2 = h2.count_work(lp, p2[0]["seq1"], p2[0]["off1"], p2[0]["seq2"], p2[0]["off2"])
-            tab2_bytes = 16 << 29     # the configs[2] index's position table: 2^29 buckets of 16 bytes = 8 GiB (1.69e8 set bits at load <= 0.3)
+            tab2_bytes = position_table_bytes(int(info2["n_set_bits"]))     # the configs[2] index's position table: 2^29 buckets of 16 bytes = 8 GiB (1.69e8 set bits at load <= 0.3)
             ceil_plain = h2.measure_random_lookups(tab2_bytes, 1 << 31, False)
             ceil_nt = h2.measure_random_lookups(tab2_bytes, 1 << 31, True)
             big["configs2"] = dict(w=w2, kern_ms=k2, n_assoc=n_assoc2 // steps2, ceiling=max(ceil_plain, ceil_nt), hasq=False,
                                    ceiling_measured={"table_bytes": tab2_bytes, "plain": round(ceil_plain, 1), "streaming": round(ceil_nt, 1),
                                                      "how": "shk_measure_random_lookups, this run"})
+        if rank == 0 and world == 1:
+            # BASELINE configs[2] is "a 60 000-gene FASTA + 100 M reads on one GPU" (README.md:63-66 is the command's shape): the same
+            # index at the host boundary (pinned buffers) and through the `shark` command on FASTQ files, 16 M pairs at the north-star
+            # read mix, ssv md5 against the device-resident result like every run of that leg
+            if not args.no_boundary:
+                log("configs[2] index: batch boundary")
+                cfg2["batch_boundary"] = boundary_leg(h2, b2, min(lp, 4_000_000), L, kinds=("pinned",), n_batches=8)
+            if not args.no_cli:
+                log("configs[2] index: the shark command end to end")
+                del b2
+                b2 = None
+                torch.cuda.empty_cache()
+                cfg2["cli_end_to_end"] = cli_end_to_end(args, g2, dev, h2, L, ots=[0.50], only_small=True, with_gz=False, with_shared=False,
+                                                        extra_args=["-b", "8"], k=17)
         h2.close()
         del b2
         # BASELINE configs[4] shape on this GPU's shard: k=31, -q 20, --single, 2^37-bit filter (the quality-mask path at max k)
@@ -1020,8 +1181,8 @@ def main():
         info4 = h4.build([g.tobytes() for g in g2])
         t_build4 = time.time() - t0
         ceil4 = None
+        tab4_bytes = position_table_bytes(int(info4["n_set_bits"]))
         if rank == 0:
-            tab4_bytes = 16 << 29
             ceil4 = max(h4.measure_random_lookups(tab4_bytes, 1 << 31, False), h4.measure_random_lookups(tab4_bytes, 1 << 31, True))
         old4 = None
         for qual_model in ("uniform", "ends"):
@@ -1039,8 +1200,10 @@ def main():
             if rank == 0:
                 w4 = h4.count_work(lp, p4[0]["seq1"], p4[0]["off1"], p4[0]["seq2"], p4[0]["off2"], p4[0]["qual1"], p4[0]["qual2"])
                 big["configs4_" + qual_model] = dict(w=w4, kern_ms=k4, n_assoc=n_assoc4 // steps2, ceiling=ceil4, hasq=True,
-                                                     ceiling_measured={"table_bytes": 16 << 29, "best_of_plain_and_streaming": round(ceil4, 1),
-                                                                       "how": "shk_measure_random_lookups, this run"})
+                                                     ceiling_measured={"table_bytes": tab4_bytes, "best_of_plain_and_streaming": round(ceil4, 1),
+                                                                       "how": "shk_measure_random_lookups, this run, on a table of the size the kernel probes: the index's "
+                                                                              "position table (%d set bits at load <= 0.3, two slots per 16-byte bucket) -- the k = 31 "
+                                                                              "kernel never reads the 16 GiB filter" % int(info4["n_set_bits"])})
             if qual_model == "uniform":
                 old4 = e4
             else:
@@ -1175,7 +1338,8 @@ def main():
             bb = big[name]
             ww = bb["w"]
             algb = ww["n_bases"] * (2 if bb["hasq"] else 1) + 8 * ww["n_kmers"] + 16 * ww["n_hits"] + 2 * ww["n_list_ids"] + 8 * (2 * lp)
-            rl = request_rate_roofline(ctr.get(name), bb["kern_ms"], bb["ceiling"], algb, ww["n_bases"] * (2 if bb["hasq"] else 1), 4 * lp + 12 * bb["n_assoc"], lp, ww)
+            rl = request_rate_roofline(ctr.get(name), bb["kern_ms"], bb["ceiling"], algb, ww["n_bases"] * (2 if bb["hasq"] else 1), 4 * lp + 12 * bb["n_assoc"], lp, ww,
+                                       cal=fetch_calibration(ctr.get("lookup_calibration")))
             rl["ceiling_measured"] = bb["ceiling_measured"]
             rl["counters_source"] = ctr_note
             cfg["roofline"] = rl
@@ -1184,40 +1348,7 @@ def main():
         boundary = None
         if not args.no_boundary and world == 1:
             log("batch boundary (host buffers, pipelined)")
-            nb = min(n, 4_000_000)
-            hbp = synth.to_host_sample(batch, nb, L)
-            from shark_amd.capi import SHK_PIPE_DEPTH
-            boundary = {"pairs_per_batch": nb, "batches": 12, "in_flight": SHK_PIPE_DEPTH,
-                        "what": "shk_classify_submit / shk_classify_wait over host buffers: H2D + kernels + D2H, results on the host; "
-                                "the H2D of the next batches overlaps the kernels of the current one"}
-            for kind in ("pageable", "pinned"):
-                bufs = []
-                for rep in range(2):                      # two sets of host buffers, used alternately
-                    arrs = {}
-                    for kk in ("seq1", "seq2"):
-                        t = torch.from_numpy(hbp[kk]).clone()
-                        arrs[kk] = (t.pin_memory() if kind == "pinned" else t).numpy()
-                    for kk in ("off1", "off2"):
-                        t = torch.from_numpy(hbp[kk].view(np.int64)).clone()
-                        arrs[kk] = (t.pin_memory() if kind == "pinned" else t).numpy().view(np.uint64)
-                    bufs.append(arrs)
-
-                def stream(nbatches):
-                    tickets, assoc = [], 0
-                    for i in range(nbatches):
-                        if len(tickets) == SHK_PIPE_DEPTH:
-                            assoc += int(h.wait(tickets.pop(0), copy=False)[0][-1])
-                        a = bufs[i % 2]
-                        tickets.append(h.submit(a["seq1"], a["off1"], a["seq2"], a["off2"]))
-                    while tickets:
-                        assoc += int(h.wait(tickets.pop(0), copy=False)[0][-1])
-                    return assoc
-                stream(3)
-                t0 = time.perf_counter()
-                assoc = stream(boundary["batches"])
-                tb = (time.perf_counter() - t0) / boundary["batches"]
-                boundary[kind] = {"value": round(2 * nb / tb, 1), "unit": "reads/s", "ms_per_batch": round(tb * 1e3, 2),
-                                  "GBps_h2d": round((hbp["seq1"].nbytes + hbp["seq2"].nbytes) / tb / 1e9, 1), "assoc_per_batch": assoc // boundary["batches"]}
+            boundary = boundary_leg(h, batch, min(n, 4_000_000), L)
             res, _ = one_pass(h, ptrs[:1], chunk_pairs)      # (`res` again: the boundary leg used the context's result buffers)
 
         # ---- CPU baseline: the oracle (port of the reference path) on this host -------
@@ -1280,6 +1411,16 @@ def main():
             torch.cuda.empty_cache()
             log("the shark command end to end")
             cli = cli_end_to_end(args, genes, dev, h, L, n_gpus=world)
+            if world == 1 and cli.get("runs") is not None:
+                # a sample whose 4 M-pair stretches come from the gene and from elsewhere BY TURNS: the library picks a batch's kernel order by
+                # what the batch before looked like, and here every such guess is wrong at every turn of the sample
+                log("the shark command on a sample of alternating stretches")
+                alt = cli_end_to_end(args, genes, dev, h, L, ots=[0.5], only_small=True, with_gz=False, with_shared=False, alternate=4_000_000)
+                cli["alternating_stretches"] = {"what": "the same command on %d pairs whose 4 M-pair stretches are drawn from the gene and from elsewhere by turns "
+                                                        "(every per-batch guess from the batch before is wrong at every turn)" % args.cli_pairs,
+                                                "runs": alt.get("runs"), "value": alt.get("value"), "unit": "reads/s", "all_runs_valid": alt.get("all_runs_valid")}
+                if alt.get("runs") is not None and not alt.get("all_runs_valid", True):
+                    cli["all_runs_valid"] = False
             log("done")
     finally:
         try:

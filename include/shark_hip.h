@@ -252,7 +252,10 @@ int shk_count_work(shk_ctx *ctx, const shk_batch *dev_batch, shk_work_counters *
  * beyond the caches each lookup is one memory-side request (a 128-byte line of which 16 bytes are used) and the RATE of
  * those bounds the classify kernel; bench.py measures the ceiling with this call in the run whose fraction of it it
  * reports.  Allocates the table, performs about `n_lookups` lookups (five in flight per lane, 8 waves per SIMD;
- * `nontemporal` != 0: streaming loads), frees it again.  On no product path; new (the reference has no counterpart). */
+ * `nontemporal` bit 0: streaming loads; bit 1: every lookup also reads 16 bytes of the other 64-byte half of its 128-byte
+ * line -- the pair of rates says whether a random lookup moves a whole line or half of one, bench.py's calibration of
+ * FETCH_SIZE for this access pattern; the figure returned is LINES per second either way), frees it again.  On no product
+ * path; new (the reference has no counterpart). */
 int shk_measure_random_lookups(shk_ctx *ctx, uint64_t table_bytes, uint64_t n_lookups, int nontemporal, double *g_lookups_per_s);
 
 /* The ISSUE ceiling of the exact-table classify kernel's own instruction mix: a kernel that does, on register operands only

@@ -327,11 +327,20 @@ class SharkHip:
             a = t.numpy().astype(np.uint64)
         return a
 
-    def measure_random_lookups(self, table_bytes, n_lookups=1 << 31, nontemporal=False):
-        """G independent random 16-byte lookups per second in a table of table_bytes on this context's GPU"""
+    def measure_random_lookups(self, table_bytes, n_lookups=1 << 31, nontemporal=False, both_halves=False):
+        """G independent random 16-byte lookups per second in a table of table_bytes on this context's GPU (both_halves: each lookup
+        also reads the other 64-byte half of its 128-byte line; the figure is lines per second either way)"""
         g = C.c_double()
-        self._check(self.L.shk_measure_random_lookups(self.h, table_bytes, n_lookups, int(bool(nontemporal)), C.byref(g)), "shk_measure_random_lookups")
+        self._check(self.L.shk_measure_random_lookups(self.h, table_bytes, n_lookups, int(bool(nontemporal)) | (2 if both_halves else 0), C.byref(g)),
+                    "shk_measure_random_lookups")
         return g.value
+
+    @staticmethod
+    def random_lookups_made(n_lookups):
+        """how many lookups (lines) shk_measure_random_lookups(…, n_lookups, …) really makes in its timed launch: 2 048 workgroups x 256
+        lanes x 5 per iteration, whole iterations"""
+        per_iter = 2048 * 256 * 5
+        return per_iter * max(1, min(n_lookups // per_iter, 1 << 20))
 
     def measure_valu_mix(self, waves_per_simd=4, iters=20000):
         """(ms, wave_iterations) of the exact-table kernel's instruction mix on register operands, `waves_per_simd` waves per SIMD"""

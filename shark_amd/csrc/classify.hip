@@ -1220,12 +1220,6 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   // kernel with the anchored extension reads the reference's payloads instead (7.9 / 11.0 / 14.8 ms).  Both give the same
   // results; the denser the summary, the earlier the other kernel wins (measured crossover: 64 / 42 / 17 % of the pairs assigned
   // at 60 / 100 / 150 genes, pass rates 0.12 / 0.20 / 0.28).  SHK_BIG_LDS_ALWAYS=1: no switching (A/B timing, tests)
-  bool many_assigned = false;
-  if (ctx->last.last_n_reads && ctx->idx.ref_total && ctx->idx.lbig_shift && !ctx->env_big_lds_always) {
-    double f = 1.0 - 3.0 * ctx->idx.lbig_pass;
-    f = f < 0.1 ? 0.1 : (f > 0.9 ? 0.9 : f);
-    many_assigned = (double)ctx->last.last_n_assoc > f * (double)ctx->last.last_n_reads;
-  }
   // tables far beyond the caches (k = 15 ... 17): the k-mer keyed, minimiser-bucketed table -- while the batch just finished left
   // a fifth of its pairs unassigned or more.  Pairs from a gene hardly probe either table (the anchored extension settles them from
   // the reference itself), and what they do probe are isolated slots that share no line with a neighbour: the same results at 18.8
@@ -1247,6 +1241,22 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   if (!pm_lds(mode) && p.ref_total && ctx->last.last_n_reads != 0 && !ctx->env_anchor_always &&
       (double)ctx->last.last_n_assoc < (mode == PM_KTAB ? 0.125 : 0.05) * (double)ctx->last.last_n_reads)
     p.ref_total = 0;
+  // anchor_verdict_kernel (below) in front of this launch?  -- uniform batches on an index that carries the reference arrays, while the
+  // anchored extension is on (above) and the batch just finished had 15 reads in 100 assigned or more: the kernel costs EVERY pair of
+  // the batch a pass (1.5 ms per 10 M pairs, 2.6 on the 60 000-gene index), which the pairs it settles repay several times over and
+  // the others not at all -- 1 000 genes at 5 / 10 / 25 % on-target 9.6 / 9.8 / 10.3 ms without it, 10.9 / 10.6 / 9.7 with
+  const bool pre_pays = ctx->last.last_n_reads == 0 || ctx->env_anchor_always || (double)ctx->last.last_n_assoc >= 0.15 * (double)ctx->last.last_n_reads;
+  const bool pre = rmode == 1 && !pm_lds(mode) && !ctx->env_no_pre_verdict && pre_pays && anchor_verdict_applies(p);
+  // (the switch described above: with that kernel in front the pairs that made the table kernel the better one hardly reach either
+  //  kernel -- the LDS summary's stays until four reads in five are assigned: 100 genes at 50 / 100 % on-target 5.7 / 5.25 ms behind
+  //  the summary, 6.75 / 4.73 through the table kernel)
+  bool many_assigned = false;
+  if (ctx->last.last_n_reads && ctx->idx.ref_total && ctx->idx.lbig_shift && !ctx->env_big_lds_always) {
+    double f = 1.0 - 3.0 * ctx->idx.lbig_pass;
+    f = f < 0.1 ? 0.1 : (f > 0.9 ? 0.9 : f);
+    if (pre && f < 0.8) f = 0.8;
+    many_assigned = (double)ctx->last.last_n_assoc > f * (double)ctx->last.last_n_reads;
+  }
   const bool big = uni && !pm_lds(mode) && ctx->idx.lbig_shift != 0 && (u <= 5 || u == 10) && !many_assigned;
   if (big) {
     mode = ctx->idx.pow2 ? PM_LDS_TAB : PM_LDS_TAB_MOD;
@@ -1271,13 +1281,11 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.tile_first = (p.tri && p.lx_gene != 0xFFFFFFFFu && ctx->env_tile_first >= 0 &&
                     (ctx->env_tile_first > 0 || (ctx->last.last_n_reads != 0 && (double)ctx->last.last_n_assoc >= 0.25 * (double)ctx->last.last_n_reads))) ? 1u : 0u;
   }
-  // The pairs a base-for-base comparison with the reference settles, settled in front of the table kernel (anchor_verdict.hip): uniform
-  // batches on an index that carries the reference arrays, while the anchored extension is on (above); also in front of the 128 KiB
-  // LDS summary's kernel.  The kernel behind it passes over the reads that have their result (SHK_NO_PRE_VERDICT=1: never)
-  bool pre = false;
-  if (rmode == 1 && (!pm_lds(mode) || big) && !ctx->env_no_pre_verdict && anchor_verdict_applies(p)) {
+  // The pairs a base-for-base comparison with the reference settles, settled in front of the table kernel (anchor_verdict.hip), also in
+  // front of the 128 KiB LDS summary's kernel.  The kernel behind it passes over the reads that have their result
+  // (SHK_NO_PRE_VERDICT=1: never)
+  if (pre) {
     if (int rc = launch_anchor_verdict(p, ctx->idx.pow2, stream)) return rc;
-    pre = true;
     p.pre_verdict = 1u;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU

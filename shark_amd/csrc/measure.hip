@@ -22,8 +22,11 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 
 typedef uint32_t m_u32x4 __attribute__((ext_vector_type(4)));
 
-// five lookups in flight per lane (what the classify kernel has per round of 2 x 150 bp); NT = streaming loads
-template <bool NT>
+// five lookups in flight per lane (what the classify kernel has per round of 2 x 150 bp); NT = streaming loads.
+// BOTH: every lookup also reads 16 bytes of the OTHER 64-byte half of its 128-byte line (address ^ 64) -- the calibration of what a
+// random lookup moves: if the memory side fetches whole 128-byte lines the second read is served by the first's line and rate and
+// request count stay what they are for one read per line; if it fetches 64-byte halves on demand both double their cost
+template <bool NT, bool BOTH>
 __global__ __launch_bounds__(256) void random_lookup_kernel(const uint8_t *__restrict__ tab, uint64_t mask16, uint32_t iters, uint32_t *__restrict__ out)
 {
   constexpr int U = 5;
@@ -42,6 +45,16 @@ __global__ __launch_bounds__(256) void random_lookup_kernel(const uint8_t *__res
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) acc += v[j].x ^ v[j].w;
+    if (BOTH) {
+      m_u32x4 u[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const m_u32x4 *p = reinterpret_cast<const m_u32x4 *>(tab + (a[j] ^ 64ull));
+        u[j] = NT ? __builtin_nontemporal_load(p) : *p;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) acc += u[j].y ^ u[j].z;
+    }
   }
   if (acc == 0x12345678u) out[tid & 1023] = acc;   // keeps the loads alive
 }
@@ -189,9 +202,15 @@ extern "C" int shk_measure_random_lookups(shk_ctx *cctx, uint64_t table_bytes, u
   const uint64_t per_iter = (uint64_t)grid * 256 * 5;
   const uint32_t iters = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_lookups / per_iter, 1u << 20));
   const uint64_t mask16 = table_bytes / 16 - 1;
+  const bool nt = (nontemporal & 1) != 0, both = (nontemporal & 2) != 0;   // (bit 1: both halves of every line, see random_lookup_kernel)
   auto launch = [&](uint32_t it) {
-    if (nontemporal) hipLaunchKernelGGL(random_lookup_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, tab, mask16, it, out);
-    else hipLaunchKernelGGL(random_lookup_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, tab, mask16, it, out);
+    if (both) {
+      if (nt) hipLaunchKernelGGL((random_lookup_kernel<true, true>), dim3(grid), dim3(256), 0, ctx->stream, tab, mask16, it, out);
+      else hipLaunchKernelGGL((random_lookup_kernel<false, true>), dim3(grid), dim3(256), 0, ctx->stream, tab, mask16, it, out);
+    } else {
+      if (nt) hipLaunchKernelGGL((random_lookup_kernel<true, false>), dim3(grid), dim3(256), 0, ctx->stream, tab, mask16, it, out);
+      else hipLaunchKernelGGL((random_lookup_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, tab, mask16, it, out);
+    }
   };
   launch(8);                                             // warm-up (page tables, clocks)
   MS_HIP(hipGetLastError());

@@ -1424,6 +1424,7 @@ def test_anchored_extension_follows_the_assigned_fraction(oracle, monkeypatch):
     on = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=1.0)
     off = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.0)
     few = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.02)
+    some = synth.make_reads(rng, genes, 2000, read_len=150, paired=True, on_target=0.10)
     monkeypatch.setenv("SHK_NO_LDS_SUMMARY", "1")      # (the position table behind the L2 summary, as in test_anchored_extension_reads)
     for always in (False, True):
         if always:
@@ -1431,13 +1432,15 @@ def test_anchored_extension_follows_the_assigned_fraction(oracle, monkeypatch):
         o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 26)
         assert h.probe_mode() in ("table", "summary+table"), h.probe_mode()
         seen = []
-        for b in (on, off, few, on, on, few, off, on):
+        for b in (on, off, few, on, on, some, on, few, off, some, some, on):
             goff, _ = _compare_classify(o, h, b)
-            seen.append((int(goff[-1]) / 2000, "+anchored-extension" in h.last_kernel()))
-        # (the first batch has no predecessor: with the extension)
-        assert seen[0][1]
-        for (frac_before, _), (_, with_ext) in zip(seen, seen[1:]):
+            seen.append((int(goff[-1]) / 2000, "+anchored-extension" in h.last_kernel(), "+pre-verdict" in h.last_kernel()))
+        # (the first batch has no predecessor: with the extension, and with anchor_verdict_kernel in front)
+        assert seen[0][1] and seen[0][2]
+        for (frac_before, _, _), (_, with_ext, with_pre) in zip(seen, seen[1:]):
             assert with_ext == (always or frac_before >= 0.05), seen
+            # anchor_verdict_kernel costs every pair of the batch a pass: behind a batch with fewer than 15 reads in 100 assigned it stays out
+            assert with_pre == (always or frac_before >= 0.15), seen
         h.close()
 
 

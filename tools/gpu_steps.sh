@@ -55,7 +55,7 @@ import csv, glob, collections, sys
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "classify_" in r["Kernel_Name"]:
+        if "classify_" in r["Kernel_Name"] or "anchor_verdict" in r["Kernel_Name"]:
             acc[(r["Kernel_Name"].split("(")[0].replace("void shk::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
     if max(v) > 1e6: print(k, c, round(max(v) / 1e7, 1), "per pair (of 10 M)")
