@@ -7,6 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#if defined(SHK_FAKE_HASH) && !defined(SHK_TIMING_ONLY)
+#error "-DSHK_FAKE_HASH builds a library whose results are WRONG (timing-only ablation): say so with -DSHK_TIMING_ONLY as well"
+#endif
+
 namespace shk {
 
 // ---------------------------------------------------------------------------
@@ -35,6 +39,11 @@ __host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r)
 
 __host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t v)
 {
+#if defined(SHK_FAKE_HASH) && defined(__HIP_DEVICE_COMPILE__)
+  // (timing-only ablation, results are WRONG: what a classify kernel would cost if a k-mer's filter position came for one multiply --
+  //  the upper bound of what any scheme that takes XXH64 out of a probe can save; profiles/README.md, round 6)
+  return (v * XP2) ^ (v >> 29);
+#endif
   uint64_t h = XP5 + 8ull;          // seed(0) + PRIME5 + len
   uint64_t k1 = v * XP2;            // round(0, v)
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -3,6 +3,8 @@
 // implementation of any hot-path step lives here: without a device every
 // computing entry point fails.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <mutex>
 
 #include <algorithm>
 #include <cstdio>
@@ -602,7 +604,14 @@ int shk_create(const shk_params *prm, shk_ctx **out)
   if (prm->min_quality < 0) return SHK_ERR_ARG;                        // :138
   if (prm->bf_bits == 0) return SHK_ERR_ARG;
   int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return SHK_ERR_NO_DEVICE;
+  {
+    // the first HIP call of a process brings the runtime up (tens of milliseconds).  N workers created on N threads (shark --gpus N) all
+    // arrive here at once: behind one mutex the first of them initialises the runtime and the others sleep -- racing into the runtime's
+    // own initialisation they took three times as long together (measured: "contexts created" 0.22 s for two workers against 0.10 s)
+    static std::mutex init_m;
+    std::lock_guard<std::mutex> l(init_m);
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return SHK_ERR_NO_DEVICE;
+  }
   if (prm->device < 0 || prm->device >= n_dev) return SHK_ERR_ARG;
   shk_ctx *ctx = new (std::nothrow) shk_ctx();
   if (!ctx) return SHK_ERR_NOMEM;
@@ -622,25 +631,40 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }
   auto fail = [&](int rc) { shk_destroy(ctx); return rc; };
+  // (SHK_TRACE_CREATE=1: where the time of this call goes, on stderr -- tools/workers_start.py)
+  const bool trace = getenv("SHK_TRACE_CREATE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto stamp = [&](const char *what) {
+    if (trace) fprintf(stderr, "[shk/create dev %d ctx %p] %-28s %8.3f ms\n", prm->device, (void *)ctx, what,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
+  stamp("device count");
 #define CR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP); } while (0)
   CR_HIP(hipSetDevice(prm->device));
+  stamp("hipSetDevice");
   CR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   CR_HIP(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
   CR_HIP(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+  stamp("three streams");
   DeviceIndex &ix = ctx->idx;
   ix.bf_bits = prm->bf_bits;
   ix.pow2 = (prm->bf_bits & (prm->bf_bits - 1)) == 0;
   ix.bf_words64 = ((prm->bf_bits + 511) / 512) * 8;
   // BF::BF(size): size zero bits (bloomfilter.h:48-53)
   CR_HIP(hipMalloc((void **)&ix.bf64, ix.bf_words64 * sizeof(uint64_t)));
+  stamp("filter allocated");
   CR_HIP(hipMemsetAsync(ix.bf64, 0, ix.bf_words64 * sizeof(uint64_t), ctx->stream));
+  stamp("filter clear enqueued");
   for (Slot &sl : ctx->slots)
     if (slot_init(ctx, sl) != SHK_OK) return fail(SHK_ERR_HIP);
+  stamp("slots");
   CR_HIP(hipMalloc((void **)&ctx->d_gene_counts, 65536 * sizeof(unsigned long long)));
   CR_HIP(hipMemsetAsync(ctx->d_gene_counts, 0, 65536 * sizeof(unsigned long long), ctx->stream));
   CR_HIP(hipMalloc((void **)&ctx->d_gene_totals, 65536 * sizeof(unsigned long long)));
   CR_HIP(hipMalloc((void **)&ctx->d_work_counters, 4 * sizeof(unsigned long long)));
+  stamp("counters");
   CR_HIP(hipStreamSynchronize(ctx->stream));
+  stamp("synchronised");
 #undef CR_HIP
   *out = ctx;
   return SHK_OK;

@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SCHEDULE = [("", 20261003, 120), ("uni", 20270000, 72), ("mid", 20280000, 20), ("mod", 20290000, 20), ("ktab", 20300000, 30)]
+SCHEDULE = [("", 20261003, 72), ("uni", 20270000, 44), ("mid", 20280000, 18), ("mod", 20290000, 14), ("ktab", 20300000, 18)]
 
 
 def test_fuzz_schedule_covers_every_probe_mode():
