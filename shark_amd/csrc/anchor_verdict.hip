@@ -94,6 +94,7 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   //  64, 128 of a 150-bp mate; all three hold an error, at 1 % per base, once in 150 mates)
   const uint32_t nkc = Lm >= k ? ((Lm - k) >> 5) + 1u : 0u;   // chunks of the mate at whose first base a k-mer starts
   const bool sampled = has_kmer && (nkc <= 3u || (cm & 1u) == 0u);
+  const uint32_t cmid = (nkm >> 1) >> 5;                  // the chunk in which the mate's middle slot starts
   const uint32_t fm = pr * lp + (in2 ? c1 : 0u);          // first lane of my mate
   const uint32_t cmn = in2 ? c2 : c1;                     // its lanes
   const uint32_t f1 = pr * lp + (nk1 ? 0u : c1);          // first lane of the pair's first mate that has slots
@@ -198,11 +199,14 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
     uint32_t a = m0 ? bk.x : bk.z;                                             // where in the reference: x | strand << 31
     const bool hit = probe && (m0 | m1) && a != 0xFFFFFFFFu;
     a ^= isrc ? 0x80000000u : 0u;                                              // bit 31 now: the read shows the other strand
-    // ---- the mate's anchor: its first sampled k-mer that is in the index ----
+    // ---- the mate's anchor: of its sampled k-mers that are in the index the one nearest the mate's middle (the first at or behind the
+    // middle chunk, else the last in front of it) -- `refext` counts at most 254 positions either way, which from the middle reaches both
+    // ends of mates of up to 500 bases, and from the mate's first k-mer only those of up to 270 ----
     const uint64_t HB = __ballot(hit);
     const uint64_t mine = (HB >> fm) & ((1ull << cmn) - 1ull);
     const bool have = act && nkm != 0u && mine != 0ull;
-    const uint32_t src = fm + (have ? (uint32_t)__builtin_ctzll(mine) : 0u);
+    const uint64_t behind = mine >> cmid;
+    const uint32_t src = fm + (have ? (behind ? cmid + (uint32_t)__builtin_ctzll(behind) : 63u - (uint32_t)__builtin_clzll(mine)) : 0u);
     const uint32_t a_src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)a);
     const uint32_t x0 = a_src & 0x7FFFFFFFu, s0 = (src - fm) << 5;             // reference position and slot (mate coordinates) of the anchor
     const bool opp = (a_src >> 31) != 0u;

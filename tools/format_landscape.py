@@ -4,6 +4,7 @@ python tools/format_landscape.py gpurun_out/r5land 'round 5: ...title...' > prof
 import json, os, sys
 d, title = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "kernel time per 10 M pairs")
 SECTIONS = [("sizes", "index sizes at 50 % on-target"), ("on_target", "on-target rates 0 / 100 %"),
+            ("pre_ab", "anchor_verdict_kernel in front of the table kernels on / off (SHK_NO_PRE_VERDICT=1)"),
             ("ktab_ab", "the minimiser table on / off (SHK_NO_KTAB=1 at index build time: the position table), 10 000 genes at 2^33 bits and the configs[2] index"),
             ("anchor_ab", "the anchored extension on / off (SHK_NO_ANCHOR=1)"), ("sparse_ab", "the sparse first round(s) on / off (SHK_NO_SPARSE=1): one gene"),
             ("sparse_multi_ab", "... 9 genes (nothing shared) and 10 genes (one sharing half of another)"),
