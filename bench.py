@@ -201,9 +201,9 @@ def workload_spec(name, args):
     if name == "configs1":
         return dict(k=args.k, bf_log2=args.bf_log2, q=0, single=False, genes=lambda: synth.make_reference(args.genes, args.gene_len),
                     on_target=args.on_target, with_qual=False, qual_model=None, seed=synth.SEED + 1)
-    if name == "configs2":
+    if name in ("configs2", "configs2_ot1.00"):      # (the second: every pair drawn from a gene -- instructions per ON-TARGET pair, profiles only)
         return dict(k=17, bf_log2=36, q=0, single=False, genes=lambda: synth.make_gencode_like_reference(60000),
-                    on_target=0.5, with_qual=False, qual_model=None, seed=synth.SEED + 7)
+                    on_target=0.5 if name == "configs2" else 1.0, with_qual=False, qual_model=None, seed=synth.SEED + 7)
     if name in ("configs4_uniform", "configs4_ends"):
         return dict(k=31, bf_log2=37, q=20, single=True, genes=lambda: synth.make_gencode_like_reference(60000),
                     on_target=0.5, with_qual=True, qual_model=name.split("_")[1], seed=synth.SEED + 7)
@@ -937,7 +937,7 @@ def main():
             res["configs1_ot%.2f" % ot] = r.get("configs1", {})
             print(note, file=sys.stderr, flush=True)
         args.on_target = 0.5
-        r, note = collect_counters(args, ["configs2", "configs4_uniform", "configs4_ends"], sets=COUNTER_SETS_FULL)
+        r, note = collect_counters(args, ["configs2", "configs2_ot1.00", "configs4_uniform", "configs4_ends"], sets=COUNTER_SETS_FULL, timeout_s=600)
         res.update(r)
         print(note, file=sys.stderr, flush=True)
         json.dump(res, open(args.profile_passes, "w"), indent=1)

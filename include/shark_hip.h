@@ -182,7 +182,9 @@ int shk_classify_device(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_
  *                  (off2 likewise) -- a sequencer's output, generated or copied to the device by the caller itself -- it says so
  *                  here, as the host entry points find out by scanning the offsets: the kernel then never reads an offset and
  *                  the pass that would verify them on the device (61 us per 10 M pairs) is not made.  0, 0: unknown, the
- *                  device looks (as shk_classify_device always does).  The caller vouches for what it states. */
+ *                  device looks (as shk_classify_device always does).  The caller vouches for what it states; one thread on
+ *                  the device compares three offsets per mate (first, middle, last) with r * length, and shk_classify_wait
+ *                  returns SHK_ERR_ARG for a batch whose caller vouched wrongly (no results are handed out). */
 int shk_classify_device_submit(shk_ctx *ctx, const shk_batch *batch, uint32_t max_read_len, uint32_t uniform_len1, uint32_t uniform_len2,
                                uint64_t *ticket);
 

@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "profiles")
-KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]    # same list as bench.py
+KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "anchor_verdict.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]    # same list as bench.py
 
 
 def kernel_src_sha():
@@ -48,13 +48,13 @@ if glob.glob(src + "/kt_trimmed/*/*_kernel_stats.csv"):     # tools/ragged_rate.
         w = csv.writer(f)
         w.writerow(rows[0])
         for r in rows[1:]:
-            if any(x in r[0] for x in ("classify", "uniform_check", "class_")):
+            if any(x in r[0] for x in ("classify", "uniform_check", "class_", "anchor_verdict")):
                 w.writerow(r)
 bench = json.loads([l for l in open(os.path.join(src, "kt.json")) if l.startswith("{")][-1])
 json.dump(bench, open(os.path.join(ROOT, "profiles", "%s_bench_profiled.json" % tag), "w"), indent=1)
 avg_ms = {}
 for r in csv.DictReader(open(stats)):
-    if "classify" in r["Name"]:
+    if "classify" in r["Name"] or "anchor_verdict" in r["Name"]:
         avg_ms[r["Name"].split("(")[0].replace("void shk::", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
 
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -73,7 +73,12 @@ for name, c in raw.items():
     if name == "valu_mix":      # shk_measure_valu_mix's kernel: VALU instructions per wave-iteration by waves per SIMD
         out["valu_mix_instructions_per_wave_iteration"] = c
         continue
+    if name == "lookup_calibration":   # the FETCH_SIZE calibration on a known number of random lookups (bench.py fetch_calibration)
+        out["lookup_calibration"] = c
+        continue
     e = {"kernel": c.get("kernel"), "kernel_reported_by_library": c.get("kernel_reported_by_library"), "pairs": 10_000_000, "n_assoc": c.get("n_assoc")}
+    if c.get("kernels"):       # a launch whose work is split over two kernels: the counters below are their sums, this is the split
+        e["kernels"] = c["kernels"]
     for key in ("FETCH_SIZE", "WRITE_SIZE"):
         if key in c:
             e[key + "_KB"] = c[key]
