@@ -50,25 +50,25 @@ __device__ __forceinline__ uint32_t av_squeeze(uint32_t e)
   return (e | (e >> 8)) & 0xFFFFu;
 }
 
-// uniform batches (one length per mate), pairs of at most 64 chunks of 32 bases.  POW2: the filter size is a power of two
-template <bool POW2, bool HASQ>
+// Batches of one length per mate (RAGGED = false), or of mixed lengths (trimmed reads: RAGGED = true) -- those in the lane layout of
+// the batch's LONGEST mates, a pair bringing its own two lengths (its chunks beyond them stay idle).  Pairs of at most 64 chunks of
+// 32 bases.  POW2: the filter size is a power of two
+template <bool POW2, bool HASQ, bool RAGGED>
 __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const ClassifyParams P)
 {
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
   if (P.uni_flag) {
-    if (P.uni_flag[0] != 1u) return;   // (the device's verdict: not a uniform batch)
+    if (P.uni_flag[0] != (RAGGED ? 0u : 1u)) return;   // (the device's verdict: not this instantiation's kind of batch)
     L1 = P.uni_flag[1];
     L2 = P.uni_flag[2];
   }
   L1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L1);
   L2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L2);
+  if (!P.seq2) L2 = 0u;
   const uint32_t k = P.k;
   const uint32_t c1 = (L1 + 31u) >> 5, c2 = (L2 + 31u) >> 5, lp = c1 + c2;   // chunks per mate, lanes per pair
   if (lp == 0u || lp > 64u) return;
   const uint32_t ppw = 64u / lp < AV_PPW ? 64u / lp : AV_PPW;                // pairs per pass
-  const uint32_t nk1 = L1 >= k ? L1 - k + 1u : 0u, nk2 = L2 >= k ? L2 - k + 1u : 0u, nks = nk1 + nk2;
-  const uint32_t thr = cov_threshold(P.c, L1 + L2);   // (a pair with invalid characters has a lower threshold: passing this one is sufficient)
-  if (nks == 0u || thr == 0u) return;
   const uint32_t n_reads = (uint32_t)P.n;
   const uint32_t n_pass = (n_reads + ppw - 1u) / ppw;
   const int lane = threadIdx.x & 63;
@@ -86,18 +86,9 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   const bool in2 = cl >= c1;
   const uint32_t cm = in2 ? cl - c1 : cl;                 // chunk of the mate
   const uint32_t bofs = cm << 5;                          // its first base (mate coordinates)
-  const uint32_t Lm = in2 ? L2 : L1, nkm = in2 ? nk2 : nk1;
-  const uint32_t nb = act ? (Lm - bofs < 32u ? Lm - bofs : 32u) : 0u;       // bases of the mate in the chunk (>= 1 for an active lane)
-  const uint32_t tail = nb < 32u ? 0xFFFFFFFFu << nb : 0u;
-  const bool has_kmer = act && bofs + k <= Lm;            // a k-mer starts at the chunk's first base (and ends inside the chunk: k <= 31)
-  // (a probe is a memory-side request on every index whose table has outgrown an XCD's L2: every other chunk is sampled -- slots 0,
-  //  64, 128 of a 150-bp mate; all three hold an error, at 1 % per base, once in 150 mates)
-  const uint32_t nkc = Lm >= k ? ((Lm - k) >> 5) + 1u : 0u;   // chunks of the mate at whose first base a k-mer starts
-  const bool sampled = has_kmer && (nkc <= 3u || (cm & 1u) == 0u);
-  const uint32_t cmid = (nkm >> 1) >> 5;                  // the chunk in which the mate's middle slot starts
   const uint32_t fm = pr * lp + (in2 ? c1 : 0u);          // first lane of my mate
-  const uint32_t cmn = in2 ? c2 : c1;                     // its lanes
-  const uint32_t f1 = pr * lp + (nk1 ? 0u : c1);          // first lane of the pair's first mate that has slots
+  const uint32_t fo = pr * lp + (in2 ? 0u : c1);          // first lane of the pair's other mate
+  const uint32_t cmn = in2 ? c2 : c1;                     // my mate's lanes
   const uint64_t pair_mask = (lp < 64u ? (1ull << lp) - 1ull : ~0ull) << (pr * lp);
   // the pair's field in the packed sums (pairs 0-2 in one word, 3-5 in another): ten bits while a pair has at most 21 lanes (672
   // bases), fifteen for the longer pairs, of which a pass holds two at most
@@ -105,32 +96,57 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   const bool hi3 = pr >= 3u;
   const uint8_t *sb = (in2 ? P.seq2 : P.seq1) + bofs;
   const uint8_t *qb = HASQ ? (in2 ? P.qual2 : P.qual1) + bofs : nullptr;
+  const uint64_t *offm = in2 ? P.off2 : P.off1;
   const uint64_t kmer_mask = (1ull << (2u * k)) - 1ull;   // (k <= 31)
   const uint32_t kbits = (1u << k) - 1u;
-  const uint32_t Lmin = L2 ? (L1 < L2 ? L1 : L2) : L1;
-  const uint32_t guard = Lmin ? (35u + Lmin - 1u) / Lmin : 0u;   // an unguarded fetch reads up to 35 bytes from the chunk's first: the last reads take the guarded form
   const uint32_t pmask = (uint32_t)((1ull << P.tab_lg) - 1ull) & (uint32_t)P.bf_mask;
   const uint32_t pspare = 1u << P.tab_lg;
   const uint32_t tagmask = (uint32_t)(P.bf_mask >> P.tab_lg);
   const uint4 *atab16 = reinterpret_cast<const uint4 *>(P.atab);
   const uint32_t ref_total = P.ref_total;
+  // where the lane's mate buffer ends: an unguarded fetch reads up to 35 bytes from the chunk's first, so only chunks that far from the
+  // end take it (RAGGED: from the offsets; else the mates are n reads of one length)
+  const uint64_t end_m = RAGGED ? (act ? offm[n_reads] : 0ull) : (uint64_t)n_reads * (in2 ? L2 : L1);
 
-  auto issue = [&](const uint8_t *base, const uint32_t gg) -> AvRaw {
+  // ---- what depends on the pair's two lengths: once for a batch of one length per mate, per pass for trimmed reads ----
+  uint32_t nb = 0u, tail = 0xFFFFFFFFu, nkm = 0u, nks = 0u, thr = 0u, cmid = 0u, f1 = 0u;
+  bool has_kmer = false, sampled = false;
+  auto set_lengths = [&](const uint32_t lm, const uint32_t lo) {      // my mate's length, the other mate's
+    nb = (act && lm > bofs) ? (lm - bofs < 32u ? lm - bofs : 32u) : 0u;                 // bases of the mate in the chunk
+    tail = nb < 32u ? 0xFFFFFFFFu << nb : 0u;
+    nkm = lm >= k ? lm - k + 1u : 0u;
+    const uint32_t nko = lo >= k ? lo - k + 1u : 0u;
+    nks = nkm + nko;
+    thr = cov_threshold(P.c, lm + lo);   // (a pair with invalid characters has a lower threshold: passing this one is sufficient)
+    has_kmer = nb != 0u && bofs + k <= lm;            // a k-mer starts at the chunk's first base (and ends inside the chunk: k <= 31)
+    // (a probe is a memory-side request on every index whose table has outgrown an XCD's L2: every other chunk is sampled -- slots 0,
+    //  64, 128 of a 150-bp mate; all three hold an error, at 1 % per base, once in 150 mates)
+    const uint32_t nkc = lm >= k ? ((lm - k) >> 5) + 1u : 0u;   // chunks of the mate at whose first base a k-mer starts
+    sampled = has_kmer && (nkc <= 3u || (cm & 1u) == 0u);
+    cmid = (nkm >> 1) >> 5;                           // the chunk in which the mate's middle slot starts
+    f1 = pr * lp + ((in2 ? nko : nkm) ? 0u : c1);     // first lane of the pair's first mate that has slots
+  };
+  if (!RAGGED) {
+    set_lengths(in2 ? L2 : L1, in2 ? L1 : L2);
+    if (__builtin_amdgcn_readfirstlane((int)(nks == 0u || thr == 0u))) return;
+  }
+
+  // the 32 bytes of the lane's chunk of the read that starts at byte `om` of its mate's buffer (nbx of them belong to the read)
+  auto issue = [&](const uint8_t *base, const uint64_t om, const uint32_t nbx) -> AvRaw {
     AvRaw r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.d[i] = 0u;
     r.sh = 0u;
-    const uint32_t rd = ppw * gg + pr;
-    if (act && rd < n_reads) {
-      const uint8_t *sp = base + (uint64_t)rd * Lm;
+    if (nbx != 0u) {
+      const uint8_t *sp = base + om;
       const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(sp) & 3u;
       const uint32_t *q = reinterpret_cast<const uint32_t *>(sp - sh);
       r.sh = sh;
-      if (n_reads - rd > guard) {
+      if (om + bofs + 36ull <= end_m) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) r.d[i] = q[i];
       } else {
-        const uint32_t last = sh + nb - 1u;              // index of the last wanted byte relative to q: only dwords that hold a byte of the mate are touched
+        const uint32_t last = sh + nbx - 1u;             // index of the last wanted byte relative to q: only dwords that hold a byte of the mate are touched
 #pragma unroll
         for (int i = 0; i < 9; ++i) r.d[i] = last >= 4u * (uint32_t)i ? q[i] : 0u;
       }
@@ -157,19 +173,56 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
     for (int i = 0; i < 8; ++i) m |= gather4(qmask4(__builtin_amdgcn_alignbyte(r.d[i + 1], r.d[i], r.sh), P.mq)) << (4 * i);   // FastqSplitter.hpp:104-109
     return m;
   };
-  AvRaw cur = issue(sb, g), qcur;
-  if (HASQ) qcur = issue(qb, g);
+  // (trimmed reads) a pass's offsets: the lane's mate's start and end of read ppw gg + pr; its length, and the other mate's by a
+  // look at that mate's first lane
+  struct Off { uint64_t a, b; };
+  auto off_issue = [&](const uint32_t gg) -> Off {
+    const uint32_t rd = ppw * gg + pr;
+    Off o{0ull, 0ull};
+    if (act && gg < g_end && rd < n_reads) { o.a = offm[rd]; o.b = offm[rd + 1u]; }
+    return o;
+  };
+  auto lengths_of = [&](const Off &o, uint32_t &lm, uint32_t &lo) {
+    const uint64_t d = o.b - o.a;
+    lm = d < 0x7FFFFFFFull ? (uint32_t)d : 0x7FFFFFFFu;
+    lo = c2 ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(fo << 2), (int)lm) : 0u;
+    // (a read longer than the layout's mates -- the lengths came from the caller as a bound that does not hold --: nothing of it is looked at)
+    if (lm > (in2 ? L2 : L1) || lo > (in2 ? L1 : L2)) { lm = 0u; lo = 0u; }
+  };
+  AvRaw cur, qcur;
+  Off off_n{0ull, 0ull};
+  uint32_t lm_c = 0u, lo_c = 0u;
+  if (RAGGED) {
+    const Off o0 = off_issue(g);
+    lengths_of(o0, lm_c, lo_c);
+    set_lengths(lm_c, lo_c);
+    cur = issue(sb, o0.a, nb);
+    if (HASQ) qcur = issue(qb, o0.a, nb);
+    off_n = off_issue(g + 1u);
+  } else {
+    const uint32_t rd0 = ppw * g + pr;
+    const uint32_t nb0 = (act && rd0 < n_reads) ? nb : 0u;
+    cur = issue(sb, (uint64_t)rd0 * (in2 ? L2 : L1), nb0);
+    if (HASQ) qcur = issue(qb, (uint64_t)rd0 * (in2 ? L2 : L1), nb0);
+  }
   for (; g < g_end; ++g) {
     AvRaw nxt, qnxt;
-    if (g + 1u < g_end) {
-      nxt = issue(sb, g + 1u);
-      if (HASQ) qnxt = issue(qb, g + 1u);
+    uint32_t lm_n = 0u, lo_n = 0u;
+    if (RAGGED) {
+      // the next pass's lengths (its offsets were asked for a pass ago), its bases, and the offsets of the pass behind it
+      lengths_of(off_n, lm_n, lo_n);
+      const uint32_t nbn = (act && g + 1u < g_end && lm_n > bofs) ? (lm_n - bofs < 32u ? lm_n - bofs : 32u) : 0u;
+      nxt = issue(sb, off_n.a, nbn);
+      if (HASQ) qnxt = issue(qb, off_n.a, nbn);
+      off_n = off_issue(g + 2u);
     } else {
-      nxt = cur;
-      if (HASQ) qnxt = qcur;
+      const uint32_t rdn = ppw * (g + 1u) + pr;
+      const uint32_t nbn = (act && g + 1u < g_end && rdn < n_reads) ? nb : 0u;
+      nxt = issue(sb, (uint64_t)rdn * (in2 ? L2 : L1), nbn);
+      if (HASQ) qnxt = issue(qb, (uint64_t)rdn * (in2 ? L2 : L1), nbn);
     }
     const uint32_t rd = ppw * g + pr;
-    const bool live = act && rd < n_reads;
+    const bool live = act && rd < n_reads && (!RAGGED || nb != 0u);
     // ---- the chunk's 32 bases as 2-bit codes, and which of them are invalid (N, a masked quality, behind the mate's end) ----
     uint64_t code;
     uint32_t inv;
@@ -285,7 +338,7 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
       so_hi = wave_sum_u32(hi3 ? covo << fsh : 0u);
     }
     const uint32_t cov_m = ((hi3 ? sm_hi : sm_lo) >> fsh) & fmask, cov_o = ((hi3 ? so_hi : so_lo) >> fsh) & fmask;
-    const bool pass = (BAD & pair_mask) == 0ull && cov_m >= thr && cov_m > cov_o;
+    const bool pass = (BAD & pair_mask) == 0ull && thr != 0u && cov_m >= thr && cov_m > cov_o;
     if (live && cl == 0u && pass) {
       const ClassifyOut *O = P.out;
       O->count[rd] = 1u;
@@ -296,10 +349,12 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
     }
     cur = nxt;
     if (HASQ) qcur = qnxt;
+    if (RAGGED) set_lengths(lm_n, lo_n);
   }
 }
 
-// does the kernel apply to uniform batches of these lengths?  (lengths only the device knows: it decides itself)
+// does the kernel apply to batches of these lengths (`ragged`: the longest mates of a batch of mixed lengths)?  Lengths only the device
+// knows: it decides itself
 bool anchor_verdict_applies(const ClassifyParams &p)
 {
   if (!p.ref_total || !p.refext || !p.refmul || !p.atab || !p.ref2 || p.n == 0 || p.n >= (1ull << 32)) return false;
@@ -308,7 +363,7 @@ bool anchor_verdict_applies(const ClassifyParams &p)
   return lp != 0u && lp <= 64u;
 }
 
-int launch_anchor_verdict(const ClassifyParams &p, bool pow2, hipStream_t s)
+int launch_anchor_verdict(const ClassifyParams &p, bool pow2, bool ragged, hipStream_t s)
 {
   // (lengths only the device knows: a pass may hold one pair only -- the grid is sized for that, waves without work return at once)
   const uint32_t lp = p.uni_flag ? 0u : ((p.uni_L1 + 31u) >> 5) + (((p.seq2 ? p.uni_L2 : 0u) + 31u) >> 5);
@@ -317,13 +372,15 @@ int launch_anchor_verdict(const ClassifyParams &p, bool pow2, hipStream_t s)
   const uint64_t waves = (n_pass + AV_PASSES - 1) / AV_PASSES;
   const unsigned grid = (unsigned)((waves + AV_WAVES - 1) / AV_WAVES);
   const bool hasq = p.hasq != 0;
-  if (pow2) {
-    if (hasq) hipLaunchKernelGGL((anchor_verdict_kernel<true, true>), dim3(grid), dim3(AV_WAVES * 64), 0, s, p);
-    else hipLaunchKernelGGL((anchor_verdict_kernel<true, false>), dim3(grid), dim3(AV_WAVES * 64), 0, s, p);
+#define AVL(P2_, HQ_, RG_) hipLaunchKernelGGL((anchor_verdict_kernel<P2_, HQ_, RG_>), dim3(grid), dim3(AV_WAVES * 64), 0, s, p)
+  if (ragged) {
+    if (pow2) { if (hasq) AVL(true, true, true); else AVL(true, false, true); }
+    else { if (hasq) AVL(false, true, true); else AVL(false, false, true); }
   } else {
-    if (hasq) hipLaunchKernelGGL((anchor_verdict_kernel<false, true>), dim3(grid), dim3(AV_WAVES * 64), 0, s, p);
-    else hipLaunchKernelGGL((anchor_verdict_kernel<false, false>), dim3(grid), dim3(AV_WAVES * 64), 0, s, p);
+    if (pow2) { if (hasq) AVL(true, true, false); else AVL(true, false, false); }
+    else { if (hasq) AVL(false, true, false); else AVL(false, false, false); }
   }
+#undef AVL
   return hipGetLastError() == hipSuccess ? SHK_OK : SHK_ERR_HIP;
 }
 

@@ -1246,7 +1246,9 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   // the batch a pass (1.5 ms per 10 M pairs, 2.6 on the 60 000-gene index), which the pairs it settles repay several times over and
   // the others not at all -- 1 000 genes at 5 / 10 / 25 % on-target 9.6 / 9.8 / 10.3 ms without it, 10.9 / 10.6 / 9.7 with
   const bool pre_pays = ctx->last.last_n_reads == 0 || ctx->env_anchor_always || (double)ctx->last.last_n_assoc >= 0.15 * (double)ctx->last.last_n_reads;
-  const bool pre = rmode == 1 && !pm_lds(mode) && !ctx->env_no_pre_verdict && pre_pays && anchor_verdict_applies(p);
+  // (trimmed batches too, rmode 0, in the lane layout of the batch's longest mates: the ragged instantiation behind it passes over
+  //  the reads that have their result by a flag per read)
+  const bool pre = (rmode == 1 || rmode == 0) && !pm_lds(mode) && !ctx->env_no_pre_verdict && pre_pays && anchor_verdict_applies(p);
   // (the switch described above: with that kernel in front the pairs that made the table kernel the better one hardly reach either
   //  kernel -- the LDS summary's stays until four reads in five are assigned: 100 genes at 50 / 100 % on-target 5.7 / 5.25 ms behind
   //  the summary, 6.75 / 4.73 through the table kernel)
@@ -1285,7 +1287,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   // front of the 128 KiB LDS summary's kernel.  The kernel behind it passes over the reads that have their result
   // (SHK_NO_PRE_VERDICT=1: never)
   if (pre) {
-    if (int rc = launch_anchor_verdict(p, ctx->idx.pow2, stream)) return rc;
+    if (int rc = launch_anchor_verdict(p, ctx->idx.pow2, rmode == 0, stream)) return rc;
     p.pre_verdict = 1u;
   }
   const bool wg16 = big || lx;   // one 1024-thread workgroup per CU

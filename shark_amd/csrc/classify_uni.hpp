@@ -663,9 +663,19 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // fetched a block ahead, a ballot says which of its reads are left, and only those are ever fetched, staged or waited for.
   // (Passing over a settled read inside the usual loop cost its prefetch's round trip: 1.2 ms per 10 M pairs at 100 % on-target.)
   constexpr bool PRE = UNI && !CLS && !LX;
+  // PRE_R: the ragged instantiations of the table modes behind that kernel (trimmed batches).  Their loop fetches a read's offsets two
+  // reads ahead and its bases one ahead at fixed steps: a settled read is passed over by its flag, fetched with the next read's bases
+  // (the read's own prefetch is paid -- these kernels wait on memory at 12-17 ms per 10 M pairs; the block walk is the uniform loop's)
+  constexpr bool PRE_R = !UNI && !pm_lds(MODE);
   const uint32_t *pre_count = nullptr;
-  if (PRE && P.pre_verdict) pre_count = P.out->count;
+  if ((PRE || PRE_R) && P.pre_verdict) pre_count = P.out->count;
   const bool BM = PRE && pre_count != nullptr;
+  uint32_t done_cur = 0u;
+  auto pre_fetch = [&](const uint32_t r) -> uint32_t {
+    const uint32_t *cp = pre_count + r;
+    asm volatile("" : "+v"(cp));   // (a vector load: a scalar one would share lgkmcnt with the LDS accesses of the read at hand)
+    return *cp;
+  };
   const uint32_t n_blk = (n_reads + 63u) >> 6;
   uint32_t bm_pos = 0u, bm_pn = 0u, bm_fn = 1u;   // the block at hand, the next one of the wave's sequence and (per lane) its flags
   uint64_t bm_bits = 0ull;                          // reads of the block at hand that are left behind the current one
@@ -713,6 +723,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   } else {
     m_cur = fetch_meta(P, read);
     fetch_groups(m_cur, w_cur, q_cur);
+    if (PRE_R && pre_count) done_cur = pre_fetch(read);
     pl_cur = plan_issue(m_cur);
     const uint32_t n1 = n32 - read > stride ? read + stride : n32;
     m_nxt = fetch_meta(P, n1 < n32 ? n1 : read);
@@ -786,6 +797,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     for (int g = 0; g < G; ++g) { w_nxt[g] = Raw8{0u, 0u, 0u, 0u}; q_nxt[g] = Raw8{0u, 0u, 0u, 0u}; }
     ReadMetaRaw r_nn{};
     uint32_t nn = n32;
+    uint32_t done_nxt = 0u;
     uint4 pl_nxt = make_uint4(0u, 0u, 0u, 0u);
     Raw16 t_nxt{0u, 0u, 0u, 0u, 0u, 0u};
     if (CLS) {
@@ -796,6 +808,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       if (have_nxt) issue(nxt, w_nxt, q_nxt);
     } else {
       if (have_nxt) { fetch_groups(m_nxt, w_nxt, q_nxt); pl_nxt = plan_issue(m_nxt); }
+      if (PRE_R && pre_count && have_nxt) done_nxt = pre_fetch(nxt);
       nn = (have_nxt && n32 - nxt > stride) ? nxt + stride : n32;
       r_nn = fetch_meta_issue(P, nn < n32 ? nn : read);          // clamped index
       if (FIXLAY) set_read(m_cur.L1, m_cur.L2); else set_geometry(m_cur.L1, m_cur.L2);
@@ -820,6 +833,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         skip = true;
       }
     }
+    // (behind the check above: a read this specialisation does not hold is queued for the general kernel whether or not it has its
+    //  result already -- the host may have COUNTED the queue's entries (LONG_KNOWN), and that kernel writes the same result again)
+    if (PRE_R && __builtin_amdgcn_readfirstlane((int)done_cur) != 0) skip = true;
     if (!skip) {
 
     // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
@@ -2027,6 +2043,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
       pl_cur = pl_nxt;
     }
     it = nxt;
+    if (PRE_R) done_cur = done_nxt;
     if (DYN && !BM) dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
     read = CLS ? read_nxt : it;
 #pragma unroll

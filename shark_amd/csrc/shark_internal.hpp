@@ -303,7 +303,7 @@ int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *f
 bool uni_kernel_available(const Ctx *ctx);
 // anchor_verdict.hip
 bool anchor_verdict_applies(const ClassifyParams &p);
-int launch_anchor_verdict(const ClassifyParams &p, bool pow2, hipStream_t stream);
+int launch_anchor_verdict(const ClassifyParams &p, bool pow2, bool ragged, hipStream_t stream);
 uint32_t fast_kernel_max_slots();
 uint32_t fast_kernel_unroll(uint32_t max_slots);  // U of the specialisation chosen for max_slots (0 = unknown)
 uint32_t uni_kernel_max_groups(uint32_t max_slots);   // staging groups per pair classify_uni_kernel can take at that specialisation

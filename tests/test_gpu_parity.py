@@ -1843,7 +1843,7 @@ def test_verdict_by_mismatch_count(oracle, monkeypatch, env, L1, L2, k):
                 goff, _ = _compare_classify(o, h, batch)
                 assert goff[-1] > 0 or c > 0.9
                 if "classify_uni_kernel" in h.last_kernel():
-                    assert ("+pre-verdict" in h.last_kernel()) == (how == "pre" and not ragged), h.last_kernel()
+                    assert ("+pre-verdict" in h.last_kernel()) == (how == "pre"), h.last_kernel()      # (trimmed batches take the kernel too)
             h.close()
 
 
