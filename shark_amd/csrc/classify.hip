@@ -712,7 +712,17 @@ __global__ __launch_bounds__(1024) void uniform_check_kernel(const ClassifyParam
       flag[1] = any_bad ? (m1 > f1 ? m1 : f1) : f1;
       flag[2] = any_bad ? (m2 > f2 ? m2 : f2) : f2;
       __threadfence();
-      flag[0] = ok ? 1u : 0u;
+      // 3: mixed lengths, and the launcher has the three-pairs kernel by offsets in the stream (P.tro) for a layout of these longest
+      // mates -- exactly tri_applies() of classify_uni.hpp
+      uint32_t verdict = ok ? 1u : 0u;
+      if (!ok && n && any_bad && P.tro) {
+        const uint32_t a1 = flag[1], a2 = P.seq2 ? flag[2] : 0u;
+        const uint32_t d1 = (a1 + 15u) >> 4, d2 = (a2 + 15u) >> 4;
+        const uint32_t q2 = a2 >= k ? a2 - k + 1u : 0u, q1 = a1 >= k ? a1 - k + 1u : 0u;
+        const uint32_t nsl = q2 ? (d1 << 4) + q2 : q1;
+        if (a1 != 0u && d1 + d2 <= 21u && nsl <= slot_cap) verdict = 3u;
+      }
+      flag[0] = verdict;
     }
   }
 }
@@ -1208,7 +1218,7 @@ void launch_uni_u10(const ClassifyParams &p, int mode, bool hasq, bool big, bool
 int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots, int rmode, hipStream_t stream)
 {
   if (p_in.n == 0) return SHK_OK;
-  const bool uni = rmode != 0;
+  const bool uni = rmode != 0;      // (1, 2, 3: the uniform loop -- of the batch, of a class, of the longest mates' layout)
   ClassifyParams p = p_in;
   const bool hasq = p.hasq != 0;
   int mode = probe_mode(ctx->idx);
@@ -1275,7 +1285,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     p.lx_gene = ctx->idx.ltab_gene;
     p.lx_multi = (uni && ctx->idx.ltab_sparse && ctx->idx.ltab_gene == 0xFFFFFFFFu) ? 1u : 0u;
     // three pairs per staging pass (classify_uni.hpp, TRI): uniform batches without qualities, U = 3 ... 5 (SHK_NO_TRI=1: not)
-    p.tri = (rmode == 1 && !hasq && u >= 3 && u <= 5 && !ctx->env_no_tri) ? 1u : 0u;
+    p.tri = ((rmode == 1 || rmode == 3) && !hasq && u >= 3 && u <= 5 && !ctx->env_no_tri) ? 1u : 0u;
     // ... with a round of disjoint k-mers for the three pairs together in front (classify_uni.hpp, TF: an instantiation of its own)
     // while the batch just finished had a quarter of its reads assigned or more: a pair from the gene then ends behind a THIRD of a
     // hash round, a pair from elsewhere pays that third on top of its own two rounds (217 VALU instructions against 191).  Per 10 M
@@ -1296,7 +1306,7 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   const uint64_t cap = wg16 ? 256ull : 256ull * (uint64_t)(min_waves / 2);   // exactly the resident workgroups
   const uint64_t want = (p.n + wpb - 1) / wpb;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
-  if (rmode == 2 && !lx) return SHK_OK;      // (no such instantiation on this index: the verdict is never "by classes" there)
+  if ((rmode == 2 || rmode == 3) && !lx) return SHK_OK;      // (no such instantiation on this index: the verdict is never "by classes" / "offsets" there)
   if (u == 2) launch_uni_u2(p, mode, hasq, big, lx, rmode, grid, stream);
   else if (u == 3) launch_uni_u3(p, mode, hasq, big, lx, rmode, grid, stream);
   else if (u == 4) launch_uni_u4(p, mode, hasq, big, lx, rmode, grid, stream);
@@ -1306,6 +1316,12 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
   else launch_uni_u10(p, mode, hasq, big, lx, rmode, grid, stream);
   SHK_HIP(ctx, hipGetLastError());
   if (rmode == 2) return SHK_OK;             // (shk_last_kernel names the uniform / ragged launch)
+  if (rmode == 3) {
+    if (!p.uni_flag)      // (the host knows the batch is of mixed lengths: this launch is the one that works)
+      snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, false, 21, offsets> +three-pairs%s%s", u, mode,
+               p.tile_first ? " +tiles-first" : "", p.lx_multi ? " +sparse-first-rounds" : (p.lx_gene != 0xFFFFFFFFu ? " +sparse-first-round" : ""));
+    return SHK_OK;
+  }
   // (with p.uni_flag both instantiations are launched and one returns at once: the name says UNI = "device")
   if (uni || !p.uni_flag)
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "classify_uni_kernel<%u, %d, %s, %d, %s>%s%s%s", u, mode, hasq ? "true" : "false",
@@ -1317,6 +1333,18 @@ int launch_classify_uni(Ctx *ctx, const ClassifyParams &p_in, uint32_t max_slots
     snprintf(ctx->last_kernel + l, sizeof(ctx->last_kernel) - l, "%s%s", p.uni_flag ? " +three-pairs-if-they-fit" : " +three-pairs", p.tile_first ? " +tiles-first" : "");
   }
   return SHK_OK;
+}
+
+// the TRO instantiations (mixed lengths through the three-pairs kernel): exact table in LDS, no qualities, U = 3 ... 5, and lengths
+// for which three pairs share a staging pass (SHK_NO_TRO=1 / SHK_NO_TRI=1: never)
+bool offsets_kernel_available(const Ctx *ctx, uint32_t max_slots, bool hasq)
+{
+  const uint32_t u = fast_kernel_unroll(max_slots);
+  return uni_kernel_available(ctx) && probe_mode(ctx->idx) == PM_LDS_TAB && ctx->idx.ltab != nullptr && !hasq && u >= 3 && u <= 5 && !ctx->env_no_tri && !ctx->env_no_tro;
+}
+bool offsets_kernel_fits(const Ctx *ctx, uint32_t max_slots, uint32_t L1, uint32_t L2)
+{
+  return tri_applies_host(L1, L2, ctx->prm.k, 64u * fast_kernel_unroll(max_slots));
 }
 
 // the CLS instantiation exists where uniform batches take the exact table in LDS

@@ -206,9 +206,19 @@ __host__ __device__ inline bool tri_applies(const uint32_t L1, const uint32_t L2
   const uint32_t ns = nk2 ? (c1 << 4) + nk2 : nk1;
   return L1 != 0u && c1 + c2 <= 21u && ns <= S;
 }
-template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false, bool TRI = false, bool TFK = false>
+// TRO (round 6; a form of TRI): a batch of MIXED read lengths (trimmed reads) through the three-pairs kernel, in the lane layout of the
+// batch's LONGEST mates, a read found by its offsets.  What lies behind a read's own end in that layout is marked invalid -- as an N
+// would be -- and that is all there is to it: ReadAnalyzer counts valid characters for `len` (ReadAnalyzer.hpp:46-49), skips every k-mer
+// with an invalid character (:64-71) and clamps the step between two hits at k (:56-62,:79-86), so a read followed by invalid
+// characters -- the mate joiner is one (FastqSplitter.hpp:63) -- has the associations of the read itself.  Slots behind a read's end
+// "exist" in the layout and are not valid k-mers: such a pair is treated as one with invalid characters (a validity window per slot).
+// The plan's structure (rounds, tiles) is the layout's for every pair; its bounds -- what the slots behind a stop cover, the threshold --
+// are computed from the pair's own two lengths (see per_pair).  No sorting by length, no pass over the offsets but
+// uniform_check_kernel's.
+template <int U, int MODE, bool HASQ, int LSL, bool UNI, bool CLS = false, bool LXM = false, bool TRI = false, bool TFK = false, bool TRO = false>
 __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE, LSL>::MIN_WAVES)) void classify_uni_kernel(const ClassifyParams P)
 {
+  static_assert(!TRO || TRI, "TRO is a form of the three-pairs instantiation");
   static_assert(!CLS || UNI, "CLS is a form of the uniform instantiation");
   static_assert(!LXM || (UNI && !CLS && pm_lds(MODE) && LSL == 21), "LXM is a form of the uniform exact-table instantiation");
   static_assert(!TRI || (UNI && !CLS && !HASQ && pm_lds(MODE) && LSL == 21 && U <= 8), "TRI is a form of the uniform exact-table instantiation without qualities");
@@ -253,10 +263,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t L1 = P.uni_L1, L2 = P.uni_L2;
   if (P.uni_flag) {
-    // every launch is made when only the device knows what the batch is like -- 0: ragged, 1: uniform, 2: by classes -- and exactly
-    // one of them works
+    // every launch is made when only the device knows what the batch is like -- 0: ragged, 1: uniform, 2: by classes, 3: mixed lengths
+    // through the three-pairs kernel (TRO) -- and exactly one of them works
     const uint32_t verdict = P.uni_flag[0];
-    if (verdict != (CLS ? 2u : (UNI ? 1u : 0u))) return;
+    if (verdict != (CLS ? 2u : (TRO ? 3u : (UNI ? 1u : 0u)))) return;
     L1 = P.uni_flag[1];
     L2 = P.uni_flag[2];
   } else if (CLS) {
@@ -300,7 +310,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     const uint4 *src = reinterpret_cast<const uint4 *>(P.lsum32);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < UG::SUM_BITS / 128; i += WAVES * 64) dst[i] = src[i];
-    if (DYN && threadIdx.x == 0) *dyn_ctr = (UNI && !CLS && !LX && P.pre_verdict) ? (uint32_t)WAVES : 2u * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave; of blocks -- see BM below --, the first)
+    if (DYN && threadIdx.x == 0) *dyn_ctr = (UNI && !CLS && !LX && P.pre_verdict) ? (uint32_t)WAVES : (TRO ? 3u : 2u) * WAVES;   // (a wave's first two turns are its own: wave, WAVES + wave -- TRO: three --; of blocks -- see BM below --, the first)
     if (DYNC && threadIdx.x == 0) *dyn_ctr = (uint32_t)WAVES;   // (its first share)
     __syncthreads();
   } else if (DYN) {
@@ -480,6 +490,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     sp_inl = reinterpret_cast<uint16_t *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pi >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pi));
     if (UNI) plan_sparse(L1, L2);
   }
+  // (TRO) the plan of the layout's own lengths, kept: a pair of those lengths takes it as a pair of a uniform batch would
+  struct { uint32_t cutE, spT, cutUb, ubJA, thr_full, spLast, spUb; } plan0{cutE, spT, cutUb, ubJA, thr_full, spLast, spUb};
   // (ragged, fixed layout) where the mates' buffers end: off[n]
   uint64_t end1 = 0, end2 = 0;
   if (FIXLAY) {
@@ -588,6 +600,46 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // that hold a byte of the mate)
   struct Raw16 { uint32_t d0, d1, d2, d3, d4, sh; };
   const uint32_t tri_guard = Lmin ? (19u + Lmin - 1u) / Lmin : 0u;
+  // (TRO) the lane's mate's offsets of the reads of triple t, asked for a third of a pass before its bases; where that mate's buffer ends
+  struct TriOff { uint64_t a, b; };
+  const uint64_t *tri_off = nullptr;
+  uint64_t tri_end = 0ull;
+  if (TRO) {
+    tri_off = (tri_cl >= ((L1 + 15u) >> 4)) ? P.off2 : P.off1;
+    tri_end = tri_act ? tri_off[n_reads] : 0ull;
+  }
+  auto tri_off_issue = [&](const uint32_t t) -> TriOff {
+    TriOff o{0ull, 0ull};
+    const uint32_t rd = 3u * t + tri_pr;
+    if (tri_act && rd < n_reads) { o.a = tri_off[rd]; o.b = tri_off[rd + 1u]; }
+    return o;
+  };
+  // (TRO) the 16 bases of the lane's chunk of the read at offsets o; lr: the read's own length of that mate (what lies behind it is the
+  // next read's: fetched like the read's own bases where the buffer allows, masked when staged)
+  auto tri_issue_at = [&](const TriOff &o, uint32_t &lr) -> Raw16 {
+    Raw16 r{0u, 0u, 0u, 0u, 0u, 0u};
+    const uint64_t d = o.b - o.a;
+    lr = d < (uint64_t)tri_Lm ? (uint32_t)d : tri_Lm;
+    if (tri_act && tri_bofs < lr) {
+      const uint8_t *sp = tri_base + o.a;
+      const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(sp) & 3u;
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(sp - sh);
+      r.sh = sh;
+      if (o.a + tri_bofs + 20ull <= tri_end) {
+        r.d0 = q[0]; r.d1 = q[1]; r.d2 = q[2]; r.d3 = q[3]; r.d4 = q[4];
+      } else {
+        const uint32_t nb = lr - tri_bofs < 16u ? lr - tri_bofs : 16u;
+        const uint32_t last = sh + nb - 1u;
+        r.d0 = q[0];
+        r.d1 = last >= 4u ? q[1] : 0u;
+        r.d2 = last >= 8u ? q[2] : 0u;
+        r.d3 = last >= 12u ? q[3] : 0u;
+        r.d4 = last >= 16u ? q[4] : 0u;
+      }
+    }
+    return r;
+  };
+  uint32_t tlr_cur = 0u;      // (TRO) the current triple's read's own length of the lane's mate
   auto tri_issue = [&](const uint32_t t) -> Raw16 {
     Raw16 r{0u, 0u, 0u, 0u, 0u, 0u};
     const uint32_t rd = 3u * t + tri_pr;
@@ -612,6 +664,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   };
   auto tri_retire = [&](Raw16 &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.d0), "+v"(r.d1), "+v"(r.d2), "+v"(r.d3), "+v"(r.d4)); };
   Raw16 t_cur{0u, 0u, 0u, 0u, 0u, 0u};
+  TriOff to_cur{0ull, 0ull};      // (TRO) the offsets of the NEXT triple, asked for a pass before its bases
 
   // DYN: the position of the workgroup's turn t (n32: behind the batch's end; the turns behind such a turn are too)
   auto dyn_pos = [&](const uint32_t t) -> uint32_t {
@@ -716,7 +769,14 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     entry_fetch(it, w_cur, q_cur);
     read = read_nxt;
   } else if (TRI) {
-    t_cur = tri_issue(it);
+    if (TRO) {
+      const TriOff o0 = tri_off_issue(it);
+      t_cur = tri_issue_at(o0, tlr_cur);
+      const uint32_t p1 = DYN ? dyn_pos((uint32_t)WAVES + wave) : (n32 - it > stride ? it + stride : n32);
+      to_cur = tri_off_issue(p1 < n32 ? p1 : n32);      // (behind the batch's end: no loads)
+    } else {
+      t_cur = tri_issue(it);
+    }
     tri_retire(t_cur);
   } else if (UNI) {
     issue(read, w_cur, q_cur);
@@ -742,6 +802,8 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   // DYN: turn q of the workgroup is position blockIdx.x * WAVES + q % WAVES + (q / WAVES) * stride of the batch -- the positions the
   // workgroup's waves walk together in the fixed order, whoever takes them
   uint32_t dyn_q = (uint32_t)WAVES + wave;
+  // (TRO draws its turns a pass earlier: a triple's OFFSETS are asked for a pass before its bases, so the turn after next has to be known)
+  uint32_t dyn_q2 = 2u * (uint32_t)WAVES + wave;
   // TF (three pairs per pass, one-gene index; P.tile_first: the host's reading of the stream): THE TILES' ROUND.  A pair is the gene's
   // as soon as k-mers of it that are in the filter are seen to cover c * len bases (sparse_first: "a lower bound that passes settles
   // a read") -- and DISJOINT k-mers cover k bases each, so up to 8 per mate, 16 per pair, one lane each, say so for THREE pairs in ONE
@@ -800,10 +862,17 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     uint32_t done_nxt = 0u;
     uint4 pl_nxt = make_uint4(0u, 0u, 0u, 0u);
     Raw16 t_nxt{0u, 0u, 0u, 0u, 0u, 0u};
+    TriOff to_nxt{0ull, 0ull};
+    uint32_t tlr_nxt = 0u;
     if (CLS) {
       if (have_nxt) entry_fetch(nxt, w_nxt, q_nxt);
     } else if (TRI) {
-      if (have_nxt) t_nxt = tri_issue(nxt);
+      if (TRO) {
+        // the next triple's bases (its offsets were asked for a pass ago) and the offsets of the triple behind it
+        if (have_nxt) t_nxt = tri_issue_at(to_cur, tlr_nxt);
+        const uint32_t nn2 = DYN ? dyn_pos(dyn_q2) : ((have_nxt && n32 - nxt > stride) ? nxt + stride : n32);
+        to_nxt = tri_off_issue(nn2 < n32 ? nn2 : n32);
+      } else if (have_nxt) t_nxt = tri_issue(nxt);
     } else if (UNI) {
       if (have_nxt) issue(nxt, w_nxt, q_nxt);
     } else {
@@ -838,6 +907,32 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     if (PRE_R && __builtin_amdgcn_readfirstlane((int)done_cur) != 0) skip = true;
     if (!skip) {
 
+    // (TRO) which pairs of the triple have a mate shorter than the layout's: bit p.  A pair of the layout's own lengths -- most pairs of
+    // a trimmed sample -- is a pair of a uniform batch: the wave's plan, nothing fetched, nothing recomputed
+    uint32_t tro_short = 0u;
+    if constexpr (TRO) {
+      const uint64_t sm = __ballot(tri_act && tlr_cur != tri_Lm);
+      const uint64_t pm = (1ull << tri_lp) - 1ull;
+#pragma unroll
+      for (uint32_t p3 = 0; p3 < 3u; ++p3) tro_short |= ((sm >> (p3 * tri_lp)) & pm) ? (1u << p3) : 0u;
+    }
+    // (the two lengths of pair p3: a mate's first chunk lane knows its read's)
+    auto tro_len = [&](const uint32_t p3, uint32_t &a, uint32_t &b) {
+      a = (uint32_t)__builtin_amdgcn_readlane((int)tlr_cur, (int)(p3 * tri_lp));
+      b = L2 ? (uint32_t)__builtin_amdgcn_readlane((int)tlr_cur, (int)(p3 * tri_lp + ((L1 + 15u) >> 4))) : 0u;
+    };
+    // (TRO) the thresholds of the triple's pairs, lane p's = pair p's: ONE pass through the double arithmetic of cov_threshold per triple
+    // that holds a short pair (per pair and use -- the tiles' round, the bounds -- it was a seventh of a short pair's cycles)
+    uint32_t tro_thr = 0u;
+    if constexpr (TRO) {
+      tro_thr = plan0.thr_full;
+      if (tro_short) {
+        uint32_t a0, b0, a1, b1, a2, b2;
+        tro_len(0u, a0, b0); tro_len(1u, a1, b1); tro_len(2u, a2, b2);
+        const uint32_t lenv = lane == 0 ? a0 + b0 : (lane == 1 ? a1 + b1 : a2 + b2);
+        tro_thr = cov_threshold(P.c, lenv);
+      }
+    }
     // ---- stage: 8 bases per lane -> the two code streams + validity (see process_read) ----
     uint32_t inv_real = 0u;   // invalid characters among the lane's bases that belong to the read
     if (TRI) {
@@ -852,7 +947,12 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         classify4(b2, c2, i2);
         classify4(b3, c3, i3);
         const uint32_t msb32 = (pack4(c0) << 24) | (pack4(c1) << 16) | (pack4(c2) << 8) | pack4(c3);      // first base in bits 31:30
-        const uint32_t inv16 = gather4(i0) | (gather4(i1) << 4) | (gather4(i2) << 8) | (gather4(i3) << 12) | tri_tail;
+        uint32_t tail16 = tri_tail;
+        if (TRO) {   // what lies behind the read's own end is invalid (the layout is the longest mates')
+          const uint32_t rem = tlr_cur > tri_bofs ? tlr_cur - tri_bofs : 0u;
+          tail16 = rem < 16u ? (0xFFFFu << rem) & 0xFFFFu : 0u;
+        }
+        const uint32_t inv16 = gather4(i0) | (gather4(i1) << 4) | (gather4(i2) << 8) | (gather4(i3) << 12) | tail16;
         uint32_t lsb32 = __builtin_bitreverse32(msb32);
         lsb32 = ((lsb32 >> 1) & 0x55555555u) | ((lsb32 & 0x55555555u) << 1);
         uint64_t *area = wbase + tri_pr * WORDS;
@@ -860,7 +960,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         fwa[tri_cl] = lsb32;
         (fwa + code_dwords_for(S))[(rcap >> 4) - 1u - tri_cl] = msb32;
         reinterpret_cast<uint16_t *>(area + code_dwords_for(S))[tri_cl] = (uint16_t)(~inv16 & 0xFFFFu);
-        inv_real = inv16 & ~tri_tail;
+        inv_real = inv16 & ~tail16;   // (TRO: a short mate is not an invalid character -- its pair's slots end where it ends: nk1e / nk2e below)
       }
     }
 #pragma unroll
@@ -942,7 +1042,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         uint32_t pay;
         const uint32_t *fwp = reinterpret_cast<const uint32_t *>(wbase + tf_area * WORDS);
         bool hit = tf_want & lx_probe(fwp, fwp + code_dwords_for(S), tf_slot, pay);
-        if (inv3[0] | inv3[1] | inv3[2]) {
+        if (inv3[0] | inv3[1] | inv3[2] | (TRO && tro_short != 0u)) {   // (TRO: a tile behind a short mate's end is no k-mer of the pair; the staging marked those bases invalid)
           // a pair with invalid characters: a tile counts when its k characters are valid (slot_valid's window); the pair's threshold
           // is at most the plan's (fewer valid bases), so the plan's is the safe one to pass
           const uint64_t *vb = reinterpret_cast<const uint64_t *>(fwp) + code_dwords_for(S);   // (the area's validity words behind its two code streams)
@@ -958,7 +1058,9 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           const uint32_t rd = 3u * it + p3;
           // (said to be uniform in so many words: taken for a per-lane value, tf_done lived in a vector register and every pair of the
           //  triple behind an exec-mask branch)
-          if (__builtin_amdgcn_readfirstlane((int)(cnt * k >= thr_full && rd < n_reads))) {
+          // (TRO: the pair's own threshold -- of its two lengths; a pair with N has a lower one still: passing this one is sufficient)
+          const uint32_t thr_p = TRO ? (uint32_t)__builtin_amdgcn_readlane((int)tro_thr, (int)p3) : thr_full;      // (TRO: thr_full is the last pair's)
+          if (__builtin_amdgcn_readfirstlane((int)((!TRO || thr_p != 0u) && cnt * k >= thr_p && rd < n_reads))) {
             if (lane == 0 && !SHK_ABL(P, 64u)) {
               sp_count[rd] = 1u;
               uint2 pk;
@@ -987,6 +1089,25 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     SHK_STAMP(10);
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
+    uint32_t nk1e = nk1, nk2e = nk2;   // (TRO: the slots of THIS pair's two mates; else the batch's)
+    if constexpr (TRO) {
+      // The plan's STRUCTURE -- which rounds first, where the tiles sit, which slots a lane holds -- stays the layout's for every pair
+      // (it is what the compiler hoists out of this loop; a plan per pair, tried, cost every pair of the batch a quarter more).  Its
+      // BOUNDS are the pair's own: what the slots behind a stop cover is a function of the pair's two lengths, and a short pair's
+      // threshold is lower -- with the layout's 172 bases behind the first two rounds no pair of 2 x 125 bp (c len = 150) would ever be cut
+      cutUb = plan0.cutUb; ubJA = plan0.ubJA; spUb = plan0.spUb; thr_full = plan0.thr_full;
+      nk1e = nk1; nk2e = nk2;
+      if ((tro_short >> tp) & 1u) {
+        uint32_t l1p, l2p;
+        tro_len(tp, l1p, l2p);
+        const uint32_t n1p = l1p >= k ? l1p - k + 1u : 0u, n2p = l2p >= k ? l2p - k + 1u : 0u;
+        nk1e = n1p; nk2e = n2p;       // (the pair's own slots: what slot_valid calls existing)
+        if (cutE < (uint32_t)U) cutUb = bases_behind(64u * cutE, n1p, n2p, P2, l1p, l2p);
+        if (JA_ROUNDS < U) ubJA = bases_behind(64u * (uint32_t)JA_ROUNDS, n1p, n2p, P2, l1p, l2p);
+        if (spT) spUb = bases_behind(128u - spT, n1p, n2p, P2, l1p, l2p);
+        thr_full = (uint32_t)__builtin_amdgcn_readlane((int)tro_thr, (int)tp);
+      }
+    }
     if (!UNI) {
       const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_cur.w);
       if (pw == PLAN_VALID) {
@@ -1068,7 +1189,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // slot pp exists and all its k characters are valid (process_read, slot_ok)
     const uint64_t kmask0 = (1ull << k) - 1ull;
     auto slot_valid = [&](const uint32_t pp) -> bool {
-      const bool exists = (pp < nk1) | ((pp - P2) < nk2);
+#ifndef SHK_TRO_EXISTS_PLAN
+#define SHK_TRO_EXISTS_PLAN 0      // (1: timing only -- the batch's slots for every pair, wrong for short ones)
+#endif
+      const bool exists = (TRO && !SHK_TRO_EXISTS_PLAN) ? ((pp < nk1e) | ((pp - P2) < nk2e)) : ((pp < nk1) | ((pp - P2) < nk2));
       if (!any_inv) return exists;
       const uint32_t V = pp >> 6, vs = pp & 63u;
       const uint64_t v0 = vbits[V], v1 = vbits[V + 1];
@@ -2034,7 +2158,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
 #endif
     if (!have_nxt) break;
-    if (TRI) { tri_retire(t_nxt); t_cur = t_nxt; }
+    if (TRI) { tri_retire(t_nxt); t_cur = t_nxt; if (TRO) { tlr_cur = tlr_nxt; to_cur = to_nxt; } }
     retire(w_nxt, q_nxt);
     if (!UNI) {
       retire_meta(r_nn);
@@ -2044,7 +2168,10 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     }
     it = nxt;
     if (PRE_R) done_cur = done_nxt;
-    if (DYN && !BM) dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
+    if (DYN && !BM) {
+      if (TRO) { dyn_q = dyn_q2; dyn_q2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take); }
+      else dyn_q = (uint32_t)__builtin_amdgcn_readfirstlane((int)dyn_take);
+    }
     read = CLS ? read_nxt : it;
 #pragma unroll
     for (int g = 0; g < G; ++g) { w_cur[g] = w_nxt[g]; q_cur[g] = q_nxt[g]; }
@@ -2073,7 +2200,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
   }   // segments
 }
 
-// rmode: 0 = the ragged instantiation, 1 = the uniform one, 2 = by classes (CLS: exact-table instantiations only)
+// rmode: 0 = the ragged instantiation, 1 = the uniform one, 2 = by classes (CLS: exact-table instantiations only), 3 = mixed lengths by offsets (TRO)
 template <int U>
 static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big, bool lx, int rmode, unsigned grid, hipStream_t s)
 {
@@ -2082,6 +2209,17 @@ static void launch_uni_u(const ClassifyParams &p, int mode, bool hasq, bool big,
       if (lx && mode == PM_LDS_TAB) {
         if (hasq) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, true, 21, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
         else hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+      }
+    }
+    return;
+  }
+  // rmode 3: a batch of mixed lengths through the three-pairs kernel by offsets (TRO): exact table in LDS, no qualities, U = 3 ... 5
+  if (rmode == 3) {
+    if constexpr (U >= 3 && U <= 5) {
+      if (lx && mode == PM_LDS_TAB && !hasq) {
+        if (p.lx_multi) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, true, true, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+        else if (p.tile_first) hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, false, true, true, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
+        else hipLaunchKernelGGL((classify_uni_kernel<U, PM_LDS_TAB, false, 21, true, false, false, true, false, true>), dim3(grid), dim3(UniGeom<U, PM_LDS_TAB, 21>::THREADS), 0, s, p);
       }
     }
     return;

@@ -266,7 +266,7 @@ static void note_verdict(Ctx *ctx, uint32_t v)
   if (char *e = strstr(ctx->last_kernel, " verdict=")) *e = 0;
   if (v) {
     const size_t l = strlen(ctx->last_kernel);
-    snprintf(ctx->last_kernel + l, sizeof(ctx->last_kernel) - l, " verdict=%s", v == 1u ? "ragged" : (v == 2u ? "uniform" : "classes"));
+    snprintf(ctx->last_kernel + l, sizeof(ctx->last_kernel) - l, " verdict=%s", v == 1u ? "ragged" : (v == 2u ? "uniform" : (v == 3u ? "classes" : "offsets")));
   }
 }
 
@@ -312,6 +312,13 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
   // read plans of a ragged batch, indexed by (l1, l2) up to the longest mates (uni_L1 / uni_L2: known, or the caller's bound for
   // a resident batch; no bound, or a loose one: 2^20 entries, of which the batch's own longest mates decide how many are used).
   // Cleared per launch, filled by the kernel.
+  // ... or, where it exists and the longest mates fit its layout, through the three-pairs kernel by offsets (TRO): no sorting.  A host
+  // batch known to be ragged (UNI_NO: uni_L1 / uni_L2 are its longest mates) takes it instead of the ragged instantiation; for a batch
+  // only the device can judge it is launched beside the others and uniform_check_kernel's verdict 3 picks it
+  const bool tro_avail = table_kernel && uni_mode != UNI_YES && offsets_kernel_available(ctx, max_slots, ctx->q8 != 0) && n < (1ull << 31);
+  const bool tro_host = tro_avail && uni_mode == UNI_NO && offsets_kernel_fits(ctx, max_slots, uni_L1, b->seq2 ? uni_L2 : 0u);
+  const bool tro_ask = tro_avail && uni_mode == UNI_ASK_DEVICE;
+  if (tro_host) by_classes = false;
   const bool with_plans = table_kernel && uni_mode != UNI_YES;
   if (by_classes) {
     // (32 bytes per pair of extra HBM: a device too full for them classifies the batch with the ragged instantiation instead)
@@ -368,6 +375,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
       SHK_HIP(ctx, hipMemsetAsync(s.d_cls_hist, 0, classes * sizeof(uint32_t), st));
     }
     if (uni_mode == UNI_ASK_DEVICE) {
+      s.p.tro = tro_ask ? 1u : 0u;
       if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
       if (by_classes && (rc = launch_class_prepass(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
       s.p.uni_flag = s.d_uni_flag;
@@ -402,8 +410,9 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
     } else {
       // what the host knows decides the launch; when only the device knows, both are made and one returns at once
       if (uni_mode != UNI_NO && (rc = launch_classify_uni(ctx, s.p, max_slots, 1, st))) return rc;
+      if ((tro_host || tro_ask) && (rc = launch_classify_uni(ctx, s.p, max_slots, 3, st))) return rc;
       if (by_classes && (rc = launch_classify_uni(ctx, s.p, max_slots, 2, st))) return rc;
-      if (uni_mode != UNI_YES && (rc = launch_classify_uni(ctx, s.p, max_slots, 0, st))) return rc;
+      if (uni_mode != UNI_YES && !tro_host && (rc = launch_classify_uni(ctx, s.p, max_slots, 0, st))) return rc;
     }
   }
   if (ctx->timing) SHK_HIP(ctx, hipEventRecord(e1, st));
@@ -627,6 +636,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     ctx->env_anchor_always = getenv("SHK_ANCHOR_ALWAYS") != nullptr;
     ctx->env_no_pre_verdict = getenv("SHK_NO_PRE_VERDICT") != nullptr;
     ctx->env_no_tri = getenv("SHK_NO_TRI") != nullptr;
+    ctx->env_no_tro = getenv("SHK_NO_TRO") != nullptr;
     ctx->env_tile_first = getenv("SHK_TILE_FIRST") ? (getenv("SHK_TILE_FIRST")[0] == '0' ? -1 : 1) : 0;
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }

@@ -144,6 +144,7 @@ struct ClassifyParams {
   const uint32_t *lsum32;    // LDS_SUM_BITS-bit summary (global copy), staged into LDS per workgroup
   uint32_t lsum_shift;
   uint32_t lx_gene;          // exact table in LDS (LSL = 21): the gene of a one-gene index (DeviceIndex::ltab_gene), else 0xFFFFFFFF
+  uint32_t tro;              // 1 = the three-pairs kernel by offsets (classify_uni.hpp, TRO) is in the stream: uniform_check_kernel's verdict 3 for a batch of mixed lengths its layout holds
   uint32_t tri;              // 1 = the three-pairs-per-pass instantiation (classify_uni.hpp, TRI) is launched beside the ordinary uniform one: the one whose lengths qualify works
   uint32_t tile_first;       // (with tri, one-gene index) 1 = a round of disjoint k-mers for the three staged pairs together in front of the pairs' own rounds (classify_uni.hpp, TF)
   uint32_t lx_multi;         // exact table in LDS of an index of SEVERAL genes: the sparse first rounds with the early decision's argument (classify_uni.hpp)
@@ -299,6 +300,8 @@ int launch_publish_results(const uint32_t *counters, uint32_t *h_counters, const
 int launch_classify_uni(Ctx *ctx, const ClassifyParams &p, uint32_t max_slots, int rmode, hipStream_t stream);   // 0 ragged, 1 uniform, 2 by classes (CLS)
 int launch_class_prepass(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);   // behind launch_uniform_check: histogram, plan, scatter
 bool class_kernel_available(const Ctx *ctx, uint32_t max_slots);
+bool offsets_kernel_available(const Ctx *ctx, uint32_t max_slots, bool hasq);
+bool offsets_kernel_fits(const Ctx *ctx, uint32_t max_slots, uint32_t L1, uint32_t L2);
 int launch_uniform_check(const ClassifyParams &p, uint32_t slot_cap, uint32_t *flag, hipStream_t stream);
 bool uni_kernel_available(const Ctx *ctx);
 // anchor_verdict.hip
@@ -341,6 +344,7 @@ struct Ctx {
   //   SHK_FORCE_GENERIC=1  every batch through classify_fast_kernel (the tests run both code paths)
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
   int env_tile_first = 0;           // SHK_TILE_FIRST=1: the tiles' round for every batch it can serve (tests); =0: never; unset: by the last batch's assigned fraction
+  bool env_no_tro = false;          // SHK_NO_TRO=1: trimmed batches never through the three-pairs kernel by offsets (the class-by-class path instead; tests, A/B timing)
   bool env_no_tri = false;          // SHK_NO_TRI=1: no three-pairs-per-pass instantiation (A/B timing, tests)
   bool env_no_pre_verdict = false;  // SHK_NO_PRE_VERDICT=1: no anchor_verdict_kernel in front of the table kernels (A/B timing, tests)
   bool env_anchor_always = false;   // SHK_ANCHOR_ALWAYS=1: the anchored extension for every batch of an index that has the reference arrays (tests, A/B timing)

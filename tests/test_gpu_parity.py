@@ -1049,12 +1049,13 @@ def test_device_resident_pipeline_submit_wait(oracle):
                         uniform_len1=150, uniform_len2=150)
 
 
-def test_device_side_uniformity_check_finds_the_one_odd_read(oracle):
+def test_device_side_uniformity_check_finds_the_one_odd_read(oracle, monkeypatch):
     """device-resident batches: uniform_check_kernel decides on the device whether every read has one length per mate (two offsets
     per thread, the third from the next lane).  One read a base shorter -- first, last, odd / even index, either side of a wave and
     of a workgroup of the check, in either mate -- makes the batch ragged; an all-equal batch with an odd read count stays uniform;
     1 %, 20 % and 50 % of the reads a few bases shorter go class by class.  The associations are the oracle's every time (a wrong
     verdict would read every later read at the wrong place)."""
+    monkeypatch.setenv("SHK_NO_TRO", "1")        # (the class-by-class path; the three-pairs kernel by offsets has its own test below)
     from shark_amd.capi import hip_memcpy_dtoh
     rng = np.random.default_rng(977)
     genes = synth.make_genes(rng, 1, 5000, 5000)
@@ -1118,6 +1119,7 @@ def test_trimmed_batches_go_class_by_class(oracle, monkeypatch, n_genes, k, q, f
     genes (the exact table without it), 2 x 90, 2 x 150 and 2 x 300 bp (the last: more classes than the
     pre-pass counts in LDS, the shortest mates take the global counters): the oracle's associations every time."""
     monkeypatch.setenv("SHK_CLS_MIN_FILL", str(fill))
+    monkeypatch.setenv("SHK_NO_TRO", "1")        # (this test: the class-by-class path; test_trimmed_batches_through_the_three_pairs_kernel: the other)
     from shark_amd.capi import hip_memcpy_dtoh
     rng = np.random.default_rng(4242 + n_genes + k)
     genes = synth.make_genes(rng, n_genes, 2500, 2600)
@@ -1161,10 +1163,73 @@ def test_trimmed_batches_go_class_by_class(oracle, monkeypatch, n_genes, k, q, f
     h.close()
 
 
-def test_class_path_follows_the_stream(oracle):
+@pytest.mark.parametrize("n_genes,k,L1,L2,c", [(1, 17, 150, 150, 0.6), (1, 17, 150, 150, 0.25), (5, 17, 150, 150, 0.6), (1, 21, 125, 125, 0.5), (1, 17, 151, 101, 0.6),
+                                                (1, 17, 150, 0, 0.6), (3, 12, 140, 140, 0.9), (1, 17, 90, 90, 0.6)])
+def test_trimmed_batches_through_the_three_pairs_kernel(oracle, monkeypatch, n_genes, k, L1, L2, c):
+    """trimmed samples on an index whose uniform batches take the exact table in LDS, without qualities, at lengths for which three
+    pairs share a staging pass: the TRO instantiations -- the three-pairs kernel in the lane layout of the batch's LONGEST mates, a read
+    found by its offsets, what lies behind its own end marked invalid (an N would do the same to ReadAnalyzer: `len` counts valid
+    characters, a k-mer with an invalid one is skipped, the step between two hits is clamped at k).  1 % ... 100 % trimmed mates, either
+    mate or both, down to shorter than k and to nothing at all, with N and chimeric pairs, one gene (sparse first round, with and
+    without the tiles' round in front) and several genes, host batches (the host knows: the kernel alone) and resident ones (the
+    device's verdict picks it): the oracle's associations, and what ran."""
+    from shark_amd.capi import hip_memcpy_dtoh
+    monkeypatch.delenv("SHK_NO_TRO", raising=False)
+    monkeypatch.delenv("SHK_NO_LDS_TABLE", raising=False)
+    rng = np.random.default_rng(5150 + n_genes + k + L1)
+    genes = synth.make_genes(rng, n_genes, 2500, 2600, share_every=3 if n_genes > 3 else 0)
+    dev = torch.device("cuda:0")
+    n = 2999
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("SHK_TILE_FIRST", tiles)
+        o, h, _ = _build_both(oracle, genes, k=k, bf_bits=1 << 30, c=c)
+        assert h.probe_mode() == "lds-table", h.probe_mode()
+        for frac in (0.01, 0.2, 0.6, 1.0):
+            base = synth.make_reads(rng, genes, n, read_len=max(L1, L2), paired=L2 > 0, on_target=0.7, n_rate=0.003)
+            chim = _chimeric_batch(rng, genes, n, L1, L2, False, with_n=True, qual=False, k_hint=k)
+
+            def mates(bt, key, off, L):
+                m = [bytes(bt[key][int(bt[off][i]):int(bt[off][i]) + L]) for i in range(n)]
+                for i in range(n):
+                    if i % 2:
+                        m[i] = bytes(chim[key][int(chim[off][i]):int(chim[off][i + 1])])[:L]
+                    if rng.random() < frac:
+                        u = rng.random()
+                        keep = 0 if u < 0.01 else (int(rng.integers(1, k)) if u < 0.05 else int(rng.integers(min(40, L // 2), L)))
+                        m[i] = m[i][:keep]
+                m[int(rng.integers(0, n))] = m[0][:L].ljust(L, b"A")[:L] if len(m[0]) else b"A" * L      # (at least one mate of the full length: the layout's)
+                return m
+            a = mates(base, "seq1", "off1", L1)
+            b = mates(base, "seq2", "off2", L2) if L2 else None
+            a[7] = (a[7] + b"A" * L1)[:L1]
+            if b is not None:
+                b[11] = (b[11] + b"C" * L2)[:L2]
+            bt = synth.batch_from_lists(a, b)
+            og, oi = o.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"])
+            hg, hi = h.classify(bt["seq1"], bt["off1"], bt["seq2"], bt["off2"])
+            assert np.array_equal(hg, og) and np.array_equal(hi, oi), ("host", frac, int(np.argmax(hg != og)))
+            assert "offsets" in h.last_kernel(), h.last_kernel()
+            assert ("+tiles-first" in h.last_kernel()) == (tiles == "1" and n_genes == 1), h.last_kernel()
+            t = {kk: (torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev) if v is not None else None) for kk, v in bt.items()}
+            pt = {kk: (v.data_ptr() if v is not None else 0) for kk, v in t.items()}
+            torch.cuda.synchronize()
+            r = h.classify_device(n, pt["seq1"], pt["off1"], pt["seq2"], pt["off2"], max_read_len=max(L1, L2))
+            goff = np.empty(n + 1, np.uint32)
+            hip_memcpy_dtoh(goff, r.gene_off, goff.nbytes)
+            gids = np.empty(int(r.n_assoc), np.uint16)
+            if len(gids):
+                hip_memcpy_dtoh(gids, r.gene_ids, gids.nbytes)
+            assert np.array_equal(goff, og) and np.array_equal(gids, oi), ("resident", frac)
+            assert "verdict=offsets" in h.last_kernel(), h.last_kernel()
+            assert int(og[-1]) > 0 or c > 0.8
+        h.close()
+
+
+def test_class_path_follows_the_stream(oracle, monkeypatch):
     """batches resident in HBM, whose lengths only the device sees: behind a uniform batch the launches of the class-by-class path are
     left out (a sequencer's stream pays nothing for them), so the first trimmed batch of a stream takes the ragged instantiation and
     the ones behind it go class by class; a uniform batch in between is still recognised.  Same associations either way."""
+    monkeypatch.setenv("SHK_NO_TRO", "1")
     from shark_amd.capi import hip_memcpy_dtoh
     rng = np.random.default_rng(77)
     genes = synth.make_genes(rng, 1, 2500, 2600)

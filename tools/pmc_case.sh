@@ -1,11 +1,13 @@
 #!/bin/bash
 # counters of the classify kernels for one landscape case: tools/pmc_case.sh <out-dir> <counter-set> -- <landscape args>
-#   counter sets: sq (instructions / waits), tcc (L2 requests, hits, misses), tcp (vector L1)
+#   counter sets: sq (instructions / waits), tcc (L2 requests, hits, misses), tcp (vector L1), ic (instruction cache), if (instruction fetch)
 export TMPDIR=/tmp
 out=$1; set_=$2; shift 3
 case $set_ in
   sq)  C="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" ;;
   tcc) C="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" ;;
+  ic)  C="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" ;;
+  if)  C="SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_SMEM" ;;
   tcp) C="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum" ;;
 esac
 rm -rf $out/pmc_$set_; mkdir -p $out
