@@ -9,6 +9,8 @@
 #include "shark_oracle.h"
 
 #include <pthread.h>
+#include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -177,18 +179,32 @@ uint64_t so_get_hash(uint64_t kmer)
 /* small_vector.hpp:25-89 -- semantics only: an appendable uint16_t list.   */
 /* (The reference's 8-byte inline/heap union is a memory optimisation.)     */
 /* ======================================================================== */
+/* (Like the reference's, a list of up to four entries lives in the eight bytes of the pointer: the 60 000-gene indices of the
+ *  scale tests hold 170 M lists, nearly all of one entry -- a heap block each made their build spend two thirds of its time in
+ *  malloc, free and the cache misses of walking them.)  cap == 0: inline. */
+#define SV_INLINE 4u
 typedef struct {
-  uint16_t *d;
+  union { uint16_t *d; uint16_t in[SV_INLINE]; } u;
   uint32_t n, cap;
 } smallvec;
 
+static inline const uint16_t *sv_data(const smallvec *v) { return v->cap ? v->u.d : v->u.in; }
+static inline uint16_t sv_back(const smallvec *v) { return sv_data(v)[v->n - 1]; }
+static inline void sv_free(smallvec *v) { if (v->cap) free(v->u.d); }
+
 static void sv_push(smallvec *v, uint16_t x) /* small_vector.hpp:44-56 */
 {
-  if (v->n == v->cap) {
-    v->cap = v->cap ? v->cap * 2 : 2;
-    v->d = (uint16_t *)realloc(v->d, v->cap * sizeof(uint16_t));
+  if (v->cap == 0) {
+    if (v->n < SV_INLINE) { v->u.in[v->n++] = x; return; }
+    uint16_t *d = (uint16_t *)malloc(2u * SV_INLINE * sizeof(uint16_t));
+    memcpy(d, v->u.in, SV_INLINE * sizeof(uint16_t));
+    v->u.d = d;
+    v->cap = 2u * SV_INLINE;
+  } else if (v->n == v->cap) {
+    v->cap *= 2;
+    v->u.d = (uint16_t *)realloc(v->u.d, v->cap * sizeof(uint16_t));
   }
-  v->d[v->n++] = x;
+  v->u.d[v->n++] = x;
 }
 
 /* ======================================================================== */
@@ -226,7 +242,7 @@ void so_bf_free(so_bf *b)
 {
   if (!b) return;
   if (b->set_index) {
-    for (uint64_t i = 0; i < b->num_kmer; ++i) free(b->set_index[i].d);
+    for (uint64_t i = 0; i < b->num_kmer; ++i) sv_free(&b->set_index[i]);
     free(b->set_index);
   }
   free(b->bf); free(b->brank); free(b->bv); free(b->select_bv); free(b->index_kmer);
@@ -267,7 +283,7 @@ void so_bf_add_to_kmer(so_bf *b, uint64_t *kmers, size_t n, int input_idx)
     int kmer_rank = (int)so_bf_rank(b, kmers[i]);
     smallvec *sv = &b->set_index[kmer_rank];
     /* :72 compares uint16_t last() with the int input_idx */
-    if (sv->n == 0 || (int)sv->d[sv->n - 1] != input_idx) sv_push(sv, (uint16_t)input_idx);
+    if (sv->n == 0 || (int)sv_back(sv) != input_idx) sv_push(sv, (uint16_t)input_idx);
   }
 }
 
@@ -310,28 +326,26 @@ int so_bf_switch_mode(so_bf *b, int new_mode)
     uint64_t tot_idx = 0;
     for (uint64_t i = 0; i < b->num_kmer; ++i) tot_idx += b->set_index[i].n;
     b->tot_idx = tot_idx;
-    /* :142-147 */
+    /* :142-147 the bit vector with a one at the last entry of every list; :148 its select support (position of the i-th one,
+     * i = 1..popcount); :156-167 the lists one behind the other -- in ONE walk over the lists (three walks of 170 M sixteen-byte
+     * entries were a tenth of the scale tests' index build) */
     b->bv = (uint64_t *)calloc(tot_idx / 64 + 2, sizeof(uint64_t));
-    int64_t pos = -1;
-    for (uint64_t i = 0; i < b->num_kmer; ++i) {
-      pos += b->set_index[i].n;
-      b->bv[pos >> 6] |= (uint64_t)1 << (pos & 63);
-    }
-    /* :148 select support: position of the i-th one, i = 1..popcount */
     b->select_bv = (uint32_t *)malloc((b->num_kmer + 2) * sizeof(uint32_t));
-    uint64_t ones = 0;
-    for (uint64_t i = 0; i < tot_idx; ++i) {
-      if ((b->bv[i >> 6] >> (i & 63)) & 1) b->select_bv[++ones] = (uint32_t)i;
-    }
-    /* :156-167 */
     b->index_kmer = (uint16_t *)malloc((tot_idx + 1) * sizeof(uint16_t));
-    uint64_t ins = 0;
+    int64_t pos = -1;
+    uint64_t ones = 0, ins = 0;
     for (uint64_t i = 0; i < b->num_kmer; ++i) {
-      memcpy(b->index_kmer + ins, b->set_index[i].d, b->set_index[i].n * sizeof(uint16_t));
-      ins += b->set_index[i].n;
+      const smallvec *sv = &b->set_index[i];
+      pos += sv->n;
+      if (pos >= 0) {                                        /* (a list is never empty: every set bit was hit by its own k-mer) */
+        if (!((b->bv[pos >> 6] >> (pos & 63)) & 1)) b->select_bv[++ones] = (uint32_t)pos;
+        b->bv[pos >> 6] |= (uint64_t)1 << (pos & 63);
+      }
+      memcpy(b->index_kmer + ins, sv_data(sv), sv->n * sizeof(uint16_t));
+      ins += sv->n;
     }
     /* :183 */
-    for (uint64_t i = 0; i < b->num_kmer; ++i) free(b->set_index[i].d);
+    for (uint64_t i = 0; i < b->num_kmer; ++i) sv_free(&b->set_index[i]);
     free(b->set_index);
     b->set_index = NULL;
     return 1;
@@ -601,10 +615,17 @@ static void *mt_pass2c(void *arg)
       const uint32_t kr = rk[i];
       if (kr < lo || kr >= hi) continue;
       smallvec *sv = &b->set_index[kr];
-      if (sv->n == 0 || (int)sv->d[sv->n - 1] != input_idx) sv_push(sv, (uint16_t)input_idx);   /* :72, literally */
+      if (sv->n == 0 || (int)sv_back(sv) != input_idx) sv_push(sv, (uint16_t)input_idx);   /* :72, literally */
     }
   }
   return NULL;
+}
+
+static double mt_now(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 static void mt_run(void *(*fn)(void *), mt_job *jobs, int nthreads)
@@ -613,6 +634,57 @@ static void mt_run(void *(*fn)(void *), mt_job *jobs, int nthreads)
   for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, fn, &jobs[t]);
   for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
   free(th);
+}
+
+/* so_bf_switch_mode(b, 1) with the popcounts of the rank support taken by several threads (an 8 GB filter is four seconds of
+ * one thread's reading): every thread counts a range of 512-bit blocks into running sums of its own, the ranges' totals are
+ * added up in order, and every thread lifts its range by what lies in front of it.  Same arrays, same values. */
+typedef struct { so_bf *b; uint64_t lo, hi, sum, base; } rank_job;
+
+static void *rank_count(void *arg)
+{
+  rank_job *j = (rank_job *)arg;
+  uint64_t acc = 0;
+  for (uint64_t blk = j->lo; blk < j->hi; ++blk) {
+    j->b->brank[blk] = acc;
+    for (int w = 0; w < 8; ++w) acc += (uint64_t)__builtin_popcountll(j->b->bf[blk * 8 + w]);
+  }
+  j->sum = acc;
+  return NULL;
+}
+
+static void *rank_lift(void *arg)
+{
+  rank_job *j = (rank_job *)arg;
+  for (uint64_t blk = j->lo; blk < j->hi; ++blk) j->b->brank[blk] += j->base;
+  return NULL;
+}
+
+static int bf_rank_support_mt(so_bf *b, int nthreads)
+{
+  if (b->mode != 0) return 0;
+  b->mode = 1;
+  const uint64_t nblk = (b->nwords + 7) / 8 + 1;            /* as so_bf_switch_mode */
+  b->brank = (uint64_t *)malloc((nblk + 1) * sizeof(uint64_t));
+  rank_job *jobs = (rank_job *)calloc((size_t)nthreads, sizeof(rank_job));
+  pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
+  const uint64_t per = (nblk + (uint64_t)nthreads - 1) / (uint64_t)nthreads;
+  for (int t = 0; t < nthreads; ++t) {
+    jobs[t].b = b;
+    jobs[t].lo = per * (uint64_t)t < nblk ? per * (uint64_t)t : nblk;
+    jobs[t].hi = jobs[t].lo + per < nblk ? jobs[t].lo + per : nblk;
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, rank_count, &jobs[t]);
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  uint64_t acc = 0;
+  for (int t = 0; t < nthreads; ++t) { jobs[t].base = acc; acc += jobs[t].sum; }
+  for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, rank_lift, &jobs[t]);
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  b->brank[nblk] = acc;
+  free(th); free(jobs);
+  b->num_kmer = so_bf_rank(b, b->size);                      /* :122 */
+  if (b->num_kmer != 0) b->set_index = (smallvec *)calloc(b->num_kmer, sizeof(smallvec));   /* :123-124 */
+  return 1;
 }
 
 int so_shark_build_mt(so_shark *s, const char *const *seqs, const uint64_t *lens, size_t n_records, int nthreads)
@@ -627,18 +699,25 @@ int so_shark_build_mt(so_shark *s, const char *const *seqs, const uint64_t *lens
     jobs[t].s = s; jobs[t].seqs = seqs; jobs[t].lens = lens; jobs[t].n_records = n_records; jobs[t].tid = t; jobs[t].nthreads = nthreads;
     jobs[t].ranks = ranks; jobs[t].cnt = cnt; jobs[t].advances = advances; jobs[t].nidx_of = nidx_of;
   }
+  const int timing = getenv("SO_TIMING") != NULL;            /* (phase times of the test infrastructure's own build, to stderr) */
+  double t0 = mt_now();
   mt_run(mt_pass1, jobs, nthreads);
-  so_bf_switch_mode(s->bf, 1);                              /* main.cpp:148 */
+  if (timing) { fprintf(stderr, "[oracle] pass 1 %.2f s\n", mt_now() - t0); t0 = mt_now(); }
+  bf_rank_support_mt(s->bf, nthreads);                      /* main.cpp:148 */
+  if (timing) { fprintf(stderr, "[oracle] rank support %.2f s\n", mt_now() - t0); t0 = mt_now(); }
   mt_run(mt_pass2a, jobs, nthreads);
+  if (timing) { fprintf(stderr, "[oracle] pass 2a %.2f s\n", mt_now() - t0); t0 = mt_now(); }
   int nidx = 0;                                             /* main.cpp:156, :165, :185 */
   for (size_t r = 0; r < n_records; ++r) {
     nidx_of[r] = nidx;
     if (advances[r]) ++nidx;
   }
   if (s->bf->num_kmer) mt_run(mt_pass2c, jobs, nthreads);
+  if (timing) { fprintf(stderr, "[oracle] pass 2c %.2f s\n", mt_now() - t0); t0 = mt_now(); }
   for (size_t r = 0; r < n_records; ++r) free(ranks[r]);
   free(ranks); free(cnt); free(advances); free(nidx_of); free(jobs);
   so_bf_switch_mode(s->bf, 2);                              /* :193 */
+  if (timing) fprintf(stderr, "[oracle] lists flattened %.2f s\n", mt_now() - t0);
   s->nidx = nidx;
   return nidx;
 }

@@ -917,9 +917,19 @@ class OffsetWriter {
         q_.pop_front();
         space_.notify_one();
       }
+      const auto t0 = std::chrono::steady_clock::now();
       write_all(j.p, j.n, j.off);
+      j.keep.reset();                                    // (the text's last owner frees it here, on this thread)
+      busy_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      bytes_ += j.n;
     }
   }
+ public:
+  // (-v) bytes written by the helper threads and the seconds they spent writing and freeing
+  uint64_t bytes_written() const { return bytes_.load(); }
+  double busy_seconds() const { return 1e-9 * (double)busy_ns_.load(); }
+ private:
+  std::atomic<uint64_t> bytes_{0}, busy_ns_{0};
   int fd_ = -1;
   bool seekable_ = false, closing_ = false;
   uint64_t off_ = 0;
@@ -1731,6 +1741,8 @@ int main(int argc, char *argv[])
     bool written = true;
     if (out1) written = w1.close() && written;
     if (out2) written = w2.close() && written;
+    if (opt.verbose)
+      std::cerr << "[shark/writers] " << w1.bytes_written() << " + " << w2.bytes_written() << " bytes, busy " << w1.busy_seconds() << " + " << w2.busy_seconds() << " s" << std::endl;
     if (!written) {
       std::cerr << "shark: cannot write the output FASTQ" << std::endl;
       return EXIT_FAILURE;
