@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <fstream>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -262,6 +263,14 @@ class Timeline {
     const double epoch = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     std::lock_guard<std::mutex> l(m_);
     std::cerr << "[shark/ms] " << what << " " << ms << " (epoch " << std::fixed << epoch << std::defaultfloat << ")" << std::endl;
+    // (SHARK_TRACE_RSS=1: the resident anonymous memory beside every stage -- what holds how much when)
+    static const bool rss = getenv("SHARK_TRACE_RSS") != nullptr;
+    if (rss) {
+      std::ifstream st("/proc/self/status");
+      std::string line;
+      while (std::getline(st, line))
+        if (line.compare(0, 8, "RssAnon:") == 0) std::cerr << "[shark/rss] " << what << " " << line.substr(8) << std::endl;
+    }
   }
 
  private:
@@ -948,9 +957,92 @@ struct FormattedSegment {
   std::string head1, head2;         // the first associated read's FASTQ records, printed unless its name equals the carried one
   std::string head_id, last_id;
   bool has_assoc = false, carries = false;
+  void reset()
+  {
+    ssv.clear(); fq1.clear(); fq2.clear(); head1.clear(); head2.clear(); head_id.clear(); last_id.clear();
+    has_assoc = carries = false;
+  }
 };
 struct FormattedBatch {
-  std::vector<FormattedSegment> segs;
+  std::vector<FormattedSegment> segs;   // (the first n of them are this batch's; the others keep their strings' memory for the next use)
+  size_t n = 0;
+};
+// The text of a batch lives from its formatter to the writer threads' last write of it; then the object -- its strings keep their
+// capacity -- goes back here for a later batch.  (Without the pool every batch's text was fresh memory: 20 GB of page faults on the
+// formatter threads and as many pages unmapped by the writer threads, each unmap stopping every thread that faults, for a sample
+// half of which is written out again.)  Never more objects than were alive at once.
+class TextPool {
+ public:
+  std::shared_ptr<FormattedBatch> get()
+  {
+    static const bool off = getenv("SHARK_NO_TEXT_POOL") != nullptr;      // (A/B timing)
+    if (off) return std::make_shared<FormattedBatch>();
+    FormattedBatch *p = nullptr;
+    {
+      std::lock_guard<std::mutex> l(st_->m);
+      if (!st_->free.empty()) { p = st_->free.back(); st_->free.pop_back(); }
+    }
+    if (!p) p = new FormattedBatch();
+    // (the deleter owns the pool's state: a text may outlive this object on an error return)
+    std::shared_ptr<State> st = st_;
+    return std::shared_ptr<FormattedBatch>(p, [st](FormattedBatch *q) {
+      std::lock_guard<std::mutex> l(st->m);
+      st->free.push_back(q);
+      st->cv.notify_one();
+    });
+  }
+  // No text will be asked for any more (every batch is formatted): from now on `threads` helpers give the pages of every text
+  // that comes back -- and of those that are back already -- to the system at once, side by side (MADV_DONTNEED takes the address
+  // space's lock shared; unmapping takes it exclusively).  What the process still holds when it ends, its end has to give back on
+  // ONE thread: 0.08 s per GB, 0.7-0.9 s for the 10 GB of a 64 M-pair sample half of which is written out again.
+  void retire(unsigned threads)
+  {
+    for (unsigned t = 0; t < std::max(1u, threads); ++t)
+      reapers_.emplace_back([st = st_] {
+        for (;;) {
+          FormattedBatch *q;
+          {
+            std::unique_lock<std::mutex> l(st->m);
+            st->cv.wait(l, [&] { return !st->free.empty() || st->done; });
+            if (st->free.empty()) return;
+            q = st->free.back();
+            st->free.pop_back();
+          }
+          for (FormattedSegment &sg : q->segs)
+            for (std::string *x : {&sg.ssv, &sg.fq1, &sg.fq2}) drop_pages(*x);
+          // (the object itself and its small strings are left to the process's end)
+        }
+      });
+  }
+  // every text is back (the writers are closed): the helpers finish what is left
+  void finish()
+  {
+    {
+      std::lock_guard<std::mutex> l(st_->m);
+      st_->done = true;
+    }
+    st_->cv.notify_all();
+    for (auto &t : reapers_) t.join();
+    reapers_.clear();
+  }
+  // (an error return in between: the helpers are joined, never destroyed while joinable; the state is left to the process's end)
+  ~TextPool() { finish(); new std::shared_ptr<State>(st_); }
+
+ private:
+  static void drop_pages(std::string &x)
+  {
+    if (x.capacity() < (1u << 20)) return;
+    const uintptr_t a = ((uintptr_t)x.data() + 4095u) & ~(uintptr_t)4095u, e = ((uintptr_t)x.data() + x.capacity()) & ~(uintptr_t)4095u;
+    if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_DONTNEED);
+  }
+  struct State {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<FormattedBatch *> free;
+    bool done = false;
+  };
+  std::shared_ptr<State> st_ = std::make_shared<State>();
+  std::vector<std::thread> reapers_;
 };
 
 class ReadOutput {
@@ -962,14 +1054,15 @@ class ReadOutput {
   void format(const ReadBatch &b, FormattedBatch &out) const
   {
     const size_t n = b.seq1.size();
-    out.segs.clear();
+    out.n = 0;
     shk::RecordFetcher f1, f2;
     // segments: [first, last) read ranges that do not cross a 50 000 boundary
     for (size_t first = 0; first < n;) {
       const uint64_t g = b.first_read + first;
       const size_t last = (size_t)std::min<uint64_t>(n, first + (50000 - g % 50000));
-      out.segs.emplace_back();
-      FormattedSegment &sg = out.segs.back();
+      if (out.n == out.segs.size()) out.segs.emplace_back();
+      FormattedSegment &sg = out.segs[out.n++];
+      sg.reset();
       sg.carries = g % 50000 != 0;                  // continues the previous batch's chunk: previd is known only when the batches are written
       std::string previd;
       bool reserved = false;
@@ -1039,7 +1132,8 @@ class ReadOutput {
   void emit(const std::shared_ptr<const FormattedBatch> &fp)
   {
     const FormattedBatch &f = *fp;
-    for (const FormattedSegment &sg : f.segs) {
+    for (size_t si = 0; si < f.n; ++si) {
+      const FormattedSegment &sg = f.segs[si];
       fwrite(sg.ssv.data(), 1, sg.ssv.size(), stdout);
       // (ReadOutput.hpp:44-48: a read's FASTQ records are printed unless its name equals the one printed just before it)
       const bool head_repeats = sg.carries && sg.has_assoc && sg.head_id == carry_;
@@ -1221,6 +1315,7 @@ int main(int argc, char *argv[])
     const unsigned hw = usable_cpus();
     unsigned io_threads = opt.nThreads > 1 ? (unsigned)opt.nThreads : std::max(1u, std::min(16u * (unsigned)n_gpus, hw));
     // (the reference opens its outputs unchecked and writes nothing to a file it could not open, main.cpp:99-106: same here)
+    TextPool text_pool;               // (in front of the writers: they hand the last texts back while they close)
     OffsetWriter w1, w2;
     // one writer thread per output file: tmpfs takes 8.7 GB/s from ONE thread writing a file and 3.6-4.6 GB/s from 2-12 threads
     // writing disjoint parts of it (tools/tmpfs_write_bench.cpp); the command with half the sample written out again, 32 M pairs,
@@ -1645,7 +1740,7 @@ int main(int argc, char *argv[])
         std::unique_ptr<ReadBatch> b;
         while (to_format.pop(b)) {
           if (b->rc == SHK_OK) {
-            std::shared_ptr<FormattedBatch> text = std::make_shared<FormattedBatch>();
+            std::shared_ptr<FormattedBatch> text = text_pool.get();
             ro.format(*b, *text);
             b->text = text;
           }
@@ -1713,6 +1808,7 @@ int main(int argc, char *argv[])
     for (auto &t : analyzers) t.join();
     to_format.close();
     for (auto &t : formatters) t.join();
+    text_pool.retire(std::min(8u, io_threads));
     fflush(stdout);
     timeline("pipeline threads joined");
     if (serial_failed) {
@@ -1741,6 +1837,7 @@ int main(int argc, char *argv[])
     bool written = true;
     if (out1) written = w1.close() && written;
     if (out2) written = w2.close() && written;
+    text_pool.finish();
     if (opt.verbose)
       std::cerr << "[shark/writers] " << w1.bytes_written() << " + " << w2.bytes_written() << " bytes, busy " << w1.busy_seconds() << " + " << w2.busy_seconds() << " s" << std::endl;
     if (!written) {
@@ -1788,6 +1885,14 @@ int main(int argc, char *argv[])
     }
   }
 
+  if (opt.verbose) {
+    // (what the process still holds is what its end has to give back: resident and peak resident memory)
+    std::ifstream st("/proc/self/status");
+    std::string line;
+    while (std::getline(st, line))
+      if (line.compare(0, 6, "VmRSS:") == 0 || line.compare(0, 6, "VmHWM:") == 0 || line.compare(0, 8, "RssAnon:") == 0 || line.compare(0, 9, "RssShmem:") == 0)
+        std::cerr << "[shark/mem] " << line << std::endl;
+  }
   if (ctx_thread.joinable()) ctx_thread.join();
   for (auto *ctx : ctxs) shk_destroy(ctx);
   timeline("contexts destroyed");

@@ -77,6 +77,9 @@ for t, run_env in [(t, e) for t in ([x for x in os.environ.get("CLI_T", "").spli
     env = dict(os.environ)
     if run_env:
         env[run_env.split("=")[0]] = run_env.split("=", 1)[1]
+    for f in ("o1.fq", "o2.fq", "out.ssv"):      # (a run that has to truncate the 10 GB files of the run before pays for freeing their pages)
+        if os.path.exists(os.path.join(td, f)):
+            os.unlink(os.path.join(td, f))
     t0 = time.time()
     with open(os.path.join(td, "out.ssv"), "wb") as so:
         r = subprocess.run([os.path.join(root, "shark_amd", "bin", "shark"), "-r", os.path.join(td, "g.fa"), "-1", os.path.join(td, "r1.fq" + SUFFIX),
@@ -88,5 +91,5 @@ for t, run_env in [(t, e) for t in ([x for x in os.environ.get("CLI_T", "").spli
     gaps = {"before_main_ms": round((ep[0] - t0) * 1e3, 1), "after_last_ms": round((t1 - ep[-1]) * 1e3, 1)} if ep else {}
     print(json.dumps({"pairs": n, "gaps": gaps, "cli_s": round(dt, 2), "reads_per_s_M": round(2 * n / dt / 1e6, 2), "rc": r.returncode, "gen_s": round(gen_s, 1),
                       "ssv_lines": sum(1 for _ in open(os.path.join(td, "out.ssv"), "rb")), "args": args, "run_env": run_env, "headers": "var" if VAR else "fixed", "gz": SUFFIX == ".gz",
-                      "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:].split(" (epoch")[0] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
+                      "rss": [l[12:].replace("\t", " ") for l in r.stderr.decode().splitlines() if l.startswith("[shark/rss]")], "mem": [l[12:] for l in r.stderr.decode().splitlines() if l.startswith("[shark/mem]")], "writers": [l for l in r.stderr.decode().splitlines() if l.startswith("[shark/writers]")], "stderr_tail": r.stderr.decode()[-500:], "timeline": [l[11:].split(" (epoch")[0] for l in r.stderr.decode().splitlines() if l.startswith("[shark/ms]")]}), flush=True)
 subprocess.run(["rm", "-rf", td])
