@@ -715,7 +715,8 @@ __global__ __launch_bounds__(1024) void uniform_check_kernel(const ClassifyParam
       // 3: mixed lengths, and the launcher has the three-pairs kernel by offsets in the stream (P.tro) for a layout of these longest
       // mates -- exactly tri_applies() of classify_uni.hpp
       uint32_t verdict = ok ? 1u : 0u;
-      if (!ok && n && any_bad && P.tro) {
+      // (P.tro == 2, SHK_FORCE_TRO=1: a batch of one length takes that kernel too -- same results; what the offsets cost on their own)
+      if (n && P.tro && ((!ok && any_bad) || (ok && P.tro == 2u))) {
         const uint32_t a1 = flag[1], a2 = P.seq2 ? flag[2] : 0u;
         const uint32_t d1 = (a1 + 15u) >> 4, d2 = (a2 + 15u) >> 4;
         const uint32_t q2 = a2 >= k ? a2 - k + 1u : 0u, q1 = a1 >= k ? a1 - k + 1u : 0u;

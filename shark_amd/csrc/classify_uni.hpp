@@ -608,9 +608,19 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     tri_off = (tri_cl >= ((L1 + 15u) >> 4)) ? P.off2 : P.off1;
     tri_end = tri_act ? tri_off[n_reads] : 0ull;
   }
+#ifndef SHK_TRO_ABL
+#define SHK_TRO_ABL 0      // (timing-only ablations of the offsets path on batches of ONE length, SHK_FORCE_TRO=1: 1 offsets by arithmetic, 2 no per-pair bounds, 4 the layout's tail)
+#endif
+#if SHK_TRO_ABL != 0 && !defined(SHK_TIMING_ONLY)
+#error "-DSHK_TRO_ABL builds a library whose results are WRONG on trimmed batches (timing-only ablation): say so with -DSHK_TIMING_ONLY as well"
+#endif
   auto tri_off_issue = [&](const uint32_t t) -> TriOff {
     TriOff o{0ull, 0ull};
     const uint32_t rd = 3u * t + tri_pr;
+    if (SHK_TRO_ABL & 1) {
+      if (tri_act && rd < n_reads) { o.a = (uint64_t)rd * tri_Lm; o.b = o.a + tri_Lm; }
+      return o;
+    }
     if (tri_act && rd < n_reads) { o.a = tri_off[rd]; o.b = tri_off[rd + 1u]; }
     return o;
   };
@@ -911,7 +921,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // a trimmed sample -- is a pair of a uniform batch: the wave's plan, nothing fetched, nothing recomputed
     uint32_t tro_short = 0u;
     if constexpr (TRO) {
-      const uint64_t sm = __ballot(tri_act && tlr_cur != tri_Lm);
+      const uint64_t sm = (SHK_TRO_ABL & 2) ? 0ull : __ballot(tri_act && tlr_cur != tri_Lm);
       const uint64_t pm = (1ull << tri_lp) - 1ull;
 #pragma unroll
       for (uint32_t p3 = 0; p3 < 3u; ++p3) tro_short |= ((sm >> (p3 * tri_lp)) & pm) ? (1u << p3) : 0u;
@@ -948,7 +958,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
         classify4(b3, c3, i3);
         const uint32_t msb32 = (pack4(c0) << 24) | (pack4(c1) << 16) | (pack4(c2) << 8) | pack4(c3);      // first base in bits 31:30
         uint32_t tail16 = tri_tail;
-        if (TRO) {   // what lies behind the read's own end is invalid (the layout is the longest mates')
+        if (TRO && !(SHK_TRO_ABL & 4)) {   // what lies behind the read's own end is invalid (the layout is the longest mates')
           const uint32_t rem = tlr_cur > tri_bofs ? tlr_cur - tri_bofs : 0u;
           tail16 = rem < 16u ? (0xFFFFu << rem) & 0xFFFFu : 0u;
         }
@@ -1059,7 +1069,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
           // (said to be uniform in so many words: taken for a per-lane value, tf_done lived in a vector register and every pair of the
           //  triple behind an exec-mask branch)
           // (TRO: the pair's own threshold -- of its two lengths; a pair with N has a lower one still: passing this one is sufficient)
-          const uint32_t thr_p = TRO ? (uint32_t)__builtin_amdgcn_readlane((int)tro_thr, (int)p3) : thr_full;      // (TRO: thr_full is the last pair's)
+          const uint32_t thr_p = (TRO && !(SHK_TRO_ABL & 2)) ? (uint32_t)__builtin_amdgcn_readlane((int)tro_thr, (int)p3) : thr_full;      // (TRO: thr_full is the last pair's)
           if (__builtin_amdgcn_readfirstlane((int)((!TRO || thr_p != 0u) && cnt * k >= thr_p && rd < n_reads))) {
             if (lane == 0 && !SHK_ABL(P, 64u)) {
               sp_count[rd] = 1u;
@@ -1090,7 +1100,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     SHK_STAMP(10);
     // ---- the bound cut: which rounds are probed first, and may the read end behind them? --------
     uint32_t nk1e = nk1, nk2e = nk2;   // (TRO: the slots of THIS pair's two mates; else the batch's)
-    if constexpr (TRO) {
+    if constexpr (TRO && !(SHK_TRO_ABL & 2)) {
       // The plan's STRUCTURE -- which rounds first, where the tiles sit, which slots a lane holds -- stays the layout's for every pair
       // (it is what the compiler hoists out of this loop; a plan per pair, tried, cost every pair of the batch a quarter more).  Its
       // BOUNDS are the pair's own: what the slots behind a stop cover is a function of the pair's two lengths, and a short pair's
@@ -1189,10 +1199,7 @@ __global__ __launch_bounds__((UniGeom<U, MODE, LSL>::THREADS), (UniGeom<U, MODE,
     // slot pp exists and all its k characters are valid (process_read, slot_ok)
     const uint64_t kmask0 = (1ull << k) - 1ull;
     auto slot_valid = [&](const uint32_t pp) -> bool {
-#ifndef SHK_TRO_EXISTS_PLAN
-#define SHK_TRO_EXISTS_PLAN 0      // (1: timing only -- the batch's slots for every pair, wrong for short ones)
-#endif
-      const bool exists = (TRO && !SHK_TRO_EXISTS_PLAN) ? ((pp < nk1e) | ((pp - P2) < nk2e)) : ((pp < nk1) | ((pp - P2) < nk2));
+      const bool exists = (TRO && !(SHK_TRO_ABL & 2)) ? ((pp < nk1e) | ((pp - P2) < nk2e)) : ((pp < nk1) | ((pp - P2) < nk2));
       if (!any_inv) return exists;
       const uint32_t V = pp >> 6, vs = pp & 63u;
       const uint64_t v0 = vbits[V], v1 = vbits[V + 1];

@@ -375,7 +375,7 @@ static int enqueue_classify(Ctx *ctx, Slot &s, const shk_batch *b, uint32_t max_
       SHK_HIP(ctx, hipMemsetAsync(s.d_cls_hist, 0, classes * sizeof(uint32_t), st));
     }
     if (uni_mode == UNI_ASK_DEVICE) {
-      s.p.tro = tro_ask ? 1u : 0u;
+      s.p.tro = tro_ask ? (ctx->env_force_tro ? 2u : 1u) : 0u;
       if ((rc = launch_uniform_check(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
       if (by_classes && (rc = launch_class_prepass(s.p, s.fast_cap, s.d_uni_flag, st))) return rc;
       s.p.uni_flag = s.d_uni_flag;
@@ -637,6 +637,7 @@ int shk_create(const shk_params *prm, shk_ctx **out)
     ctx->env_no_pre_verdict = getenv("SHK_NO_PRE_VERDICT") != nullptr;
     ctx->env_no_tri = getenv("SHK_NO_TRI") != nullptr;
     ctx->env_no_tro = getenv("SHK_NO_TRO") != nullptr;
+    ctx->env_force_tro = getenv("SHK_FORCE_TRO") != nullptr;
     ctx->env_tile_first = getenv("SHK_TILE_FIRST") ? (getenv("SHK_TILE_FIRST")[0] == '0' ? -1 : 1) : 0;
     if (const char *f = getenv("SHK_CLS_MIN_FILL")) { ctx->env_cls_min_fill = (uint32_t)strtoul(f, nullptr, 10); ctx->env_cls_always = true; }
   }

@@ -345,6 +345,7 @@ struct Ctx {
   //   SHK_BIG_LDS_ALWAYS=1 panels of 60-150 genes stay on the 128 KiB LDS summary whatever the previous batch said
   int env_tile_first = 0;           // SHK_TILE_FIRST=1: the tiles' round for every batch it can serve (tests); =0: never; unset: by the last batch's assigned fraction
   bool env_no_tro = false;          // SHK_NO_TRO=1: trimmed batches never through the three-pairs kernel by offsets (the class-by-class path instead; tests, A/B timing)
+  bool env_force_tro = false;      // SHK_FORCE_TRO=1: batches of one length through the offsets kernel as well (diagnostic: what the offsets cost)
   bool env_no_tri = false;          // SHK_NO_TRI=1: no three-pairs-per-pass instantiation (A/B timing, tests)
   bool env_no_pre_verdict = false;  // SHK_NO_PRE_VERDICT=1: no anchor_verdict_kernel in front of the table kernels (A/B timing, tests)
   bool env_anchor_always = false;   // SHK_ANCHOR_ALWAYS=1: the anchored extension for every batch of an index that has the reference arrays (tests, A/B timing)
