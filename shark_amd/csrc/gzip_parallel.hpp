@@ -646,14 +646,21 @@ class ParallelGunzip {
     // bit by bit in vain: slower than gzread, for nothing.  The second chunk's search is made here: no start there, no parallel
     // inflate (the caller falls back to gzread, constant memory, as the reference reads it).  A stream that only turns unfriendly
     // further on stays correct and bounded: a chunk that inflates far beyond its territory hands its text out in pieces.
+    // (ONE chunk without a start -- a stored or fixed-Huffman stretch near the head of an otherwise ordinary file -- does
+    //  not decide for the whole file: the search goes on through the third and fourth chunk, and the first start found anywhere
+    //  takes the file on; a chunk without a start is inflated by the chunk in front of it, as everywhere else in the file)
     {
-      gzp::Inflater t;
-      uint64_t bit = 0;
-      const bool found = find_block(t, CHUNK, std::min(n_, 2 * CHUNK), bit);
-      ch_[1]->start_bit = bit;
-      ch_[1]->search_state.store(1);
-      ch_[1]->start_known.store(found ? 1 : -1, std::memory_order_release);
-      if (!found && !getenv("SHARK_GZ_FORCE_PARALLEL")) return;
+      bool any = false;
+      for (size_t i = 1; i < std::min<size_t>(n_chunks_, 4) && !any; ++i) {
+        gzp::Inflater t;
+        uint64_t bit = 0;
+        const bool found = find_block(t, i * CHUNK, std::min(n_, (i + 1) * CHUNK), bit);
+        ch_[i]->start_bit = bit;
+        ch_[i]->search_state.store(1);
+        ch_[i]->start_known.store(found ? 1 : -1, std::memory_order_release);
+        any = found;
+      }
+      if (!any && !getenv("SHARK_GZ_FORCE_PARALLEL")) return;
     }
     usable_ = true;
     for (unsigned t = 0; t < threads_; ++t) th_.emplace_back([this] { worker(); });

@@ -827,8 +827,18 @@ int build_index(Ctx *ctx)
           const double est = (double)n_set + canon * ((double)n_set / (double)ix.bf_bits);
           uint32_t line_lg = 6;
           while (line_lg < 28 && (double)(16ull << line_lg) * load < est) ++line_lg;
+          // What the device has left decides as well: the table may take what is free less an eighth of the device's memory
+          // (at least 8 GiB) -- the batches' buffers, the arrays built behind this one, other workers' indices on the same device
+          // (`--devices 0,0,0,0` builds one per worker).  Too little for the size wanted: half of it, twice the load (0.18 measured 3 %
+          // behind 0.09), while the keys still fill at most half of the slots; else the index goes without -- it is complete without.
+          size_t mem_free = 0, mem_total = 0;
+          bool mem_known = hipMemGetInfo(&mem_free, &mem_total) == hipSuccess;
+          if (const char *e = getenv("SHK_TEST_MEM_FREE")) { mem_free = (size_t)strtoull(e, nullptr, 10); mem_total = 0; mem_known = true; }   // (tests: as if that much were free)
+          const uint64_t mem_keep = mem_known ? std::max<uint64_t>(8ull << 30, (uint64_t)mem_total / 8) : 0;
+          auto fits_device = [&](const uint32_t lg2) { return !mem_known || ((16ull << lg2) + 16) * sizeof(uint64_t) + mem_keep <= (uint64_t)mem_free; };
+          while (!fits_device(line_lg) && line_lg > 6 && (double)(16ull << (line_lg - 1)) * 0.5 >= est) --line_lg;
           const uint64_t kslots = 16ull << line_lg;
-          if ((double)kslots * 0.5 >= est && kslots * sizeof(uint64_t) <= (64ull << 30)) {
+          if ((double)kslots * 0.5 >= est && kslots * sizeof(uint64_t) <= (64ull << 30) && fits_device(line_lg)) {
             unsigned long long *d_nk = nullptr;
             uint32_t *d_kf = nullptr;
             bool have = hipMalloc((void **)&ix.ktab, (kslots + 16) * sizeof(uint64_t)) == hipSuccess &&   // (+8 buckets that stay empty: probes that need no answer)

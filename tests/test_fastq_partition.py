@@ -274,7 +274,7 @@ def _fastq_text(rng, n, L=150, real_names=True):
 
 
 @pytest.mark.parametrize("shape", ["gzip_-1", "gzip_-6", "gzip_-9", "gzip_multi_member", "stored_member_in_the_middle", "synthetic_names_constant_quality",
-                                   "huffman_only", "fixed_huffman_member", "stored_only", "sync_flush_points"])
+                                   "huffman_only", "fixed_huffman_member", "stored_only", "sync_flush_points", "stored_second_chunk"])
 def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
     """every chunking (chunks of 64 KiB ... 1 MiB of compressed bytes: hundreds of block searches, windows handed from chunk to
     chunk) and every thread count gives exactly the bytes zlib gives: the levels gzip writes, several members in one file (a new
@@ -310,6 +310,11 @@ def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
         # Z_SYNC_FLUSH every 300 000 bytes: empty stored blocks, byte-aligned block starts
         co = zlib.compressobj(6, zlib.DEFLATED, 31)
         open(path, "wb").write(b"".join(co.compress(text[i:i + 300000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(text), 300000)) + co.flush())
+    elif shape == "stored_second_chunk":
+        # 45 KB of an ordinary member, then 200 KB stored, then ordinary members: with chunks of 64 KiB the second and third chunk hold no block
+        # start, the fourth does -- the file is taken on all the same (one chunk without a start does not decide for the file)
+        a, b = 100_000, 300_000
+        open(path, "wb").write(gzip.compress(text[:a], 6) + gzip.compress(text[a:b], 0) + gzip.compress(text[b:], 6))
     elif shape == "stored_member_in_the_middle":
         a, b = len(text) // 3, len(text) // 3 + 600_000
         open(path, "wb").write(gzip.compress(text[:a], 6) + gzip.compress(text[a:b], 0) + gzip.compress(text[b:], 6))
@@ -326,6 +331,8 @@ def test_parallel_gunzip_equals_zlib(gunzip_tool, tmp_path, shape):
         assert (rc == 3 and out == b"") or (rc == 0 and out == text), (shape, chunk, threads, len(out), len(text))
         if shape == "stored_only":
             assert rc == 3
+        if shape == "stored_second_chunk" and chunk == 65536:
+            assert rc == 0
         if shape.startswith("gzip_-") or shape == "synthetic_names_constant_quality":
             assert rc == 0
         # ... and taken on regardless (SHARK_GZ_FORCE_PARALLEL=1) every shape is delivered exactly: as one text per chunk, and with

@@ -1912,6 +1912,34 @@ def test_verdict_by_mismatch_count(oracle, monkeypatch, env, L1, L2, k):
             h.close()
 
 
+def test_minimiser_table_asks_what_the_device_has_left(oracle, monkeypatch):
+    """the minimiser-bucketed table is optional and large (16 GiB on the configs[2] index): it is built at the size wanted only while the device
+    keeps an eighth of its memory (8 GiB at least) free behind it, at half the size -- twice the load -- when that fits instead, and not at all
+    otherwise; the index is complete either way and returns the same associations (SHK_TEST_MEM_FREE: as if that much were free)"""
+    for v in ("SHK_PROBE", "SHK_NO_LDS_TABLE", "SHK_FORCE_GENERIC"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("SHK_KTAB", "1")
+    monkeypatch.setenv("SHK_NO_LDS_SUMMARY", "1")
+    monkeypatch.setenv("SHK_NO_SUMMARY", "1")
+    rng = np.random.default_rng(4711)
+    genes = synth.make_genes(rng, 40, 1_500, 3_000, share_every=5)
+    batch = _sequenced_pairs(rng, genes, 600, 150, 150, False, False, 0.01, 0.001, 0.002)
+    seen = {}
+    for free in (None, (8 << 30) + (1 << 20), 1 << 20):      # plenty; room for a small table only; no room
+        if free is None:
+            monkeypatch.delenv("SHK_TEST_MEM_FREE", raising=False)
+        else:
+            monkeypatch.setenv("SHK_TEST_MEM_FREE", str(free))
+        o, h, info = _build_both(oracle, genes, k=17, bf_bits=1 << 30, c=0.6)
+        seen[free] = h.probe_mode()
+        goff, _ = _compare_classify(o, h, batch)
+        assert goff[-1] > 0
+        h.close()
+    assert seen[None] == "minimiser-table", seen
+    assert seen[1 << 20] == "table", seen                     # (no room: the position table, as for every other k)
+    assert seen[(8 << 30) + (1 << 20)] in ("minimiser-table", "table"), seen
+
+
 # ---------------------------------------------------------------------------
 # one-gene indices in LDS: the sparse first round (classify_uni.hpp, spT / sparse_first)
 # ---------------------------------------------------------------------------
