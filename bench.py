@@ -75,7 +75,8 @@ CLK_GHZ = 2.4               # max clock; a wave64 VALU instruction issues over 2
 VALU_PEAK_GINST = N_SIMD * CLK_GHZ / 2.0   # 1228.8 G wave-instructions/s
 LAUNCH_PAIRS = 10_000_000
 L2_LINE_BYTES = 128         # a memory-side request of gfx950's L2 is a 128-byte line (MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at 64 B)
-KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "anchor_verdict.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]
+KERNEL_SOURCES = ["classify_uni.hpp", "classify_uni_plan.inc", "classify_uni_loads.inc", "classify_uni_staging.inc", "classify_uni_tiles.inc", "classify_uni_rounds.inc",
+                  "classify_uni_vote.inc", "classify_uni_anchored.inc", "classify_uni_sparse.inc", "classify_common.hpp", "classify.hip", "anchor_verdict.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]
 # one rocprofv3 --pmc pass per entry (gfx950: 8 SQ slots; FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2)
 COUNTER_SETS = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],

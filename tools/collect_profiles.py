@@ -22,7 +22,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "profiles")
-KERNEL_SOURCES = ["classify_uni.hpp", "classify_common.hpp", "classify.hip", "anchor_verdict.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]    # same list as bench.py
+KERNEL_SOURCES = ["classify_uni.hpp", "classify_uni_plan.inc", "classify_uni_loads.inc", "classify_uni_staging.inc", "classify_uni_tiles.inc", "classify_uni_rounds.inc",
+                  "classify_uni_vote.inc", "classify_uni_anchored.inc", "classify_uni_sparse.inc", "classify_common.hpp", "classify.hip", "anchor_verdict.hip", "kmer_device.hpp", "shark_internal.hpp", "lds_table.hpp"]    # same list as bench.py
 
 
 def kernel_src_sha():
