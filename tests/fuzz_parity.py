@@ -73,6 +73,27 @@ def run_case(seed, bias=""):
         n_genes = int(rng.choice([2, 40, 300]))
         gl = int(rng.choice([400, 2500]))
         var_len = bool(rng.random() < 0.3)
+    elif bias == "trim":
+        # trimmed samples on indices held in LDS: the three-pairs kernel by offsets (one length class or many, mates shorter than k, single-end),
+        # the class-by-class path where the longest mates do not fit three pairs per pass
+        env.pop("SHK_PROBE", None)
+        k = int(rng.choice([5, 12, 17, 17, 21, 31]))
+        bf_bits = 1 << int(rng.integers(24, 34))
+        n_genes = int(rng.choice([1, 1, 2, 7]))
+        q = 0 if rng.random() < 0.8 else q
+        read_len = int(rng.choice([76, 100, 125, 140, 150, 151, 160, 200, 250]))
+        var_len = bool(rng.random() < 0.9)
+        env["SHK_TILE_FIRST"] = "1" if rng.random() < 0.5 else "0"
+    elif bias == "pre":
+        # references of many genes behind a position table, streams from the genes: anchor_verdict_kernel in front of the table kernels
+        # (uniform and trimmed batches), shared halves, every threshold
+        env.pop("SHK_PROBE", None)
+        k = int(rng.choice([11, 17, 17, 21, 31]))
+        bf_bits = (1 << int(rng.integers(24, 33))) if rng.random() < 0.8 else (int(rng.integers(1 << 24, 1 << 28)) | 1)
+        n_genes = int(rng.choice([40, 300]))
+        gl = int(rng.choice([400, 2500]))
+        read_len = int(rng.choice([76, 100, 150, 151, 250, 300]))
+        var_len = bool(rng.random() < 0.4)
     elif bias == "ktab":
         # the k-mer keyed, minimiser-bucketed table: k = 15 ... 17, power-of-two filters from sparse to a quarter full (dense ones
         # give the filter's false positives, which the table holds as keys of their own, a share of every read's k-mers)
@@ -97,8 +118,9 @@ def run_case(seed, bias=""):
         h = SharkHip(**kw)
         info = h.build([bytes(g) for g in genes])
         ok = info["nidx"] == nidx and info["n_set_bits"] == o.num_kmer() and np.array_equal(o.bf_words(), h.copy_bf())
+        feats = []
         n_reads = int(rng.choice([1, 63, 64, 65, 1000, 4000]))
-        b = synth.make_reads(rng, genes, n_reads, read_len=read_len, paired=paired, on_target=float(rng.choice([0.0, 0.5, 1.0])),
+        b = synth.make_reads(rng, genes, n_reads, read_len=read_len, paired=paired, on_target=float(rng.choice([0.5, 1.0, 1.0]) if bias == "pre" else rng.choice([0.0, 0.5, 1.0])),
                              n_rate=float(rng.choice([0.0, 0.002, 0.05])), lower_rate=float(rng.choice([0.0, 0.1])),
                              var_len=var_len, qual=q > 0)
         og, oi = o.classify(b["seq1"], b["off1"], b["seq2"], b["off2"], b["qual1"], b["qual2"], nthreads=4)
@@ -117,6 +139,9 @@ def run_case(seed, bias=""):
             if len(di):
                 hip_memcpy_dtoh(di, r.gene_ids, di.nbytes)
             ok = ok and np.array_equal(og, dg) and np.array_equal(oi, di)
+            lk = h.last_kernel()
+            feats = [f for f, tag in (("offsets", "offsets"), ("pre", "+pre-verdict"), ("classes", "classes"), ("tiles", "+tiles-first"), ("anch", "+anchored-extension"),
+                                      ("tri", "+three-pairs")) if tag in lk]
         # key by key: (up to 20 000 of) the reference's k-mers, each as a read of its own
         km = [g[i:i + k] for g in genes for i in range(0, len(g) - k + 1)]
         if km:
@@ -126,9 +151,9 @@ def run_case(seed, bias=""):
             khg, khi = h.classify(kb["seq1"], kb["off1"], kb["seq2"], kb["off2"], kb["qual1"], kb["qual2"])
             ok = ok and np.array_equal(kog, khg) and np.array_equal(koi, khi)
         mode = h.probe_mode()
-        desc = "seed=%d bias=%s k=%d bf=%d genes=%d len=%d%s q=%d s=%d c=%.1f reads=%d%s mode=%s set=%d assoc=%d" % (
-            seed, bias or "-", k, bf_bits, n_genes, read_len, "x2" if paired else "", q, single, c, n_reads,
-            "".join(" %s=%s" % kv for kv in sorted(env.items())), mode, info["n_set_bits"], int(og[-1]))
+        desc = "seed=%d bias=%s k=%d bf=%d genes=%d len=%d%s%s q=%d s=%d c=%.1f reads=%d%s mode=%s set=%d assoc=%d feat=%s" % (
+            seed, bias or "-", k, bf_bits, n_genes, read_len, "x2" if paired else "", "~" if var_len else "", q, single, c, n_reads,
+            "".join(" %s=%s" % kv for kv in sorted(env.items())), mode, info["n_set_bits"], int(og[-1]), "+".join(feats) or "-")
         h.close()
         o.close()
         return ok, mode, desc
@@ -142,15 +167,17 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20261003
     bias = sys.argv[3] if len(sys.argv) > 3 else ("uni" if os.environ.get("FUZZ_UNI") == "1" else "")
     t_start = time.time()
-    modes = {}
+    modes, feats = {}, {}
     for it in range(iters):
         ok, mode, desc = run_case(seed0 + it, bias)
         modes[mode] = modes.get(mode, 0) + 1
+        for f in desc.rsplit("feat=", 1)[1].split("+"):      # (what the device-resident call's kernels were: offsets, pre-verdict, classes ...)
+            feats[f] = feats.get(f, 0) + 1
         print("%4d %s %s" % (it, desc, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             print("replay: python tests/fuzz_parity.py 1 %d %s" % (seed0 + it, bias))
             sys.exit(1)
-    print("FUZZ OK: %d cases in %.0f s, probe modes %s" % (iters, time.time() - t_start, modes))
+    print("FUZZ OK: %d cases in %.0f s, probe modes %s, kernels of the resident call %s" % (iters, time.time() - t_start, modes, feats))
 
 
 if __name__ == "__main__":
