@@ -1735,7 +1735,12 @@ int main(int argc, char *argv[])
       done_cv.notify_all();
     };
     std::vector<std::thread> formatters;
-    for (unsigned f = 0; f < std::max(2u, io_threads); ++f) {
+    // half as many formatters as readers: with half the sample written out again the two writer threads are what the command waits for,
+    // and they get their cores only if the others leave some (-t 12 on a 16-core share, 16 M / 64 M pairs at 0.50 on-target: 0.84-0.85 /
+    // 2.25 s with twelve formatters, 0.75 / 2.09 s with six, 0.81 / 2.07 s with four, 1.12 s with three -- then THEY are the wait)
+    unsigned n_formatters = std::max(2u, (io_threads + 1) / 2);
+    if (const char *e = getenv("SHARK_FORMATTERS")) n_formatters = (unsigned)std::max(1, atoi(e));      // (A/B timing)
+    for (unsigned f = 0; f < n_formatters; ++f) {
       formatters.emplace_back([&] {
         std::unique_ptr<ReadBatch> b;
         while (to_format.pop(b)) {
