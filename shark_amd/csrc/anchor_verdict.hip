@@ -30,7 +30,8 @@
 namespace shk {
 
 constexpr int AV_WAVES = 4;            // waves per workgroup
-constexpr uint32_t AV_PASSES = 6;      // consecutive passes (groups of up to six pairs) a wave takes
+constexpr uint32_t AV_PASSES = 6;      // consecutive passes (groups of up to six pairs) a wave takes at least ...
+constexpr uint32_t AV_PASSES_MAX = 24; // ... and at most: large batches (ClassifyParams::av_passes, launch_anchor_verdict)
 constexpr uint32_t AV_PPW = 6;         // pairs per pass at most
 
 struct AvRaw { uint32_t d[9]; uint32_t sh; };
@@ -73,9 +74,11 @@ __global__ __launch_bounds__(AV_WAVES * 64) void anchor_verdict_kernel(const Cla
   const uint32_t n_pass = (n_reads + ppw - 1u) / ppw;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * AV_WAVES + (threadIdx.x >> 6)));
-  uint32_t g = wave * AV_PASSES;
-  if (g >= n_pass) return;
-  const uint32_t g_end = g + AV_PASSES < n_pass ? g + AV_PASSES : n_pass;
+  const uint32_t passes = P.av_passes;
+  const uint64_t g64 = (uint64_t)wave * passes;
+  if (g64 >= n_pass) return;
+  uint32_t g = (uint32_t)g64;
+  const uint32_t g_end = n_pass - g > passes ? g + passes : n_pass;
 
   // ---- lane geometry: pair of the pass, chunk of the pair, mate ----
   const uint32_t ln = (uint32_t)lane;
@@ -369,10 +372,14 @@ int launch_anchor_verdict(const ClassifyParams &p, bool pow2, bool ragged, hipSt
   const uint32_t lp = p.uni_flag ? 0u : ((p.uni_L1 + 31u) >> 5) + (((p.seq2 ? p.uni_L2 : 0u) + 31u) >> 5);
   const uint64_t ppw = p.uni_flag ? 1u : (64u / lp < AV_PPW ? 64u / lp : AV_PPW);
   const uint64_t n_pass = (p.n + ppw - 1) / ppw;
-  const uint64_t waves = (n_pass + AV_PASSES - 1) / AV_PASSES;
+  // passes per wave: six while that still gives every CU several workgroups (the command's batches of 2^16 ... 2^18 pairs), up to 24 for
+  // the large ones (10 M pairs at 100 % on-target, 1 000 / 60 000 genes: 5.56 / 8.14 ms with six, 5.43 / 8.08 with 16 or 24)
+  ClassifyParams q = p;
+  q.av_passes = (uint32_t)std::min<uint64_t>(AV_PASSES_MAX, std::max<uint64_t>(AV_PASSES, (p.n / AV_PPW) / 16384));
+  const uint64_t waves = (n_pass + q.av_passes - 1) / q.av_passes;
   const unsigned grid = (unsigned)((waves + AV_WAVES - 1) / AV_WAVES);
   const bool hasq = p.hasq != 0;
-#define AVL(P2_, HQ_, RG_) hipLaunchKernelGGL((anchor_verdict_kernel<P2_, HQ_, RG_>), dim3(grid), dim3(AV_WAVES * 64), 0, s, p)
+#define AVL(P2_, HQ_, RG_) hipLaunchKernelGGL((anchor_verdict_kernel<P2_, HQ_, RG_>), dim3(grid), dim3(AV_WAVES * 64), 0, s, q)
   if (ragged) {
     if (pow2) { if (hasq) AVL(true, true, true); else AVL(true, false, true); }
     else { if (hasq) AVL(false, true, true); else AVL(false, false, true); }

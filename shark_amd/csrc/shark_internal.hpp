@@ -172,6 +172,7 @@ struct ClassifyParams {
   const uint32_t *refext;    // DeviceIndex::refext / refmul; nullptr: no anchor_verdict_kernel
   const uint32_t *refmul;
   uint32_t pre_verdict;      // 1 = anchor_verdict_kernel ran in front of this launch: a read whose count[] is set has its result
+  uint32_t av_passes;        // anchor_verdict_kernel: consecutive passes a wave takes (set by its launcher from the batch's size)
   // the k-mer keyed, minimiser-bucketed table (DeviceIndex::ktab; classify_uni_kernel's PM_KTAB instantiations)
   const uint64_t *ktab;
   uint32_t ktab_lg, ktab_w;
